@@ -1,0 +1,121 @@
+"""ctypes binding of libdeepi2p_hip.so (include/deepi2p_hip.h).
+
+There is NO CPU fallback: if the HIP library cannot be loaded every operator raises.  PyTorch is
+used only for device memory and streams; every compute kernel is ours.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdeepi2p_hip.so")
+_lib = None
+
+c_void_p, c_int, c_float, c_double, c_ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_longlong
+
+
+class DeepI2PHipError(RuntimeError):
+    pass
+
+
+class SrcT(ctypes.Structure):
+    _fields_ = [("ptr", c_void_p), ("gidx", c_void_p), ("batch_stride", c_ll), ("row_stride", c_int),
+                ("channels", c_int), ("mode", c_int), ("group", c_int), ("pad_", c_int)]
+
+
+class EpilogueT(ctypes.Structure):
+    _fields_ = [("scale", c_void_p), ("shift", c_void_p), ("batch_bias", c_void_p), ("relu", c_int),
+                ("group_max", c_int), ("g_table", c_void_p * 2), ("g_idx", c_void_p * 2), ("g_w", c_void_p * 2),
+                ("g_nodes", c_int * 2), ("g_k", c_int)]
+
+
+SRC_DENSE, SRC_GATHER, SRC_GROUP = 0, 1, 2
+
+# name -> argtypes (all return int)
+_SIGS = {
+    "di2p_index_max_forward": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "di2p_index_max_values": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "di2p_ball_query_forward": [c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p],
+    "di2p_knn_nodes": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "di2p_cluster_stats": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "di2p_build_point_input": [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p],
+    "di2p_interpolate": [c_void_p] * 4 + [c_int] * 5 + [c_void_p],
+    "di2p_gather_neighbors": [c_void_p] * 4 + [c_int] * 4 + [c_void_p],
+    "di2p_argmax_channels": [c_void_p, c_void_p, c_int, c_int, c_int, c_ll, c_void_p],
+    "di2p_pointwise_gemm": [ctypes.POINTER(SrcT), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                            ctypes.POINTER(EpilogueT), c_void_p],
+    "di2p_batch_gemv": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
+    "di2p_attention_pool": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "di2p_conv2d": [c_void_p] * 6 + [c_int] * 10 + [c_void_p],
+    "di2p_maxpool3x3s2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "di2p_global_avgpool": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "di2p_channel_max": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "di2p_initial_guess": [c_void_p] * 5 + [c_int, c_int, c_void_p],
+    "di2p_solve_batched": [c_void_p] * 6 + [c_double, c_double, ctypes.POINTER(c_double), ctypes.POINTER(c_double)]
+                          + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_void_p],
+    "di2p_solve_batched_f32": [c_void_p] * 6 + [c_double, c_double, ctypes.POINTER(c_double), ctypes.POINTER(c_double)]
+                              + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_void_p],
+    "di2p_select_best": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "di2p_solver_residuals": [c_void_p] * 4 + [c_double, c_double, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "di2p_f32_to_f64": [c_void_p, c_void_p, c_ll, c_void_p],
+}
+EXPORTS = sorted(list(_SIGS) + ["di2p_last_error", "di2p_version"])
+
+
+def load():
+    """Load (once) and return the ctypes library; raises DeepI2PHipError if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DeepI2PHipError(
+                "libdeepi2p_hip.so not found at %s -- build it with `python -m deepi2p_amd.build` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = c_int
+        lib.di2p_last_error.restype = ctypes.c_char_p
+        lib.di2p_version.restype = c_int
+        _lib = lib
+    return _lib
+
+
+# Optional per-launch timing (bench.py): {kernel name: [(start_event, end_event, tag), ...]}.  Events are
+# recorded on the stream the kernel is launched on (torch's current stream).
+TIMED = None
+TIMED_TAG = None
+
+
+def call(name, *args):
+    lib = load()
+    rec = TIMED is not None and name in TIMED
+    if rec:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = getattr(lib, name)(*args)
+    if rec:
+        e1.record()
+        TIMED[name].append((e0, e1, TIMED_TAG))
+    if rc != 0:
+        raise DeepI2PHipError("%s failed (%d): %s" % (name, rc, lib.di2p_last_error().decode()))
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    """Mirror of the reference's CHECK_INPUT (index_max.cpp:119-121): CUDA + contiguous, RuntimeError otherwise."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("tensor must be a CUDA tensor/variable")
+        if not t.is_contiguous():
+            raise RuntimeError("tensor must be contiguous")

@@ -1,0 +1,15 @@
+#include "common.h"
+
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "ok";
+
+void di2p_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* di2p_last_error(void) { return g_err; }
+extern "C" int di2p_version(void) { return 1; }

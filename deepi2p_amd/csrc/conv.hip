@@ -1,0 +1,174 @@
+// ResNet-34 image branch kernels (models/resnet.py:56-72,125-216) for gfx950.
+//
+// conv + BN(eval) + [residual] + [ReLU] as ONE implicit-GEMM kernel on fp32 MFMA:
+//   M = Cout, N = B*OH*OW (output pixels of the whole batch, so /32 maps still fill the chip),
+//   K = Cin*KH*KW in the weight's own (ci,kh,kw) order.  The B operand is the im2col view of the
+//   NCHW input gathered on the fly (never materialised): for a fixed k the 32 lanes of an MFMA
+//   operand read 32 consecutive output pixels = consecutive input addresses (stride 1) of one
+//   input row, i.e. coalesced 128-B segments straight from the reference's own layout.
+#include "mfma_tile.h"
+
+namespace {
+
+struct LoaderWtC {
+    const float* Wt;  // [K][Cout]
+    int K, M;
+    __device__ __forceinline__ float load(int k, int m) const { return (k < K && m < M) ? Wt[(long long)k * M + m] : 0.0f; }
+};
+
+struct LoaderIm2col {
+    const float* x;
+    int Cin, H, W, OH, OW, KH, KW, stride, pad, K, Ntot;
+    const float* xb;
+    int ih0, iw0;
+    bool valid;
+    __device__ __forceinline__ void column(int j) {
+        valid = j < Ntot;
+        const int jj = valid ? j : 0;
+        const int opix = OH * OW;
+        const int b = jj / opix, pix = jj - b * opix;
+        const int oh = pix / OW, ow = pix - oh * OW;
+        xb = x + (long long)b * Cin * H * W;
+        ih0 = oh * stride - pad;
+        iw0 = ow * stride - pad;
+    }
+    __device__ __forceinline__ float load(int k) const {
+        k = __builtin_amdgcn_readfirstlane(k);
+        if (!valid || k >= K) return 0.0f;
+        const int khw = KH * KW;
+        const int ci = k / khw, rem = k - ci * khw;
+        const int kh = rem / KW, kw = rem - kh * KW;
+        const int ih = ih0 + kh, iw = iw0 + kw;
+        if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) return 0.0f;
+        return xb[((long long)ci * H + ih) * W + iw];
+    }
+};
+
+struct EpiConv {
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    float* y;
+    int Cout, opix, Ntot, relu;
+    __device__ __forceinline__ void tile(int mrow0, int j, const f32x16& acc) {
+        if (j >= Ntot) return;
+        const int b = j / opix, pix = j - b * opix;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+            if (m < Cout) {
+                const long long o = ((long long)b * Cout + m) * opix + pix;
+                float v = acc[r] * scale[m] + shift[m];
+                if (residual) v += residual[o];
+                if (relu) v = fmaxf(v, 0.0f);
+                y[o] = v;
+            }
+        }
+    }
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::THREADS) void conv2d_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* __restrict__ residual, float* __restrict__ y, int Cin,
+                                                               int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride,
+                                                               int pad, int Ntot, int relu) {
+    extern __shared__ float lds[];
+    const int K = Cin * KH * KW;
+    LoaderWtC la{Wt, K, Cout};
+    LoaderIm2col lb{x, Cin, H, W, OH, OW, KH, KW, stride, pad, K, Ntot, nullptr, 0, 0, false};
+    EpiConv ep{scale, shift, residual, y, Cout, OH * OW, Ntot, relu};
+    mfma_gemm_block<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
+}
+
+template <class Cfg>
+void launch_conv(const float* x, const float* Wt, const float* scale, const float* shift, const float* residual, float* y,
+                 int Cin, int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride, int pad, int Ntot, int relu,
+                 hipStream_t st) {
+    hipLaunchKernelGGL(conv2d_kernel<Cfg>, dim3(di2p_cdiv(Ntot, Cfg::BN), di2p_cdiv(Cout, Cfg::BM)), dim3(Cfg::THREADS),
+                       Cfg::LDS_FLOATS * sizeof(float), st, x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW,
+                       stride, pad, Ntot, relu);
+}
+
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int OH,
+                                                           int OW, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ow = (int)(i % OW);
+    const long long t = i / OW;
+    const int oh = (int)(t % OH);
+    const long long bc = t / OH;
+    const float* p = x + bc * H * W;
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+        const int ih = oh * 2 - 1 + dh;
+        if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) {
+            const int iw = ow * 2 - 1 + dw;
+            if ((unsigned)iw < (unsigned)W) m = fmaxf(m, p[(long long)ih * W + iw]);
+        }
+    }
+    y[i] = m;
+}
+
+// one wavefront per (b,c): mean over HW
+__global__ __launch_bounds__(256) void global_avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows, int HW) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* r = x + row * HW;
+    float s = 0.0f;
+    for (int n = lane; n < HW; n += 64) s += r[n];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) y[row] = s / (float)HW;
+}
+
+}  // namespace
+
+using CfgC128x128 = TileCfg<2, 2, 2, 2>;
+using CfgC64x128 = TileCfg<2, 2, 1, 2>;
+using CfgC64x64 = TileCfg<2, 2, 1, 1>;
+
+extern "C" int di2p_conv2d(const float* x, const float* Wt, const float* scale, const float* shift, const float* residual,
+                           float* y, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int relu,
+                           void* stream) {
+    DI2P_CHECK_ARG(x && Wt && scale && shift && y, "null pointer");
+    DI2P_CHECK_ARG(B >= 0 && Cin >= 1 && H >= 1 && W >= 1 && Cout >= 1 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0, "bad size");
+    if (B == 0) return 0;
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    DI2P_CHECK_ARG(OH >= 1 && OW >= 1, "empty output");
+    const long long Ntot_ll = (long long)B * OH * OW;
+    DI2P_CHECK_ARG(Ntot_ll < (1ll << 31), "too many output pixels");
+    const int Ntot = (int)Ntot_ll;
+    hipStream_t st = (hipStream_t)stream;
+    // biggest tile that still gives every CU a workgroup
+    const long long b128 = (long long)di2p_cdiv(Ntot, 128) * di2p_cdiv(Cout, 128);
+    const long long b64x128 = (long long)di2p_cdiv(Ntot, 128) * di2p_cdiv(Cout, 64);
+    if (Cout > 64 && b128 >= 512)
+        launch_conv<CfgC128x128>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, st);
+    else if (b64x128 >= 384)
+        launch_conv<CfgC64x128>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, st);
+    else
+        launch_conv<CfgC64x64>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, st);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_maxpool3x3s2(const float* x, float* y, int B, int C, int H, int W, void* stream) {
+    DI2P_CHECK_ARG(x && y && B >= 0 && C >= 1 && H >= 1 && W >= 1, "bad args");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)B * C * OH * OW;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(di2p_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, OH, OW, total);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_global_avgpool(const float* x, float* y, int B, int C, int HW, void* stream) {
+    DI2P_CHECK_ARG(x && y && B >= 0 && C >= 1 && HW >= 1, "bad args");
+    const long long rows = (long long)B * C;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(global_avgpool_kernel, dim3(di2p_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, rows, HW);
+    DI2P_RETURN_LAUNCH();
+}

@@ -1,0 +1,105 @@
+// fp32 MFMA tile engine shared by the pointwise GEMM and the implicit-GEMM convolution (gfx950).
+//
+// C[M x N] = A^T[K x M] * B[K x N], both operands "k-major" so that lanes map to consecutive m / n:
+//   * A (weights, packed once to [K][M]) and B (activations, or the on-the-fly im2col view) are
+//     staged through LDS as [BK][BM] / [BK][BN] panels, double buffered, one barrier per K-step;
+//   * v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles, A/B operand = one VGPR: lane l holds
+//     A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]) reads its operands with conflict-free ds_read_b32
+//     (both 32-lane halves read 32 consecutive floats of one panel row);
+//   * the next K-step's global loads are issued before the current step's MFMAs (register
+//     prefetch), so HBM/L2 latency hides under the 64-cycle matrix instructions;
+//   * accumulators: TM x TN tiles of 16 VGPRs per wave; C/D layout col = lane&31,
+//     row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int WM_, int WN_, int TM_, int TN_>
+struct TileCfg {
+    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+    static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 16;
+    static constexpr int THREADS = WM * WN * 64;
+    static constexpr int A_RPP = THREADS / BM, A_PASSES = BK / A_RPP;  // rows per pass / passes
+    static constexpr int B_RPP = THREADS / BN, B_PASSES = BK / B_RPP;
+    static constexpr int LDS_FLOATS = 2 * BK * (BM + BN);
+    static_assert(THREADS % BM == 0 && THREADS % BN == 0, "tile/threads mismatch");
+    static_assert(BK % A_RPP == 0 && BK % B_RPP == 0, "BK/passes mismatch");
+};
+
+// LoaderA: float load(int k, int m)             (k < K, m < M checked by the loader)
+// LoaderB: void  column(int j) ; float load(int k)
+// Epi    : void  store(int m, int j, float acc)  -- called for every valid (m, j)
+template <class Cfg, class LoaderA, class LoaderB, class Epi>
+__device__ __forceinline__ void mfma_gemm_block(float* lds, LoaderA& la, LoaderB& lb, Epi& epi, int K, int m_blk, int j_blk) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
+    float* As = lds;                 // [2][BK][BM]
+    float* Bs = lds + 2 * BK * BM;   // [2][BK][BN]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int a_col = tid % BM, a_row0 = tid / BM;
+    const int b_col = tid % BN, b_row0 = tid / BN;
+    lb.column(j_blk + b_col);
+
+    f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float ra[Cfg::A_PASSES], rb[Cfg::B_PASSES];
+    const int T = (K + BK - 1) / BK;
+
+    auto gload = [&](int t) {
+        const int k0 = t * BK;
+#pragma unroll
+        for (int p = 0; p < Cfg::A_PASSES; ++p) ra[p] = la.load(k0 + a_row0 + p * Cfg::A_RPP, m_blk + a_col);
+#pragma unroll
+        for (int p = 0; p < Cfg::B_PASSES; ++p) rb[p] = lb.load(k0 + b_row0 + p * Cfg::B_RPP);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < Cfg::A_PASSES; ++p) As[(buf * BK + a_row0 + p * Cfg::A_RPP) * BM + a_col] = ra[p];
+#pragma unroll
+        for (int p = 0; p < Cfg::B_PASSES; ++p) Bs[(buf * BK + b_row0 + p * Cfg::B_RPP) * BN + b_col] = rb[p];
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < T) gload(t + 1);
+        const float* Ab = As + buf * BK * BM + wm * Cfg::TM * 32 + l31;
+        const float* Bb = Bs + buf * BK * BN + wn * Cfg::TN * 32 + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[Cfg::TM], b[Cfg::TN];
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i) a[i] = Ab[(kk + half) * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) b[j] = Bb[(kk + half) * BN + j * 32];
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < T) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) {
+            const int jcol = j_blk + (wn * Cfg::TN + j) * 32 + l31;
+            const int mrow0 = m_blk + (wm * Cfg::TM + i) * 32 + 4 * half;
+            epi.tile(mrow0, jcol, acc[i][j]);
+        }
+}

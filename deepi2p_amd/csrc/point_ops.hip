@@ -1,0 +1,271 @@
+// Point <-> node kernels of the SO-Net point branch and the fusion head (gfx950).
+//
+// The reference materialises B x 3 x N x M broadcast tensors (1 GB each at B=32) to get distances,
+// one-hot masks and cluster sums (models/networks_pc.py:61-76) and 4-D gathers for the
+// interpolation (models/networks_united.py:76-103).  Here the M node coordinates of a frame sit in
+// LDS, one lane owns one query point and keeps its k best (distance, node) pairs in registers, so a
+// frame's whole assignment costs one coalesced read of pc and one write of the indices/weights.
+#include "common.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------
+// k nearest nodes, ascending (distance, node id).  Distance is sqrtf((dx*dx + dy*dy) + dz*dz) with
+// separately rounded operations, the same value torch.norm(dim=1) produces for 3 components.
+template <int KN>
+__global__ __launch_bounds__(256) void knn_nodes_kernel(const float* __restrict__ query, const float* __restrict__ nodes,
+                                                        int* __restrict__ idx, float* __restrict__ weights, int Nq,
+                                                        int M) {
+    extern __shared__ float s_nodes[];  // [3][M]
+    const int b = blockIdx.y;
+    const float* nb = nodes + (long long)b * 3 * M;
+    for (int i = threadIdx.x; i < 3 * M; i += blockDim.x) s_nodes[i] = nb[i];
+    __syncthreads();
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Nq) return;
+    const float* q = query + (long long)b * 3 * Nq;
+    const float qx = q[n], qy = q[Nq + n], qz = q[2 * Nq + n];
+    float bd[KN];
+    int bi[KN];
+#pragma unroll
+    for (int j = 0; j < KN; ++j) { bd[j] = __builtin_inff(); bi[j] = 0x7fffffff; }
+    for (int m = 0; m < M; ++m) {
+        const float dx = __fsub_rn(qx, s_nodes[m]), dy = __fsub_rn(qy, s_nodes[M + m]), dz = __fsub_rn(qz, s_nodes[2 * M + m]);
+        float d = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+        int i = m;
+        if (d < bd[KN - 1] || (d == bd[KN - 1] && i < bi[KN - 1])) {
+#pragma unroll
+            for (int j = 0; j < KN; ++j) {
+                const bool lt = d < bd[j] || (d == bd[j] && i < bi[j]);
+                const float td = bd[j];
+                const int ti = bi[j];
+                bd[j] = lt ? d : td;
+                bi[j] = lt ? i : ti;
+                d = lt ? td : d;
+                i = lt ? ti : i;
+            }
+        }
+    }
+    int* o = idx + ((long long)b * Nq + n) * KN;
+#pragma unroll
+    for (int j = 0; j < KN; ++j) o[j] = bi[j] == 0x7fffffff ? 0 : bi[j];
+    if (weights) {
+        float sum = bd[0];
+#pragma unroll
+        for (int j = 1; j < KN; ++j) sum = __fadd_rn(sum, bd[j]);
+        float* w = weights + ((long long)b * Nq + n) * KN;
+#pragma unroll
+        for (int j = 0; j < KN; ++j) w[j] = __fsub_rn(1.0f, __fdiv_rn(bd[j], sum));
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Cluster sums in 2^-24 m fixed point: integer adds are associative, so the result does not depend
+// on the order LDS atomics retire (bit-reproducible run to run), and it is exact for the quantised
+// inputs.  One 1024-thread workgroup per frame; the work is tiny (12N bytes).
+constexpr double kFix = 16777216.0;
+
+__global__ __launch_bounds__(1024) void cluster_stats_kernel(const float* __restrict__ pc, const int* __restrict__ knn_idx,
+                                                             int idx_stride, float* __restrict__ cluster_mean,
+                                                             float* __restrict__ mask, int* __restrict__ min_idx, int N,
+                                                             int M) {
+    extern __shared__ unsigned long long s_acc[];  // [M][4]: x,y,z (two's complement), count
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < 4 * M; i += blockDim.x) s_acc[i] = 0ull;
+    __syncthreads();
+    const float* p = pc + (long long)b * 3 * N;
+    const int* ki = knn_idx + (long long)b * N * idx_stride;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const int k = ki[(long long)n * idx_stride];
+        if (min_idx) min_idx[(long long)b * N + n] = k;
+        const long long fx = __double2ll_rn((double)p[n] * kFix);
+        const long long fy = __double2ll_rn((double)p[N + n] * kFix);
+        const long long fz = __double2ll_rn((double)p[2 * N + n] * kFix);
+        atomicAdd(&s_acc[4 * k + 0], (unsigned long long)fx);
+        atomicAdd(&s_acc[4 * k + 1], (unsigned long long)fy);
+        atomicAdd(&s_acc[4 * k + 2], (unsigned long long)fz);
+        atomicAdd(&s_acc[4 * k + 3], 1ull);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < M; k += blockDim.x) {
+        const float cnt = (float)s_acc[4 * k + 3];
+        const float den = __fadd_rn(cnt, 1e-5f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float s = (float)((double)(long long)s_acc[4 * k + c] / kFix);
+            cluster_mean[((long long)b * 3 + c) * M + k] = __fdiv_rn(s, den);
+        }
+        if (mask) mask[(long long)b * M + k] = cnt > 0.0f ? 1.0f : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void build_point_input_kernel(const float* __restrict__ pc, const float* __restrict__ intensity,
+                                                                const float* __restrict__ sn, const float* __restrict__ cluster_mean,
+                                                                const int* __restrict__ min_idx, float* __restrict__ centers,
+                                                                float* __restrict__ aug, int N, int M) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int k = min_idx[(long long)b * N + n];
+    const float* cm = cluster_mean + (long long)b * 3 * M;
+    const float* p = pc + (long long)b * 3 * N;
+    float* a = aug + (long long)b * 7 * N;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float ctr = cm[c * M + k];
+        if (centers) centers[((long long)b * 3 + c) * N + n] = ctr;
+        a[c * N + n] = __fsub_rn(p[c * N + n], ctr);
+    }
+    a[3 * N + n] = intensity[(long long)b * N + n];
+    const float* s = sn + (long long)b * 3 * N;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a[(4 + c) * N + n] = s[c * N + n];
+}
+
+// out[b,c,n] = sum_j w[b,n,j] * feats[b,c,idx[b,n,j]]   (left-to-right sum like torch.sum over k)
+__global__ __launch_bounds__(256) void interpolate_kernel(const float* __restrict__ feats, const int* __restrict__ idx,
+                                                          const float* __restrict__ weights, float* __restrict__ out, int C,
+                                                          int M, int Nq, int k) {
+    const int b = blockIdx.z;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Nq) return;
+    const int c0 = blockIdx.y * 32;
+    const int* ii = idx + ((long long)b * Nq + n) * k;
+    const float* ww = weights + ((long long)b * Nq + n) * k;
+    for (int c = c0; c < min(C, c0 + 32); ++c) {
+        const float* f = feats + ((long long)b * C + c) * M;
+        float acc = 0.0f;
+        for (int j = 0; j < k; ++j) acc = __fadd_rn(acc, __fmul_rn(ww[j], f[ii[j]]));
+        out[((long long)b * C + c) * Nq + n] = acc;
+    }
+}
+
+__global__ void gather_neighbors_kernel(const float* __restrict__ database, const float* __restrict__ query,
+                                        const int* __restrict__ idx, float* __restrict__ out, int Md, int Mq, int K) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Mq * K) return;
+    const int m = t / K;
+    const int src = idx[(long long)b * Mq * K + t];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        out[((long long)b * 3 + c) * Mq * K + t] =
+            __fsub_rn(database[((long long)b * 3 + c) * Md + src], query[((long long)b * 3 + c) * Mq + m]);
+}
+
+__global__ __launch_bounds__(256) void argmax_channels_kernel(const float* __restrict__ scores, int* __restrict__ out, int C, int N,
+                                                              long long batch_stride) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* s = scores + (long long)b * batch_stride;
+    float best = s[n];
+    int bi = 0;
+    for (int c = 1; c < C; ++c) {
+        const float v = s[(long long)c * N + n];
+        if (v > best) { best = v; bi = c; }
+    }
+    out[(long long)b * N + n] = bi;
+}
+
+// one wavefront per (b,c) row
+__global__ __launch_bounds__(256) void channel_max_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows, int N) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* r = x + row * N;
+    float m = -__builtin_inff();
+    for (int n = lane; n < N; n += 64) m = fmaxf(m, r[n]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) y[row] = m;
+}
+
+__global__ void f32_to_f64_kernel(const float* __restrict__ in, double* __restrict__ out, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = (double)in[i];
+}
+
+}  // namespace
+
+extern "C" int di2p_knn_nodes(const float* query, const float* nodes, int32_t* idx, float* weights, int B, int Nq, int M,
+                              int k, void* stream) {
+    DI2P_CHECK_ARG(B >= 0 && Nq >= 0 && M > 0, "bad size");
+    DI2P_CHECK_ARG(k >= 1 && k <= 16 && k <= M, "k must be in [1,16] and <= M");
+    DI2P_CHECK_ARG(M <= 4096, "M too large for the LDS node table");
+    if (B == 0 || Nq == 0) return 0;
+    const dim3 grid(di2p_cdiv(Nq, 256), B), block(256);
+    const size_t lds = (size_t)3 * M * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+#define DI2P_KNN_CASE(KK) \
+    case KK: hipLaunchKernelGGL(knn_nodes_kernel<KK>, grid, block, lds, st, query, nodes, idx, weights, Nq, M); break;
+    switch (k) {
+        DI2P_KNN_CASE(1) DI2P_KNN_CASE(2) DI2P_KNN_CASE(3) DI2P_KNN_CASE(4) DI2P_KNN_CASE(5) DI2P_KNN_CASE(6)
+        DI2P_KNN_CASE(7) DI2P_KNN_CASE(8) DI2P_KNN_CASE(9) DI2P_KNN_CASE(10) DI2P_KNN_CASE(11) DI2P_KNN_CASE(12)
+        DI2P_KNN_CASE(13) DI2P_KNN_CASE(14) DI2P_KNN_CASE(15) DI2P_KNN_CASE(16)
+    }
+#undef DI2P_KNN_CASE
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_cluster_stats(const float* pc, const int32_t* knn_idx, int idx_stride, float* cluster_mean, float* mask,
+                                  int32_t* min_idx, int B, int N, int M, void* stream) {
+    DI2P_CHECK_ARG(B >= 0 && N >= 0 && M > 0 && idx_stride >= 1, "bad size");
+    DI2P_CHECK_ARG(M <= 2048, "M too large");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(cluster_stats_kernel, dim3(B), dim3(1024), (size_t)4 * M * sizeof(unsigned long long),
+                       (hipStream_t)stream, pc, knn_idx, idx_stride, cluster_mean, mask, min_idx, N, M);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_build_point_input(const float* pc, const float* intensity, const float* sn, const float* cluster_mean,
+                                      const int32_t* min_idx, float* pc_centers, float* augmented, int B, int N, int M,
+                                      void* stream) {
+    DI2P_CHECK_ARG(B >= 0 && N >= 0 && M > 0, "bad size");
+    if (B == 0 || N == 0) return 0;
+    hipLaunchKernelGGL(build_point_input_kernel, dim3(di2p_cdiv(N, 256), B), dim3(256), 0, (hipStream_t)stream, pc,
+                       intensity, sn, cluster_mean, min_idx, pc_centers, augmented, N, M);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_interpolate(const float* feats, const int32_t* idx, const float* weights, float* out, int B, int C, int M,
+                                int Nq, int k, void* stream) {
+    DI2P_CHECK_ARG(B >= 0 && C >= 0 && M > 0 && Nq >= 0 && k >= 1, "bad size");
+    if (B == 0 || C == 0 || Nq == 0) return 0;
+    hipLaunchKernelGGL(interpolate_kernel, dim3(di2p_cdiv(Nq, 256), di2p_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream,
+                       feats, idx, weights, out, C, M, Nq, k);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_gather_neighbors(const float* database, const float* query, const int32_t* idx, float* out, int B, int Md,
+                                     int Mq, int K, void* stream) {
+    DI2P_CHECK_ARG(B >= 0 && Md > 0 && Mq >= 0 && K >= 1, "bad size");
+    if (B == 0 || Mq == 0) return 0;
+    hipLaunchKernelGGL(gather_neighbors_kernel, dim3(di2p_cdiv((long long)Mq * K, 256), B), dim3(256), 0,
+                       (hipStream_t)stream, database, query, idx, out, Md, Mq, K);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_argmax_channels(const float* scores, int32_t* out, int B, int C, int N, long long batch_stride, void* stream) {
+    DI2P_CHECK_ARG(B >= 0 && C >= 1 && N >= 0, "bad size");
+    if (B == 0 || N == 0) return 0;
+    if (batch_stride <= 0) batch_stride = (long long)C * N;
+    hipLaunchKernelGGL(argmax_channels_kernel, dim3(di2p_cdiv(N, 256), B), dim3(256), 0, (hipStream_t)stream, scores, out, C, N, batch_stride);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_channel_max(const float* x, float* y, int B, int C, int N, void* stream) {
+    DI2P_CHECK_ARG(B >= 0 && C >= 0 && N >= 1, "bad size");
+    const long long rows = (long long)B * C;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(channel_max_kernel, dim3(di2p_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, rows, N);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_f32_to_f64(const float* in, double* out, long long n, void* stream) {
+    if (n <= 0) return 0;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(f32_to_f64_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, n);
+    DI2P_RETURN_LAUNCH();
+}

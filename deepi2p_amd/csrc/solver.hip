@@ -1,0 +1,667 @@
+// Batched "inverse camera projection" pose solver for gfx950 -- replaces Ceres + the reference's
+// 60-process restart fan-out.
+//
+// Replaces evaluation/frustum_reg/src/registration.cpp:9-186 (solvePGivenK), the four auto-diff
+// functors registration_2d.hpp:35-69,107-129 / registration_3d.hpp:35-68,106-127, and the process
+// waves of evaluation/registration_lsq.py:142-186.
+//
+// One WAVEFRONT per pose hypothesis; a 256-thread workgroup holds 4 hypotheses of one frame so they
+// share the frame's points in L1/L2.  Each lane strides over the points, evaluates residual and
+// ANALYTIC Jacobian rows (the reference differentiates with Jets), robustifies with the Cauchy
+// corrector, and accumulates its share of J^T J (upper triangle), J^T r and the cost in fp64
+// registers; a 6-step xor-butterfly leaves every lane with bit-identical sums, so the whole
+// Levenberg-Marquardt state machine (damping, box projection, Armijo search, accept/reject,
+// termination tests) runs redundantly on all lanes with wave-uniform control flow and needs no LDS
+// and no barriers.  Every trial point is evaluated with its normal equations in the same pass, so an
+// accepted step costs ONE sweep over the points.  The algorithm statement is the oracle's
+// (oracle/frustum_lm.cpp); DESIGN.md lists it step by step.
+#include "common.h"
+
+#include <float.h>
+#include <math.h>
+
+namespace {
+
+enum { T_MAX_ITER = 0, T_GRADIENT = 1, T_PARAMETER = 2, T_FUNCTION = 3, T_RADIUS = 4, T_INVALID = 5, T_EVAL_FAIL = 6 };
+
+struct Cam { double fx, fy, cx, cy, H1, W1; };
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int NP> struct Tri { static constexpr int N = NP * (NP + 1) / 2; };
+template <int NP> __device__ __forceinline__ constexpr int tri(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
+
+// Rotation of the current iterate and its parameter derivatives, computed once per sweep.
+template <int NP>
+struct Rot {
+    double R[9];        // row-major
+    double dR[3][9];    // NP == 6 only: dR/dw_i
+};
+
+__device__ __forceinline__ void skew_add(double* M, double s, double ux, double uy, double uz) {  // M += s*[u]x
+    M[1] -= s * uz; M[2] += s * uy; M[3] += s * uz; M[5] -= s * ux; M[6] -= s * uy; M[7] += s * ux;
+}
+
+template <int NP>
+__device__ __forceinline__ void make_rot(const double* x, Rot<NP>& r) {
+    if (NP == 4) {
+        // AngleAxisRotatePoint with axis (0,theta,0): Ry(theta); first-order branch for theta^2 <= eps
+        const double th = x[0];
+        double c, s;
+        if (th * th > DBL_EPSILON) { c = cos(th); s = sin(th); } else { c = 1.0; s = th; }
+        r.R[0] = c; r.R[1] = 0; r.R[2] = s; r.R[3] = 0; r.R[4] = 1; r.R[5] = 0; r.R[6] = -s; r.R[7] = 0; r.R[8] = c;
+    } else {
+        const double wx = x[0], wy = x[1], wz = x[2];
+        const double t2 = wx * wx + wy * wy + wz * wz;
+        for (int i = 0; i < 9; ++i) { r.R[i] = 0; r.dR[0][i] = r.dR[1][i] = r.dR[2][i] = 0; }
+        if (t2 > DBL_EPSILON) {
+            const double th = sqrt(t2), ux = wx / th, uy = wy / th, uz = wz / th;
+            const double c = cos(th), s = sin(th), oc = 1.0 - c;
+            const double u[3] = {ux, uy, uz};
+            r.R[0] = r.R[4] = r.R[8] = c;
+            skew_add(r.R, s, ux, uy, uz);
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) r.R[a * 3 + b] += oc * u[a] * u[b];
+            for (int i = 0; i < 3; ++i) {
+                double du[3];
+                for (int j = 0; j < 3; ++j) du[j] = ((i == j ? 1.0 : 0.0) - u[i] * u[j]) / th;
+                double* D = r.dR[i];
+                D[0] = D[4] = D[8] = -s * u[i];
+                skew_add(D, c * u[i], ux, uy, uz);
+                skew_add(D, s, du[0], du[1], du[2]);
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) D[a * 3 + b] += s * u[i] * u[a] * u[b] + oc * (du[a] * u[b] + u[a] * du[b]);
+            }
+        } else {  // pt + w x pt
+            r.R[0] = r.R[4] = r.R[8] = 1.0;
+            skew_add(r.R, 1.0, wx, wy, wz);
+            skew_add(r.dR[0], 1.0, 1, 0, 0);
+            skew_add(r.dR[1], 1.0, 0, 1, 0);
+            skew_add(r.dR[2], 1.0, 0, 0, 1);
+        }
+    }
+}
+
+// One sweep over the frame's points: cost (1/2 sum rho), and if FULL the loss-corrected J^T r and
+// J^T J.  Returns false (wave-uniform) if anything was non-finite.
+template <int NP, bool FULL, typename PT>
+__device__ __forceinline__ bool sweep(const PT* __restrict__ px_, const PT* __restrict__ py_, const PT* __restrict__ pz_,
+                                      const int* __restrict__ labels, int N, const Cam& k, const double* x, double& cost_out,
+                                      double* g, double* A) {
+    constexpr int TOFF = NP == 4 ? 1 : 3;
+    Rot<NP> rot;
+    make_rot<NP>(x, rot);
+    const double tx = x[TOFF], ty = x[TOFF + 1], tz = x[TOFF + 2];
+    const int lane = threadIdx.x & 63;
+    double cost = 0.0;
+    double lg[NP], lA[Tri<NP>::N];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) lg[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < Tri<NP>::N; ++i) lA[i] = 0.0;
+    bool bad = false;
+    const double hw = k.W1 * 0.5, hh = k.H1 * 0.5;
+    for (int n = lane; n < N; n += 64) {
+        const int lab = labels[n];
+        if (lab != 0 && lab != 1) continue;
+        const double X = (double)px_[n], Y = (double)py_[n], Z = (double)pz_[n];
+        double qx, qy, qz;
+        if (NP == 4) {
+            qx = rot.R[0] * X + rot.R[2] * Z; qy = Y; qz = rot.R[6] * X + rot.R[8] * Z;
+        } else {
+            qx = rot.R[0] * X + rot.R[1] * Y + rot.R[2] * Z;
+            qy = rot.R[3] * X + rot.R[4] * Y + rot.R[5] * Z;
+            qz = rot.R[6] * X + rot.R[7] * Y + rot.R[8] * Z;
+        }
+        const double p0 = qx + tx, p1 = qy + ty, p2 = qz + tz;
+        const double pix_x = p0 * k.fx / p2 + k.cx;
+        const double pix_y = p1 * k.fy / p2 + k.cy;
+        // residual rows as (value, d/dpix_x, d/dpix_y, d/dp2 direct) -- at most 3 rows
+        double rv[3], sx[3], sy[3], sz[3];
+        int nr;
+        if (lab == 1) {
+            nr = 3;
+            const double a0 = -pix_x, b0 = pix_x - k.W1;
+            rv[0] = (a0 < 0.0 ? 0.0 : a0) + (b0 < 0.0 ? 0.0 : b0);
+            sx[0] = (a0 < 0.0 ? 0.0 : -1.0) + (b0 < 0.0 ? 0.0 : 1.0); sy[0] = 0.0; sz[0] = 0.0;
+            const double a1 = -pix_y, b1 = pix_y - k.H1;
+            rv[1] = (a1 < 0.0 ? 0.0 : a1) + (b1 < 0.0 ? 0.0 : b1);
+            sy[1] = (a1 < 0.0 ? 0.0 : -1.0) + (b1 < 0.0 ? 0.0 : 1.0); sx[1] = 0.0; sz[1] = 0.0;
+            const double a2 = -p2;
+            rv[2] = (a2 < 0.0 ? 0.0 : a2) * 100.0;
+            sz[2] = a2 < 0.0 ? 0.0 : -100.0; sx[2] = 0.0; sy[2] = 0.0;
+        } else {
+            nr = 1;
+            const double ex = pix_x - hw, ey = pix_y - hh;
+            const double dx = hw - fabs(ex), dy = hh - fabs(ey);
+            // fmax(v,0)/v is NaN at v == 0 (registration_2d.hpp:53,56,58): evaluation failure
+            if (dx == 0.0 || dy == 0.0 || p2 == 0.0) bad = true;
+            const bool act = dx > 0.0 && dy > 0.0 && p2 > 0.0;
+            rv[0] = act ? dx + dy : 0.0;
+            sx[0] = act ? (ex < 0.0 ? 1.0 : -1.0) : 0.0;
+            sy[0] = act ? (ey < 0.0 ? 1.0 : -1.0) : 0.0;
+            sz[0] = 0.0;
+        }
+        double s = 0.0;
+        for (int i = 0; i < nr; ++i) s += rv[i] * rv[i];
+        if (!isfinite(s) || !isfinite(pix_x) || !isfinite(pix_y)) bad = true;
+        bool any_j = false;
+        for (int i = 0; i < nr; ++i) any_j |= (sx[i] != 0.0) | (sy[i] != 0.0) | (sz[i] != 0.0);
+        if (s > 0.0) cost += 0.5 * log1p(s);
+        if (FULL && any_j) {
+            const double rho1 = 1.0 / (1.0 + s);
+            const double iz = 1.0 / p2;
+            const double ax = k.fx * iz, bx = -k.fx * p0 * iz * iz;   // dpix_x = ax*dp0 + bx*dp2
+            const double ay = k.fy * iz, by = -k.fy * p1 * iz * iz;   // dpix_y = ay*dp1 + by*dp2
+            // dp/dparam : rotation part
+            double dp0[NP], dp1[NP], dp2[NP];
+            if (NP == 4) {
+                dp0[0] = qz; dp1[0] = 0.0; dp2[0] = -qx;      // d/dtheta of Ry(theta) x  (first-order branch: (Z, 0, -X) = same form)
+                if (!(x[0] * x[0] > DBL_EPSILON)) { dp0[0] = Z; dp2[0] = -X; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    dp0[i] = rot.dR[i][0] * X + rot.dR[i][1] * Y + rot.dR[i][2] * Z;
+                    dp1[i] = rot.dR[i][3] * X + rot.dR[i][4] * Y + rot.dR[i][5] * Z;
+                    dp2[i] = rot.dR[i][6] * X + rot.dR[i][7] * Y + rot.dR[i][8] * Z;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { dp0[TOFF + i] = i == 0 ? 1.0 : 0.0; dp1[TOFF + i] = i == 1 ? 1.0 : 0.0; dp2[TOFF + i] = i == 2 ? 1.0 : 0.0; }
+            for (int i = 0; i < nr; ++i) {
+                if (sx[i] == 0.0 && sy[i] == 0.0 && sz[i] == 0.0) continue;
+                double J[NP];
+#pragma unroll
+                for (int a = 0; a < NP; ++a) {
+                    const double dpx = ax * dp0[a] + bx * dp2[a];
+                    const double dpy = ay * dp1[a] + by * dp2[a];
+                    J[a] = sx[i] * dpx + sy[i] * dpy + sz[i] * dp2[a];
+                    if (!isfinite(J[a])) bad = true;
+                }
+                const double wr = rho1 * rv[i];
+#pragma unroll
+                for (int a = 0; a < NP; ++a) {
+                    lg[a] += wr * J[a];
+                    const double wa = rho1 * J[a];
+#pragma unroll
+                    for (int b = 0; b <= a; ++b) lA[a * (a + 1) / 2 + b] += wa * J[b];
+                }
+            }
+        }
+    }
+    cost_out = wave_sum(cost);
+    if (FULL) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) g[i] = wave_sum(lg[i]);
+#pragma unroll
+        for (int i = 0; i < Tri<NP>::N; ++i) A[i] = wave_sum(lA[i]);
+    }
+    const bool any_bad = __any(bad) != 0;
+    return !any_bad && isfinite(cost_out);
+}
+
+template <int NP>
+__device__ __forceinline__ bool chol_solve(const double* Mtri, const double* rhs, double* y) {
+    double L[Tri<NP>::N];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double s = Mtri[i * (i + 1) / 2 + j];
+#pragma unroll
+            for (int q = 0; q < j; ++q) s -= L[i * (i + 1) / 2 + q] * L[j * (j + 1) / 2 + q];
+            if (i == j) {
+                if (!(s > 0.0) || !isfinite(s)) return false;
+                L[i * (i + 1) / 2 + i] = sqrt(s);
+            } else {
+                L[i * (i + 1) / 2 + j] = s / L[j * (j + 1) / 2 + j];
+            }
+        }
+    }
+    double z[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        double s = rhs[i];
+#pragma unroll
+        for (int q = 0; q < i; ++q) s -= L[i * (i + 1) / 2 + q] * z[q];
+        z[i] = s / L[i * (i + 1) / 2 + i];
+    }
+#pragma unroll
+    for (int i = NP - 1; i >= 0; --i) {
+        double s = z[i];
+#pragma unroll
+        for (int q = i + 1; q < NP; ++q) s -= L[q * (q + 1) / 2 + i] * y[q];
+        y[i] = s / L[i * (i + 1) / 2 + i];
+    }
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) ok &= isfinite(y[i]);
+    return ok;
+}
+
+template <int NP>
+__device__ __forceinline__ void plus_proj(const double* x, const double* d, double t, const double* lb, const double* ub, double* out) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) out[i] = fmin(fmax(x[i] + t * d[i], lb[i]), ub[i]);
+}
+
+template <int NP>
+__device__ __forceinline__ double grad_max_norm(const double* x, const double* g, const double* lb, const double* ub) {
+    double m = 0.0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const double pr = fmin(fmax(x[i] - g[i], lb[i]), ub[i]);
+        m = fmax(m, fabs(x[i] - pr));
+    }
+    return m;
+}
+
+struct Bounds { double lb[3], ub[3]; };
+
+template <int NP, typename PT>
+__global__ __launch_bounds__(256) void solve_kernel(const PT* __restrict__ points, const int* __restrict__ labels,
+                                                    const double* __restrict__ Kmat, const double* __restrict__ init_y,
+                                                    const double* __restrict__ init_T, const double* __restrict__ yaw0,
+                                                    double H, double W, Bounds bnd, int max_iter, int R, int N,
+                                                    double* __restrict__ params_out, double* __restrict__ cost_out,
+                                                    int* __restrict__ iters_out) {
+    constexpr int TOFF = NP == 4 ? 1 : 3;
+    constexpr int NT = Tri<NP>::N;
+    const int f = blockIdx.y;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= R) return;  // whole wave exits
+    const PT* px = points + (long long)f * 3 * N;
+    const PT* py = px + N;
+    const PT* pz = py + N;
+    const int* lab = labels + (long long)f * N;
+    const double* Kf = Kmat + (long long)f * 9;
+    const Cam k{Kf[0], Kf[4], Kf[2], Kf[5], H - 1.0, W - 1.0};
+
+    double lb[NP], ub[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { lb[i] = -DBL_MAX; ub[i] = DBL_MAX; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { lb[TOFF + i] = bnd.lb[i]; ub[TOFF + i] = bnd.ub[i]; }
+
+    double x[NP];
+    const long long hr = (long long)f * R + r;
+    const double y0 = init_y[hr] + (yaw0 ? yaw0[f] : 0.0);
+    if (NP == 4) { x[0] = y0; } else { x[0] = 0.0; x[1] = y0; x[2] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) x[TOFF + i] = init_T[hr * 3 + i];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) x[i] = fmin(fmax(x[i], lb[i]), ub[i]);
+
+    const double kMinDiag = 1e-6, kMaxDiag = 1e32, kMaxRadius = 1e16, kMinRadius = 1e-32;
+    const double kMinRelDec = 1e-3, kFuncTol = 1e-6, kGradTol = 1e-10, kParamTol = 1e-8;
+
+    double cost, g[NP], A[NT];
+    int iter = 0;
+    bool ok = sweep<NP, true, PT>(px, py, pz, lab, N, k, x, cost, g, A);
+    if (ok) {
+        double S[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) S[i] = 1.0 / (1.0 + sqrt(A[i * (i + 1) / 2 + i]));
+        double gmax = grad_max_norm<NP>(x, g, lb, ub);
+        double radius = 1e4, decrease = 2.0;
+        bool reuse_diag = false;
+        double diag[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) diag[i] = 0.0;
+        int invalid_run = 0;
+        for (;;) {
+            if (iter >= max_iter) break;
+            if (gmax <= kGradTol) break;
+            if (radius <= kMinRadius) break;
+            ++iter;
+            double As[NT], gs[NP], M[NT], rhs[NP], ds[NP];
+#pragma unroll
+            for (int a = 0; a < NP; ++a) {
+                gs[a] = S[a] * g[a];
+#pragma unroll
+                for (int b = 0; b <= a; ++b) As[a * (a + 1) / 2 + b] = S[a] * A[a * (a + 1) / 2 + b] * S[b];
+            }
+            if (!reuse_diag) {
+#pragma unroll
+                for (int a = 0; a < NP; ++a) diag[a] = fmin(fmax(As[a * (a + 1) / 2 + a], kMinDiag), kMaxDiag);
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i) M[i] = As[i];
+#pragma unroll
+            for (int a = 0; a < NP; ++a) { M[a * (a + 1) / 2 + a] += diag[a] / radius; rhs[a] = -gs[a]; }
+            bool valid = chol_solve<NP>(M, rhs, ds);
+            double model_change = 0.0;
+            if (valid) {
+                double q = 0.0, l = 0.0;
+#pragma unroll
+                for (int a = 0; a < NP; ++a) {
+                    l += ds[a] * gs[a];
+#pragma unroll
+                    for (int b = 0; b < NP; ++b) q += ds[a] * As[tri<NP>(a, b)] * ds[b];
+                }
+                model_change = -(l + 0.5 * q);
+                valid = model_change > 0.0;
+            }
+            if (!valid) {
+                if (++invalid_run >= 5) break;
+                radius /= decrease; decrease *= 2.0; reuse_diag = true;
+                continue;
+            }
+            invalid_run = 0;
+            double delta[NP];
+#pragma unroll
+            for (int a = 0; a < NP; ++a) delta[a] = ds[a] * S[a];
+            // projected Armijo search; every trial carries its normal equations (gT, AT)
+            double gd = 0.0, dmax = 0.0;
+#pragma unroll
+            for (int a = 0; a < NP; ++a) { gd += g[a] * delta[a]; dmax = fmax(dmax, fabs(delta[a])); }
+            double t = 1.0, ft, gT[NP], AT[NT], xc[NP];
+            plus_proj<NP>(x, delta, t, lb, ub, xc);
+            bool okv = sweep<NP, true, PT>(px, py, pz, lab, N, k, xc, ft, gT, AT);
+            const double f1 = okv ? ft : DBL_MAX;   // the unscaled candidate (used when the search fails) is this first trial
+            const bool ok1 = okv;
+            int ls_it = 0;
+            bool success = false;
+            for (;;) {
+                if (okv && ft <= cost + 1e-4 * gd * t) { success = true; break; }
+                if (++ls_it >= 20) break;
+                const double lo = 1e-3 * t, hi = 0.6 * t;
+                double tn;
+                if (!okv) {
+                    tn = fmin(fmax(0.5 * t, lo), hi);
+                } else {
+                    const double a2 = (ft - cost - gd * t) / (t * t);
+                    const double qlo = cost + gd * lo + a2 * lo * lo, qhi = cost + gd * hi + a2 * hi * hi;
+                    tn = qlo <= qhi ? lo : hi;
+                    if (a2 > 0.0) {
+                        const double sc = -gd / (2.0 * a2);
+                        const double qsc = cost + gd * sc + a2 * sc * sc;
+                        const double qtn = qlo <= qhi ? qlo : qhi;
+                        if (sc > lo && sc < hi && qsc < qtn) tn = sc;
+                    }
+                }
+                if (tn * dmax < 1e-9) break;
+                t = tn;
+                plus_proj<NP>(x, delta, t, lb, ub, xc);
+                okv = sweep<NP, true, PT>(px, py, pz, lab, N, k, xc, ft, gT, AT);
+            }
+            double cand_cost;
+            bool cand_ok;
+            if (!success) {  // delta stays unscaled: the candidate is the first trial point (rare: re-sweep it)
+                cand_cost = f1; cand_ok = ok1;
+                if (ls_it > 0) {
+                    plus_proj<NP>(x, delta, 1.0, lb, ub, xc);
+                    double fdummy;
+                    sweep<NP, true, PT>(px, py, pz, lab, N, k, xc, fdummy, gT, AT);
+                }
+            } else {
+                cand_cost = ft; cand_ok = true;
+            }
+            double step_norm = 0.0, x_norm = 0.0;
+#pragma unroll
+            for (int a = 0; a < NP; ++a) { step_norm += (x[a] - xc[a]) * (x[a] - xc[a]); x_norm += x[a] * x[a]; }
+            step_norm = sqrt(step_norm); x_norm = sqrt(x_norm);
+            if (step_norm <= kParamTol * (x_norm + kParamTol)) break;
+            if (fabs(cost - cand_cost) <= kFuncTol * cost) break;
+            const double rel = (cost - cand_cost) / model_change;
+            if (rel > kMinRelDec) {
+                if (!cand_ok) break;  // (cannot happen: cand_cost would be DBL_MAX)
+#pragma unroll
+                for (int a = 0; a < NP; ++a) { x[a] = xc[a]; g[a] = gT[a]; }
+#pragma unroll
+                for (int i = 0; i < NT; ++i) A[i] = AT[i];
+                cost = cand_cost;
+                gmax = grad_max_norm<NP>(x, g, lb, ub);
+                const double w = 2.0 * rel - 1.0;
+                radius = fmin(kMaxRadius, radius / fmax(1.0 / 3.0, 1.0 - w * w * w));
+                decrease = 2.0; reuse_diag = false;
+            } else {
+                radius /= decrease; decrease *= 2.0; reuse_diag = true;
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) params_out[hr * NP + i] = x[i];
+        cost_out[hr] = cost;
+        iters_out[hr] = iter;
+    }
+}
+
+__device__ __forceinline__ void angle_axis_to_R(const double* w, double* R) {
+    const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    if (t2 > DBL_EPSILON) {
+        const double t = sqrt(t2), wx = w[0] / t, wy = w[1] / t, wz = w[2] / t, c = cos(t), s = sin(t);
+        R[0] = c + wx * wx * (1 - c);       R[1] = wx * wy * (1 - c) - wz * s;  R[2] = wy * s + wx * wz * (1 - c);
+        R[3] = wz * s + wx * wy * (1 - c);  R[4] = c + wy * wy * (1 - c);       R[5] = -wx * s + wy * wz * (1 - c);
+        R[6] = -wy * s + wx * wz * (1 - c); R[7] = wx * s + wy * wz * (1 - c);  R[8] = c + wz * wz * (1 - c);
+    } else {
+        R[0] = 1; R[1] = -w[2]; R[2] = w[1]; R[3] = w[2]; R[4] = 1; R[5] = -w[0]; R[6] = -w[1]; R[7] = w[0]; R[8] = 1;
+    }
+}
+
+// one wavefront per frame: argmin over R (ties -> lowest r), assemble P
+__global__ __launch_bounds__(64) void select_best_kernel(const double* __restrict__ params, const double* __restrict__ cost,
+                                                         const int* __restrict__ has_inside, int np, int R, int* __restrict__ best,
+                                                         double* __restrict__ P, double* __restrict__ best_cost) {
+    const int f = blockIdx.x, lane = threadIdx.x;
+    double bc = __builtin_inf();
+    int bi = 0x7fffffff;
+    for (int r = lane; r < R; r += 64) {
+        const double c = cost[(long long)f * R + r];
+        if (c < bc || (c == bc && r < bi)) { bc = c; bi = r; }   // NaN never wins
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double oc = __shfl_xor(bc, o);
+        const int oi = __shfl_xor(bi, o);
+        if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
+    }
+    if (lane != 0) return;
+    double* Pf = P + (long long)f * 16;
+    for (int i = 0; i < 16; ++i) Pf[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    if (has_inside && has_inside[f] == 0) {  // registration_lsq.py:329-332
+        best[f] = -1;
+        best_cost[f] = 1e4;
+        return;
+    }
+    if (bi == 0x7fffffff) bi = 0;
+    const double* x = params + ((long long)f * R + bi) * np;
+    double w[3] = {0, 0, 0};
+    int toff;
+    if (np == 4) { w[1] = x[0]; toff = 1; } else { w[0] = x[0]; w[1] = x[1]; w[2] = x[2]; toff = 3; }
+    double Rm[9];
+    angle_axis_to_R(w, Rm);
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) Pf[r * 4 + c] = Rm[r * 3 + c]; Pf[r * 4 + 3] = x[toff + r]; }
+    best[f] = bi;
+    best_cost[f] = cost[(long long)f * R + bi];
+}
+
+// registration_lsq.py:196-220.  One 1024-thread workgroup per frame, fixed-order tree reductions.
+__global__ __launch_bounds__(1024) void initial_guess_kernel(const double* __restrict__ points, const int* __restrict__ labels,
+                                                             double* __restrict__ yaw0, int* __restrict__ labels_out,
+                                                             int* __restrict__ has_inside, int N) {
+    __shared__ double s_a[1024], s_b[1024], s_c[1024];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const double* px = points + (long long)f * 3 * N;
+    const double* pz = px + 2 * (long long)N;
+    const int* lab = labels + (long long)f * N;
+    double sx = 0, sz = 0, cnt = 0;
+    for (int n = tid; n < N; n += 1024)
+        if (lab[n] == 1) { sx += px[n]; sz += pz[n]; cnt += 1.0; }
+    s_a[tid] = sx; s_b[tid] = sz; s_c[tid] = cnt;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) { s_a[tid] += s_a[tid + o]; s_b[tid] += s_b[tid + o]; s_c[tid] += s_c[tid + o]; }
+        __syncthreads();
+    }
+    const double count = s_c[0];
+    const double mx = s_a[0] / count, mz = s_b[0] / count;
+    __syncthreads();
+    if (!(count > 0.0)) {
+        if (tid == 0) { yaw0[f] = 0.0; has_inside[f] = 0; }
+        for (int n = tid; n < N; n += 1024) labels_out[(long long)f * N + n] = lab[n];
+        return;
+    }
+    const double kPi = 3.14159265358979323846;
+    double a = fmod(atan2(mz, mx) - kPi / 2 + kPi, 2 * kPi);   // wrap_in_pi (:189-193)
+    if (a < 0) a += 2 * kPi;
+    a -= kPi;
+    const double c = cos(a), s = sin(a);
+    double zmin = __builtin_inf();
+    for (int n = tid; n < N; n += 1024)
+        if (lab[n] == 1) zmin = fmin(zmin, -s * px[n] + c * pz[n]);
+    s_a[tid] = zmin;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) s_a[tid] = fmin(s_a[tid], s_a[tid + o]);
+        __syncthreads();
+    }
+    const double thr = s_a[0] - 10.0;
+    for (int n = tid; n < N; n += 1024) {
+        const double zr = -s * px[n] + c * pz[n];
+        labels_out[(long long)f * N + n] = zr > thr ? lab[n] : -1;
+    }
+    if (tid == 0) { yaw0[f] = a; has_inside[f] = 1; }
+}
+
+// Problem::Evaluate (registration.cpp:150-155): loss-corrected residuals in point order, compacted.
+template <int NP>
+__global__ __launch_bounds__(256) void residuals_kernel(const double* __restrict__ points, const int* __restrict__ labels,
+                                                        const double* __restrict__ Kmat, const double* __restrict__ params, double H,
+                                                        double W, int N, double* __restrict__ residuals, int* __restrict__ counts,
+                                                        double* __restrict__ cost_out) {
+    __shared__ int s_scan[256];
+    __shared__ double s_cost[256];
+    __shared__ int s_base;
+    constexpr int TOFF = NP == 4 ? 1 : 3;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const double* px = points + (long long)f * 3 * N;
+    const int* lab = labels + (long long)f * N;
+    const double* Kf = Kmat + (long long)f * 9;
+    const Cam k{Kf[0], Kf[4], Kf[2], Kf[5], H - 1.0, W - 1.0};
+    const double* x = params + (long long)f * NP;
+    double xr[NP];
+    for (int i = 0; i < NP; ++i) xr[i] = x[i];
+    Rot<NP> rot;
+    make_rot<NP>(xr, rot);
+    double* out = residuals + (long long)f * 3 * N;
+    if (tid == 0) s_base = 0;
+    double cost = 0.0;
+    __syncthreads();
+    for (int n0 = 0; n0 < N; n0 += 256) {
+        const int n = n0 + tid;
+        int nr = 0;
+        double rv[3] = {0, 0, 0};
+        if (n < N && (lab[n] == 0 || lab[n] == 1)) {
+            const double X = px[n], Y = px[N + n], Z = px[2 * (long long)N + n];
+            const double qx = rot.R[0] * X + rot.R[1] * Y + rot.R[2] * Z, qy = rot.R[3] * X + rot.R[4] * Y + rot.R[5] * Z,
+                         qz = rot.R[6] * X + rot.R[7] * Y + rot.R[8] * Z;
+            const double p0 = qx + xr[TOFF], p1 = qy + xr[TOFF + 1], p2 = qz + xr[TOFF + 2];
+            const double pix_x = p0 * k.fx / p2 + k.cx, pix_y = p1 * k.fy / p2 + k.cy;
+            if (lab[n] == 1) {
+                nr = 3;
+                rv[0] = fmax(-pix_x, 0.0) + fmax(pix_x - k.W1, 0.0);
+                rv[1] = fmax(-pix_y, 0.0) + fmax(pix_y - k.H1, 0.0);
+                rv[2] = fmax(-p2, 0.0) * 100.0;
+            } else {
+                nr = 1;
+                const double dx = k.W1 * 0.5 - fabs(pix_x - k.W1 * 0.5), dy = k.H1 * 0.5 - fabs(pix_y - k.H1 * 0.5);
+                rv[0] = (dx + dy) * (fmax(p2, 0.0) / p2) * (fmax(dx, 0.0) / dx) * (fmax(dy, 0.0) / dy);
+            }
+            const double s = rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2];
+            cost += 0.5 * log1p(s);
+            const double sq = sqrt(1.0 / (1.0 + s));
+            for (int i = 0; i < 3; ++i) rv[i] *= sq;
+        }
+        s_scan[tid] = nr;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int v = tid >= o ? s_scan[tid - o] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        const int excl = s_scan[tid] - nr + s_base;
+        for (int i = 0; i < nr; ++i) out[excl + i] = rv[i];
+        __syncthreads();
+        if (tid == 255) s_base += s_scan[255];
+        __syncthreads();
+    }
+    s_cost[tid] = cost;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) s_cost[tid] += s_cost[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) { counts[f] = s_base; cost_out[f] = s_cost[0]; }
+}
+
+template <typename PT>
+int launch_solve(const PT* points, const int* labels, const double* K, const double* init_y, const double* init_T,
+                 const double* yaw0, double H, double W, const double* lb, const double* ub, int max_iter, int is_2d, int F,
+                 int R, int N, double* params, double* cost, int* iters, hipStream_t st) {
+    Bounds b;
+    for (int i = 0; i < 3; ++i) { b.lb[i] = lb[i]; b.ub[i] = ub[i]; }
+    const dim3 grid(di2p_cdiv(R, 4), F), block(256);
+    if (is_2d)
+        hipLaunchKernelGGL((solve_kernel<4, PT>), grid, block, 0, st, points, labels, K, init_y, init_T, yaw0, H, W, b, max_iter, R, N, params, cost, iters);
+    else
+        hipLaunchKernelGGL((solve_kernel<6, PT>), grid, block, 0, st, points, labels, K, init_y, init_T, yaw0, H, W, b, max_iter, R, N, params, cost, iters);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int di2p_solve_batched(const double* points, const int32_t* labels, const double* K, const double* init_y,
+                                  const double* init_T, const double* yaw0, double H, double W, const double* lb_host,
+                                  const double* ub_host, int max_iter, int is_2d, int F, int R, int N, double* params,
+                                  double* cost, int32_t* iters, void* stream) {
+    DI2P_CHECK_ARG(points && labels && K && init_y && init_T && lb_host && ub_host && params && cost && iters, "null pointer");
+    DI2P_CHECK_ARG(F >= 0 && R >= 0 && N >= 0 && max_iter >= 0, "bad size");
+    if (F == 0 || R == 0) return 0;
+    launch_solve<double>(points, labels, K, init_y, init_T, yaw0, H, W, lb_host, ub_host, max_iter, is_2d, F, R, N, params, cost, iters, (hipStream_t)stream);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_solve_batched_f32(const float* points, const int32_t* labels, const double* K, const double* init_y,
+                                      const double* init_T, const double* yaw0, double H, double W, const double* lb_host,
+                                      const double* ub_host, int max_iter, int is_2d, int F, int R, int N, double* params,
+                                      double* cost, int32_t* iters, void* stream) {
+    DI2P_CHECK_ARG(points && labels && K && init_y && init_T && lb_host && ub_host && params && cost && iters, "null pointer");
+    DI2P_CHECK_ARG(F >= 0 && R >= 0 && N >= 0 && max_iter >= 0, "bad size");
+    if (F == 0 || R == 0) return 0;
+    launch_solve<float>(points, labels, K, init_y, init_T, yaw0, H, W, lb_host, ub_host, max_iter, is_2d, F, R, N, params, cost, iters, (hipStream_t)stream);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_select_best(const double* params, const double* cost, const int32_t* has_inside, int is_2d, int F, int R,
+                                int32_t* best, double* P, double* best_cost, void* stream) {
+    DI2P_CHECK_ARG(params && cost && best && P && best_cost && F >= 0 && R >= 1, "bad args");
+    if (F == 0) return 0;
+    hipLaunchKernelGGL(select_best_kernel, dim3(F), dim3(64), 0, (hipStream_t)stream, params, cost, has_inside, is_2d ? 4 : 6, R, best, P, best_cost);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_initial_guess(const double* points, const int32_t* labels, double* yaw0, int32_t* labels_out,
+                                  int32_t* has_inside, int F, int N, void* stream) {
+    DI2P_CHECK_ARG(points && labels && yaw0 && labels_out && has_inside && F >= 0 && N >= 0, "bad args");
+    if (F == 0) return 0;
+    hipLaunchKernelGGL(initial_guess_kernel, dim3(F), dim3(1024), 0, (hipStream_t)stream, points, labels, yaw0, labels_out, has_inside, N);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_solver_residuals(const double* points, const int32_t* labels, const double* K, const double* params, double H,
+                                     double W, int is_2d, int F, int N, double* residuals, int32_t* counts, double* cost,
+                                     void* stream) {
+    DI2P_CHECK_ARG(points && labels && K && params && residuals && counts && cost && F >= 0 && N >= 0, "bad args");
+    if (F == 0) return 0;
+    if (is_2d)
+        hipLaunchKernelGGL(residuals_kernel<4>, dim3(F), dim3(256), 0, (hipStream_t)stream, points, labels, K, params, H, W, N, residuals, counts, cost);
+    else
+        hipLaunchKernelGGL(residuals_kernel<6>, dim3(F), dim3(256), 0, (hipStream_t)stream, points, labels, K, params, H, W, N, residuals, counts, cost);
+    DI2P_RETURN_LAUNCH();
+}

@@ -1,0 +1,414 @@
+"""Host-side mirror of the reference's network modules, running on the HIP kernels.
+
+Same constructor arguments, call signatures, return tuples and ``state_dict`` keys (361 tensors)
+as the reference, so a released checkpoint loads unchanged:
+
+  PointNet / EquivariantLayer      models/layers_pc.py:259-408
+  GeneralKNNFusionModule           models/layers_pc.py:756-818
+  PCEncoder                        models/networks_pc.py:15-124
+  ImageEncoder (ResNet-34)         models/networks_img.py:12-28, models/resnet.py:125-216
+  KeypointDetector                 models/networks_united.py:14-210
+  MMClassifer / MMClassiferCoarse  models/multimodal_classifier.py:25-117, :380-469 (inference part)
+
+Only inference (eval mode) is implemented: BatchNorm uses running statistics, dropout is identity.
+The modules hold the reference's parameters verbatim; ``_pack()`` derives the kernel operands once
+per load (weights transposed to [K,M]; BN folded to scale/shift; concatenated inputs that are
+broadcasts folded into per-frame bias vectors; per_point_pn layer 0 split so that the interpolated
+inputs are contracted per NODE instead of per POINT -- W*sum_k w_k f_k == sum_k w_k (W f_k)).
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .ops import Src
+
+BN_EPS = 1e-5
+
+
+# ------------------------------------------------------------------ parameter tree with reference keys
+class _Holder(nn.Module):
+    pass
+
+
+def _register(root, key, tensor, is_buffer):
+    parts = key.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Holder())
+        mod = mod._modules[p]
+    if is_buffer:
+        mod.register_buffer(parts[-1], tensor)
+    else:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+def _pn_spec(prefix, cin, couts, norm_last):
+    spec, c = [], cin
+    for i, co in enumerate(couts):
+        q = "%s.layers.%d" % (prefix, i)
+        spec += [(q + ".conv.weight", (co, c, 1)), (q + ".conv.bias", (co,))]
+        if i < len(couts) - 1 or norm_last:
+            spec += [(q + ".norm." + s, (co,)) for s in ("weight", "bias", "running_mean", "running_var")]
+            spec += [(q + ".norm.num_batches_tracked", ())]
+        c = co
+    return spec
+
+
+def _c2d_spec(prefix, cin, co):
+    return ([(prefix + ".conv.weight", (co, cin, 1, 1)), (prefix + ".conv.bias", (co,))]
+            + [(prefix + ".norm." + s, (co,)) for s in ("weight", "bias", "running_mean", "running_var")]
+            + [(prefix + ".norm.num_batches_tracked", ())])
+
+
+def _bn_spec(prefix, c):
+    return [(prefix + "." + s, (c,)) for s in ("weight", "bias", "running_mean", "running_var")] + \
+           [(prefix + ".num_batches_tracked", ())]
+
+
+def _materialise(module, spec):
+    """Create parameters/buffers with reference names; default init = identity BN, zero bias, He weights."""
+    g = torch.Generator().manual_seed(0)
+    for key, shape in spec:
+        leaf = key.rsplit(".", 1)[1]
+        if leaf == "num_batches_tracked":
+            _register(module, key, torch.zeros((), dtype=torch.long), True)
+        elif leaf in ("running_mean",):
+            _register(module, key, torch.zeros(shape), True)
+        elif leaf in ("running_var",):
+            _register(module, key, torch.ones(shape), True)
+        elif leaf == "bias":
+            _register(module, key, torch.zeros(shape), False)
+        elif len(shape) == 1:   # norm weight
+            _register(module, key, torch.ones(shape), False)
+        else:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            _register(module, key, torch.randn(shape, generator=g) * (2.0 / fan_in) ** 0.5, False)
+
+
+class _PackedModule(nn.Module):
+    """nn.Module whose kernel operands are re-derived after every load_state_dict / device move."""
+
+    def __init__(self):
+        super().__init__()
+        self._packed = None
+        self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
+
+    def _invalidate(self):
+        for m in self.modules():
+            if isinstance(m, _PackedModule):
+                m._packed = None
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._invalidate()
+        return r
+
+    def _sd(self):
+        return {k: v for k, v in self.state_dict().items()}
+
+
+def _fold(sd, conv_key, norm_key):
+    """(Wt [K,M], scale [M]|None, shift [M]) for conv(+bias) followed by optional BN(eval)."""
+    w = sd[conv_key + ".weight"]
+    Wt = w.reshape(w.shape[0], -1).t().contiguous()
+    bias = sd.get(conv_key + ".bias")
+    if norm_key is not None and (norm_key + ".weight") in sd:
+        scale = sd[norm_key + ".weight"] / torch.sqrt(sd[norm_key + ".running_var"] + BN_EPS)
+        shift = sd[norm_key + ".bias"] - sd[norm_key + ".running_mean"] * scale
+        if bias is not None:
+            shift = shift + bias * scale
+        return Wt, scale.contiguous(), shift.contiguous(), True
+    shift = bias.contiguous() if bias is not None else torch.zeros(w.shape[0], device=w.device)
+    return Wt, None, shift, False
+
+
+def _pn_pack(sd, prefix):
+    layers, i = [], 0
+    while (prefix + ".layers.%d.conv.weight" % i) in sd:
+        q = prefix + ".layers.%d" % i
+        layers.append(_fold(sd, q + ".conv", q + ".norm"))
+        i += 1
+    return layers
+
+
+def _run_layer(srcs, layer, N, **kw):
+    Wt, scale, shift, act = layer
+    return ops.pointwise_gemm(srcs, Wt, Wt.shape[1], N, scale=scale, shift=shift, relu=act, **kw)
+
+
+def _run_pn(x, layers):
+    N = x.shape[2]
+    for layer in layers:
+        x = _run_layer([Src(x)], layer, N)
+    return x
+
+
+# ------------------------------------------------------------------ point-cloud encoder
+class PCEncoder(_PackedModule):
+    def __init__(self, opt, Ca: int, Cb: int, Cg: int, prefix=""):
+        super().__init__()
+        self.opt, self.Ca, self.Cb, self.Cg = opt, Ca, Cb, Cg
+        spec = (_pn_spec("first_pointnet", 7, [Ca // 2] * 3, True)
+                + _pn_spec("second_pointnet", Ca, [Ca, Ca], True)
+                + _c2d_spec("knnlayer.layers_before.0", 3 + Ca, Cb) + _c2d_spec("knnlayer.layers_before.1", Cb, Cb)
+                + _c2d_spec("knnlayer.layers_after.0", 2 * Cb, 2 * Cb) + _c2d_spec("knnlayer.layers_after.1", 2 * Cb, Cb)
+                + _pn_spec("final_pointnet", 3 + Cb, [Cg // 2, Cg], True))
+        _materialise(self, spec)
+
+    def _pack(self):
+        if self._packed is None:
+            sd = self._sd()
+            p = {"first": _pn_pack(sd, "first_pointnet"), "second": _pn_pack(sd, "second_pointnet"),
+                 "final": _pn_pack(sd, "final_pointnet")}
+            for name in ("layers_before.0", "layers_before.1", "layers_after.0", "layers_after.1"):
+                q = "knnlayer." + name
+                p[name] = _fold(sd, q + ".conv", q + ".norm")
+            self._packed = p
+        return self._packed
+
+    def forward_device(self, pc, intensity, sn, node_a, node_b):
+        """Returns the reference 8-tuple plus the device-side extras the fusion head re-uses."""
+        if pc.size(2) != self.opt.input_pt_num:
+            raise RuntimeError("N must equal opt.input_pt_num (the reference bakes it in, networks_pc.py:44-45)")
+        p = self._pack()
+        B, N, Ma, Mb = pc.size(0), pc.size(2), node_a.size(2), node_b.size(2)
+        idx_a, w_a = ops.knn_nodes(pc, node_a, self.opt.k_interp_point_a, want_weights=True)
+        cluster_mean, mask, min_idx = ops.cluster_stats(pc, idx_a, Ma)
+        pc_centers, aug = ops.build_point_input(pc, intensity, sn, cluster_mean, min_idx)
+        first = _run_pn(aug, p["first"])
+        _, first_max = ops.index_max(first, min_idx, Ma, return_values=True, mask=mask)
+        second = _run_layer([Src(first), Src(first_max, _lib.SRC_GATHER, gidx=min_idx)], p["second"][0], N)
+        second = _run_pn(second, p["second"][1:])
+        _, node_a_features = ops.index_max(second, min_idx, Ma, return_values=True, mask=mask)
+        # GeneralKNNFusionModule (layers_pc.py:779-818)
+        K = self.opt.k_ab
+        knn_I = ops.knn_nodes(node_b, cluster_mean, K)
+        coord = ops.gather_neighbors(cluster_mean, node_b, knn_I)
+        y = _run_layer([Src(coord), Src(node_a_features, _lib.SRC_GATHER, gidx=knn_I.view(B, Mb * K))],
+                       p["layers_before.0"], Mb * K)
+        y = _run_layer([Src(y)], p["layers_before.1"], Mb * K)
+        Cb = y.shape[1]
+        fmax = ops.channel_max(y.view(B, Cb * Mb, K)).view(B, Cb, Mb)
+        y = _run_layer([Src(fmax, _lib.SRC_GROUP, group=K), Src(y)], p["layers_after.0"], Mb * K)
+        if K & (K - 1) == 0 and K <= 32:
+            node_b_features = _run_layer([Src(y)], p["layers_after.1"], Mb * K, group_max=K)
+        else:
+            y = _run_layer([Src(y)], p["layers_after.1"], Mb * K)
+            node_b_features = ops.channel_max(y.view(B, y.shape[1] * Mb, K)).view(B, y.shape[1], Mb)
+        final = _run_layer([Src(node_b), Src(node_b_features)], p["final"][0], Mb)
+        final = _run_pn(final, p["final"][1:])
+        global_feature = ops.channel_max(final).unsqueeze(2)
+        ref_tuple = (pc_centers, cluster_mean, idx_a, first, second, node_a_features, node_b_features, global_feature)
+        return ref_tuple, dict(w_a=w_a, min_idx=min_idx, mask=mask, knn_I=knn_I)
+
+    def forward(self, pc, intensity, sn, node_a, node_b):
+        t, _ = self.forward_device(pc, intensity, sn, node_a, node_b)
+        return t[0], t[1], t[2].long(), t[3], t[4], t[5], t[6], t[7]
+
+
+# ------------------------------------------------------------------ image encoder
+class ImageEncoder(_PackedModule):
+    LAYERS = (3, 4, 6, 3)
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        r = "backbone"
+        spec = [(r + ".conv1.weight", (64, 3, 7, 7))] + _bn_spec(r + ".bn1", 64)
+        inpl = 64
+        for li, (planes, nb) in enumerate(zip((64, 128, 256, 512), self.LAYERS), start=1):
+            for bi in range(nb):
+                q = "%s.layer%d.%d" % (r, li, bi)
+                spec += [(q + ".conv1.weight", (planes, inpl, 3, 3))] + _bn_spec(q + ".bn1", planes)
+                spec += [(q + ".conv2.weight", (planes, planes, 3, 3))] + _bn_spec(q + ".bn2", planes)
+                if bi == 0 and li > 1:
+                    spec += [(q + ".downsample.0.weight", (planes, inpl, 1, 1))] + _bn_spec(q + ".downsample.1", planes)
+                inpl = planes
+        spec += [(r + ".fc.weight", (1000, 512)), (r + ".fc.bias", (1000,))]   # present, unused (resnet.py:152)
+        _materialise(self, spec)
+
+    def _pack(self):
+        if self._packed is None:
+            sd = self._sd()
+            r = "backbone"
+            p = {"stem": _fold(sd, r + ".conv1", r + ".bn1"), "blocks": []}
+            for li, nb in enumerate(self.LAYERS, start=1):
+                for bi in range(nb):
+                    q = "%s.layer%d.%d" % (r, li, bi)
+                    blk = {"c1": _fold(sd, q + ".conv1", q + ".bn1"), "c2": _fold(sd, q + ".conv2", q + ".bn2"),
+                           "stride": 2 if (bi == 0 and li > 1) else 1, "last_of_stage": bi == nb - 1, "stage": li}
+                    if (q + ".downsample.0.weight") in sd:
+                        blk["ds"] = _fold(sd, q + ".downsample.0", q + ".downsample.1")
+                    p["blocks"].append(blk)
+            self._packed = p
+        return self._packed
+
+    def forward(self, x):
+        p = self._pack()
+        ops.require_cuda(x)
+        Wt, sc, sh, _ = p["stem"]
+        x = ops.conv2d(x, Wt, sc, sh, 7, 7, 2, 3, True)
+        x = ops.maxpool3x3s2(x)
+        stage_out = {}
+        for blk in p["blocks"]:
+            identity = x
+            Wt, sc, sh, _ = blk["c1"]
+            y = ops.conv2d(x, Wt, sc, sh, 3, 3, blk["stride"], 1, True)
+            if "ds" in blk:
+                Wd, sd_, shd, _ = blk["ds"]
+                identity = ops.conv2d(x, Wd, sd_, shd, 1, 1, blk["stride"], 0, False)
+            Wt, sc, sh, _ = blk["c2"]
+            x = ops.conv2d(y, Wt, sc, sh, 3, 3, 1, 1, True, residual=identity)
+            if blk["last_of_stage"]:
+                stage_out[blk["stage"]] = x
+        return stage_out[3], stage_out[4], ops.global_avgpool(stage_out[4])
+
+
+# ------------------------------------------------------------------ fusion classifier
+class KeypointDetector(_PackedModule):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.pc_encoder = PCEncoder(opt, Ca=64, Cb=256, Cg=512)
+        self.img_encoder = ImageEncoder(opt)
+        self.H_fine_res = int(round(opt.img_H / opt.img_fine_resolution_scale))
+        self.W_fine_res = int(round(opt.img_W / opt.img_fine_resolution_scale))
+        L = self.H_fine_res * self.W_fine_res
+        spec = (_pn_spec("node_b_attention_pn", 256 + 512, [256, L], False)
+                + _pn_spec("node_b_pn", 256 + 512 + 512 + 512, [1024, 512, 512], False)
+                + _pn_spec("node_a_attention_pn", 64 + 512, [256, L * 4], False)
+                + _pn_spec("node_a_pn", 64 + 256 + 512, [512, 128, 128], False))
+        if opt.is_fine_resolution:
+            spec += _pn_spec("per_point_pn", 736, [256, 256, 2 + L], False)
+        else:
+            spec += _pn_spec("per_point_pn", 736, [128, 128, 2], False)
+        _materialise(self, spec)
+
+    def _pack(self):
+        if self._packed is None:
+            sd = {k: v for k, v in self.state_dict().items() if not k.startswith(("pc_encoder.", "img_encoder."))}
+            p = {n: _pn_pack(sd, n) for n in ("node_b_attention_pn", "node_b_pn", "node_a_attention_pn", "node_a_pn", "per_point_pn")}
+            # node_b_pn layer 0: channel order [node_b_feat 256 | global 512 (bcast) | w_s32 512 | img_global 512 (bcast)]
+            Wt = p["node_b_pn"][0][0]
+            p["node_b_pn_dense_Wt"] = torch.cat((Wt[0:256], Wt[768:1280]), dim=0).contiguous()
+            self._packed = p
+        return self._packed
+
+    def forward(self, pc, intensity, sn, node_a, node_b, img):
+        ops.require_cuda(pc, intensity, sn, node_a, node_b, img)
+        p = self._pack()
+        B, N, Ma, Mb = pc.size(0), pc.size(2), node_a.size(2), node_b.size(2)
+        (pc_center, cluster_mean, idx_a, first, second, node_a_features, node_b_features, global_feature), ex = \
+            self.pc_encoder.forward_device(pc, intensity, sn, node_a, node_b)
+        s16, s32, iglob = self.img_encoder(img)
+        s16f = s16.view(B, s16.size(1), -1)
+        s32f = s32.view(B, s32.size(1), -1)
+        ig = iglob.view(B, -1)                      # [B,512]
+        gf = global_feature.view(B, -1)             # [B,512]
+
+        # node_b attention over the /32 map (networks_united.py:139-150); broadcast channels -> per-frame bias
+        Wt, sc, sh, act = p["node_b_attention_pn"][0]
+        h = ops.pointwise_gemm([Src(node_b_features)], Wt[0:256], Wt.shape[1], Mb, scale=sc, shift=sh, relu=act,
+                               batch_bias=ops.batch_gemv(Wt, 256, ig))
+        score_b = _run_pn(h, p["node_b_attention_pn"][1:])
+        w_s32 = ops.attention_pool(s32f, score_b)
+        # node_b_pn (:152-155)
+        Wt, sc, sh, act = p["node_b_pn"][0]
+        bias = ops.batch_gemv(Wt, 256, gf) + ops.batch_gemv(Wt, 1280, ig)
+        h = ops.pointwise_gemm([Src(node_b_features), Src(w_s32)], p["node_b_pn_dense_Wt"], Wt.shape[1], Mb,
+                               scale=sc, shift=sh, relu=act, batch_bias=bias)
+        up_b = _run_pn(h, p["node_b_pn"][1:])
+        # point <- node_b neighbours (:158-161)
+        idx_pb, w_pb = ops.knn_nodes(pc, node_b, self.opt.k_interp_point_b, want_weights=True)
+        # node_a attention over the /16 map (:170-174)
+        Wt, sc, sh, act = p["node_a_attention_pn"][0]
+        h = ops.pointwise_gemm([Src(node_a_features)], Wt[0:64], Wt.shape[1], Ma, scale=sc, shift=sh, relu=act,
+                               batch_bias=ops.batch_gemv(Wt, 64, ig))
+        score_a = _run_pn(h, p["node_a_attention_pn"][1:])
+        w_s16 = ops.attention_pool(s16f, score_a)
+        # node_a <- node_b interpolation (:176-182), node_a_pn (:184-187)
+        idx_ab, w_ab = ops.knn_nodes(node_a, node_b, self.opt.k_interp_ab, want_weights=True)
+        interp_ab = ops.interpolate(up_b, idx_ab, w_ab)
+        h = _run_layer([Src(node_a_features), Src(interp_ab), Src(w_s16)], p["node_a_pn"][0], Ma)
+        up_a = _run_pn(h, p["node_a_pn"][1:])
+        # per-point head (:188-197): layer 0 contracts the interpolated inputs per node
+        Wt, sc, sh, act = p["per_point_pn"][0]
+        M0 = Wt.shape[1]
+        G_a = ops.pointwise_gemm([Src(up_a)], Wt[0:128], M0, Ma)
+        G_b = ops.pointwise_gemm([Src(up_b)], Wt[128:640], M0, Mb)
+        h = ops.pointwise_gemm([Src(first), Src(second)], Wt[640:736], M0, N, scale=sc, shift=sh, relu=act,
+                               gathered=[(G_a, idx_a, ex["w_a"]), (G_b, idx_pb, w_pb)])
+        scores = _run_pn(h, p["per_point_pn"][1:])
+        coarse = scores[:, 0:2, :]
+        if self.opt.is_fine_resolution:
+            return coarse, scores[:, 2:, :]
+        return coarse
+
+    def intermediates(self, pc, intensity, sn, node_a, node_b, img):
+        """Test hook: the materialised per-stage tensors the reference would produce."""
+        p = self._pack()
+        B, N, Ma, Mb = pc.size(0), pc.size(2), node_a.size(2), node_b.size(2)
+        t, ex = self.pc_encoder.forward_device(pc, intensity, sn, node_a, node_b)
+        s16, s32, iglob = self.img_encoder(img)
+        return dict(pc_center=t[0], cluster_mean=t[1], a_min_k_idx=t[2], first_pn_out=t[3], second_pn_out=t[4],
+                    node_a_features=t[5], node_b_features=t[6], global_feature=t[7], s16=s16, s32=s32, img_global=iglob,
+                    w_a=ex["w_a"], knn_I=ex["knn_I"])
+
+
+def model_state_dict_convert_auto(sd):
+    """util/pytorch_helper.py:24-33: accept DataParallel ('module.'-prefixed) or bare checkpoints."""
+    if len(sd) and all(k.startswith("module.") for k in sd):
+        return {k[len("module."):]: v for k, v in sd.items()}
+    return sd
+
+
+class MMClassifer:
+    """Inference part of models/multimodal_classifier.py:25-117 (coarse + fine)."""
+
+    fine = True
+
+    def __init__(self, opt, writer=None):
+        self.opt = opt
+        self.writer = writer
+        opt.is_fine_resolution = self.fine if not hasattr(opt, "is_fine_resolution") else opt.is_fine_resolution
+        self.device = getattr(opt, "device", torch.device("cuda", 0))
+        self.detector = KeypointDetector(opt).to(self.device).eval()
+        self.pc = self.intensity = self.sn = self.node_a = self.node_b = self.P = self.img = self.K = None
+
+    def load_model(self, model_path):
+        self.detector.load_state_dict(model_state_dict_convert_auto(torch.load(model_path, map_location="cpu")))
+
+    def set_input(self, pc, intensity, sn, node_a, node_b, P, img, K):
+        """H2D copies into persistent device tensors (multimodal_classifier.py:82-93)."""
+        def put(name, t):
+            cur = getattr(self, name)
+            if cur is None or cur.shape != t.shape or cur.dtype != t.dtype:
+                cur = torch.empty(t.shape, dtype=t.dtype, device=self.device)
+                setattr(self, name, cur)
+            cur.copy_(t, non_blocking=True)
+        for n, t in (("pc", pc), ("intensity", intensity), ("sn", sn), ("node_a", node_a), ("node_b", node_b),
+                     ("P", P), ("img", img), ("K", K)):
+            put(n, t)
+
+    def forward(self, pc, intensity, sn, node_a, node_b, img):
+        return self.detector(pc, intensity, sn, node_a, node_b, img)
+
+    def inference_pass(self):
+        out = self.forward(self.pc, self.intensity, self.sn, self.node_a, self.node_b, self.img)
+        if self.opt.is_fine_resolution:
+            coarse, fine = out
+            return ops.argmax_channels(coarse).long(), ops.argmax_channels(fine).long()
+        return ops.argmax_channels(out).long()
+
+
+class MMClassiferCoarse(MMClassifer):
+    """models/multimodal_classifier.py:380-469: coarse head only, inference_pass -> coarse_prediction."""
+
+    fine = False
+
+    def __init__(self, opt, writer=None):
+        opt.is_fine_resolution = False
+        super().__init__(opt, writer)

@@ -1,0 +1,267 @@
+"""Thin torch-tensor front-ends of the C-ABI kernels (include/deepi2p_hip.h).
+
+torch supplies device memory and the current HIP stream only.  Every function launches on
+``torch.cuda.current_stream()`` (the reference launched on the legacy default stream,
+index_max_cuda.cu:75,93) and never synchronises, so sequences of these calls can be captured in a
+``torch.cuda.CUDAGraph``.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import EpilogueT, SrcT, call, ptr, require_cuda, stream
+
+_f32, _i32, _f64 = torch.float32, torch.int32, torch.float64
+
+
+def _chk(t, dtype, name):
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+
+
+# ------------------------------------------------------------------------------------ native ops
+def index_max(data, index, K, return_values=False, mask=None):
+    """data f32[B,C,N], index i32[B,N] -> max_idx i32[B,C,K] (and masked max values if asked)."""
+    require_cuda(data, index, mask)
+    _chk(data, _f32, "data")
+    _chk(index, _i32, "index")
+    B, C, N = data.shape
+    K = int(K)
+    idx = torch.empty((B, C, K), dtype=_i32, device=data.device)
+    ws = torch.empty((B * C * K,), dtype=torch.int64, device=data.device)
+    if return_values:
+        val = torch.empty((B, C, K), dtype=_f32, device=data.device)
+        call("di2p_index_max_values", ptr(data), ptr(index), ptr(mask), ptr(val), ptr(idx), B, C, N, K, ptr(ws), stream())
+        return idx, val
+    call("di2p_index_max_forward", ptr(data), ptr(index), ptr(idx), B, C, N, K, ptr(ws), stream())
+    return idx
+
+
+def ball_query(node_to_point_dist, radius, K):
+    require_cuda(node_to_point_dist)
+    _chk(node_to_point_dist, _f32, "node_to_point_dist")
+    B, M, N = node_to_point_dist.shape
+    out = torch.empty((B, M, int(K)), dtype=_i32, device=node_to_point_dist.device)
+    call("di2p_ball_query_forward", ptr(node_to_point_dist), ptr(out), float(radius), int(K), B, M, N, stream())
+    return out
+
+
+def knn_nodes(query, nodes, k, want_weights=False):
+    """query f32[B,3,Nq], nodes f32[B,3,M] -> idx i32[B,Nq,k] (+ weights f32[B,Nq,k])."""
+    require_cuda(query, nodes)
+    B, _, Nq = query.shape
+    M = nodes.shape[2]
+    idx = torch.empty((B, Nq, k), dtype=_i32, device=query.device)
+    w = torch.empty((B, Nq, k), dtype=_f32, device=query.device) if want_weights else None
+    call("di2p_knn_nodes", ptr(query), ptr(nodes), ptr(idx), ptr(w), B, Nq, M, int(k), stream())
+    return (idx, w) if want_weights else idx
+
+
+def cluster_stats(pc, knn_idx, M):
+    require_cuda(pc, knn_idx)
+    B, _, N = pc.shape
+    mean = torch.empty((B, 3, M), dtype=_f32, device=pc.device)
+    mask = torch.empty((B, M), dtype=_f32, device=pc.device)
+    min_idx = torch.empty((B, N), dtype=_i32, device=pc.device)
+    call("di2p_cluster_stats", ptr(pc), ptr(knn_idx), knn_idx.shape[2], ptr(mean), ptr(mask), ptr(min_idx), B, N, M, stream())
+    return mean, mask, min_idx
+
+
+def build_point_input(pc, intensity, sn, cluster_mean, min_idx):
+    require_cuda(pc, intensity, sn, cluster_mean, min_idx)
+    B, _, N = pc.shape
+    centers = torch.empty_like(pc)
+    aug = torch.empty((B, 7, N), dtype=_f32, device=pc.device)
+    call("di2p_build_point_input", ptr(pc), ptr(intensity), ptr(sn), ptr(cluster_mean), ptr(min_idx), ptr(centers),
+         ptr(aug), B, N, cluster_mean.shape[2], stream())
+    return centers, aug
+
+
+def interpolate(feats, idx, weights):
+    require_cuda(feats, idx, weights)
+    B, C, M = feats.shape
+    Nq, k = idx.shape[1], idx.shape[2]
+    out = torch.empty((B, C, Nq), dtype=_f32, device=feats.device)
+    call("di2p_interpolate", ptr(feats), ptr(idx), ptr(weights), ptr(out), B, C, M, Nq, k, stream())
+    return out
+
+
+def gather_neighbors(database, query, idx):
+    require_cuda(database, query, idx)
+    B, _, Md = database.shape
+    Mq, K = idx.shape[1], idx.shape[2]
+    out = torch.empty((B, 3, Mq * K), dtype=_f32, device=database.device)
+    call("di2p_gather_neighbors", ptr(database), ptr(query), ptr(idx), ptr(out), B, Md, Mq, K, stream())
+    return out
+
+
+def argmax_channels(scores):
+    """scores f32[B,C,N] (a channel slice of a larger [B,C',N] tensor is fine) -> i32[B,N]."""
+    if not scores.is_cuda:
+        raise RuntimeError("tensor must be a CUDA tensor/variable")
+    B, C, N = scores.shape
+    if scores.stride(2) != 1 or scores.stride(1) != N:
+        raise RuntimeError("scores rows must be contiguous")
+    out = torch.empty((B, N), dtype=_i32, device=scores.device)
+    call("di2p_argmax_channels", ptr(scores), ptr(out), B, C, N, scores.stride(0), stream())
+    return out
+
+
+def channel_max(x):
+    require_cuda(x)
+    B, C, N = x.shape
+    out = torch.empty((B, C), dtype=_f32, device=x.device)
+    call("di2p_channel_max", ptr(x), ptr(out), B, C, N, stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------ contractions
+class Src:
+    """One operand source of the virtual concatenation (see di2p_src_t)."""
+
+    def __init__(self, t, mode=_lib.SRC_DENSE, gidx=None, group=1):
+        require_cuda(t, gidx)
+        assert t.dim() == 3
+        self.t, self.mode, self.gidx, self.group = t, mode, gidx, group
+
+
+def pointwise_gemm(srcs, Wt, M, N, scale=None, shift=None, batch_bias=None, relu=False, group_max=1, gathered=None):
+    """Y[b] = epi(Wt^T @ concat(srcs)[b]).  srcs: list of Src; Wt f32[K,M].  gathered: optional list of up
+    to two (table f32[B,M,nodes], idx i32[B,N,k], w f32[B,N,k])."""
+    B = srcs[0].t.shape[0]
+    K = Wt.shape[0]
+    arr = (SrcT * len(srcs))()
+    keep = []
+    for i, s in enumerate(srcs):
+        arr[i].ptr = ptr(s.t)
+        arr[i].gidx = ptr(s.gidx)
+        arr[i].batch_stride = s.t.stride(0)
+        arr[i].row_stride = s.t.stride(1)
+        arr[i].channels = s.t.shape[1]
+        arr[i].mode = s.mode
+        arr[i].group = s.group
+        keep.append(s)
+    e = EpilogueT()
+    e.scale, e.shift, e.batch_bias = ptr(scale), ptr(shift), ptr(batch_bias)
+    e.relu, e.group_max = int(bool(relu)), int(group_max)
+    e.g_k = 0
+    if gathered:
+        for t, (tab, gi, gw) in enumerate(gathered):
+            require_cuda(tab, gi, gw)
+            e.g_table[t], e.g_idx[t], e.g_w[t] = ptr(tab), ptr(gi), ptr(gw)
+            e.g_nodes[t] = tab.shape[2]
+            e.g_k = gi.shape[2]
+    Nout = N // group_max if group_max > 1 else N
+    Y = torch.empty((B, M, Nout), dtype=_f32, device=Wt.device)
+    call("di2p_pointwise_gemm", arr, len(srcs), ptr(Wt), ptr(Y), B, M, K, N, ctypes.byref(e), stream())
+    return Y
+
+
+def batch_gemv(Wt, k0, v):
+    """out[b,m] = sum_k Wt[k0+k, m] v[b,k]."""
+    require_cuda(Wt, v)
+    B, Kv = v.shape
+    M = Wt.shape[1]
+    out = torch.empty((B, M), dtype=_f32, device=Wt.device)
+    call("di2p_batch_gemv", ptr(Wt), M, int(k0), ptr(v), Kv, ptr(out), B, stream())
+    return out
+
+
+def attention_pool(feat, score):
+    """feat f32[B,C,HW], score f32[B,HW,Mn] -> f32[B,C,Mn] = feat@score / HW."""
+    require_cuda(feat, score)
+    B, C, HW = feat.shape
+    Mn = score.shape[2]
+    out = torch.empty((B, C, Mn), dtype=_f32, device=feat.device)
+    call("di2p_attention_pool", ptr(feat), ptr(score), ptr(out), B, C, HW, Mn, stream())
+    return out
+
+
+def conv2d(x, Wt, scale, shift, KH, KW, stride, pad, relu, residual=None):
+    require_cuda(x, Wt, scale, shift, residual)
+    B, Cin, H, W = x.shape
+    Cout = Wt.shape[1]
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (W + 2 * pad - KW) // stride + 1
+    y = torch.empty((B, Cout, OH, OW), dtype=_f32, device=x.device)
+    call("di2p_conv2d", ptr(x), ptr(Wt), ptr(scale), ptr(shift), ptr(residual), ptr(y), B, Cin, H, W, Cout, KH, KW,
+         stride, pad, int(bool(relu)), stream())
+    return y
+
+
+def maxpool3x3s2(x):
+    require_cuda(x)
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=_f32, device=x.device)
+    call("di2p_maxpool3x3s2", ptr(x), ptr(y), B, C, H, W, stream())
+    return y
+
+
+def global_avgpool(x):
+    require_cuda(x)
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, 1, 1), dtype=_f32, device=x.device)
+    call("di2p_global_avgpool", ptr(x), ptr(y), B, C, H * W, stream())
+    return y
+
+
+# ------------------------------------------------------------------------------------ solver
+def _dbl3(v):
+    a = (ctypes.c_double * 3)()
+    for i in range(3):
+        a[i] = float(v[i])      # IndexError on short lists, like the reference's .at(i)
+    return a
+
+
+def initial_guess(points64, labels):
+    require_cuda(points64, labels)
+    F, _, N = points64.shape
+    yaw0 = torch.empty((F,), dtype=_f64, device=points64.device)
+    labels_out = torch.empty_like(labels)
+    has_inside = torch.empty((F,), dtype=_i32, device=points64.device)
+    call("di2p_initial_guess", ptr(points64), ptr(labels), ptr(yaw0), ptr(labels_out), ptr(has_inside), F, N, stream())
+    return yaw0, labels_out, has_inside
+
+
+def solve_batched(points, labels, K, init_y, init_T, H, W, lb, ub, max_iter, is_2d, yaw0=None):
+    """points f64|f32 [F,3,N], labels i32[F,N], K f64[F,3,3], init_y f64[F,R], init_T f64[F,R,3]
+    -> params f64[F,R,np], cost f64[F,R], iters i32[F,R]."""
+    require_cuda(points, labels, K, init_y, init_T, yaw0)
+    _chk(labels, _i32, "labels")
+    _chk(K, _f64, "K")
+    _chk(init_y, _f64, "init_y")
+    _chk(init_T, _f64, "init_T")
+    F, _, N = points.shape
+    R = init_y.shape[1]
+    npar = 4 if is_2d else 6
+    params = torch.empty((F, R, npar), dtype=_f64, device=points.device)
+    cost = torch.empty((F, R), dtype=_f64, device=points.device)
+    iters = torch.empty((F, R), dtype=_i32, device=points.device)
+    name = "di2p_solve_batched" if points.dtype == _f64 else "di2p_solve_batched_f32"
+    if points.dtype not in (_f64, _f32):
+        raise RuntimeError("points must be float64 or float32")
+    call(name, ptr(points), ptr(labels), ptr(K), ptr(init_y), ptr(init_T), ptr(yaw0), float(H), float(W), _dbl3(lb),
+         _dbl3(ub), int(max_iter), int(bool(is_2d)), F, R, N, ptr(params), ptr(cost), ptr(iters), stream())
+    return params, cost, iters
+
+
+def select_best(params, cost, is_2d, has_inside=None):
+    require_cuda(params, cost, has_inside)
+    F, R = cost.shape
+    best = torch.empty((F,), dtype=_i32, device=cost.device)
+    P = torch.empty((F, 4, 4), dtype=_f64, device=cost.device)
+    bc = torch.empty((F,), dtype=_f64, device=cost.device)
+    call("di2p_select_best", ptr(params), ptr(cost), ptr(has_inside), int(bool(is_2d)), F, R, ptr(best), ptr(P), ptr(bc), stream())
+    return best, P, bc
+
+
+def solver_residuals(points64, labels, K, params, H, W, is_2d):
+    require_cuda(points64, labels, K, params)
+    F, _, N = points64.shape
+    res = torch.empty((F, 3 * N), dtype=_f64, device=points64.device)
+    counts = torch.empty((F,), dtype=_i32, device=points64.device)
+    cost = torch.empty((F,), dtype=_f64, device=points64.device)
+    call("di2p_solver_residuals", ptr(points64), ptr(labels), ptr(K), ptr(params), float(H), float(W), int(bool(is_2d)),
+         F, N, ptr(res), ptr(counts), ptr(cost), stream())
+    return res, counts, cost

@@ -1,0 +1,195 @@
+/*
+ * deepi2p_hip.h -- C ABI of libdeepi2p_hip.so: the MI355X (gfx950) implementation of the
+ * DeepI2P registration hot path.  Plain pointers and sizes only; every pointer is a DEVICE
+ * pointer (HBM) unless the name ends in _host; `stream` is a hipStream_t passed as void*
+ * (NULL = the null stream).  No function allocates, frees or synchronises: all are safe to
+ * capture into a hipGraph.  Return value: 0 on success, otherwise a hipError_t / negative
+ * argument-check code; di2p_last_error() returns a static description.
+ *
+ * Each entry point names the reference interface (path:line under lijx10/DeepI2P) it replaces.
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Tensor layouts are the reference's own: point features f32 [B,C,N] (N contiguous), images
+ * f32 NCHW, indices i32.
+ */
+#ifndef DEEPI2P_HIP_H
+#define DEEPI2P_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* di2p_last_error(void);
+int di2p_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * index_max  -- replaces models/index_max_ext: index_max.cpp:141-148 (forward_cuda_shared_mem),
+ * :132-139 (forward_cuda); kernels index_max_cuda.cu:10-26, :30-62.
+ *   data f32[B,C,N], index i32[B,N] with values in [0,K)  ->  max_idx i32[B,C,K]
+ *   max_idx[b,c,k] = first n with index[b,n]==k attaining max(data[b,c,n]) ; floor -1000 ;
+ *   empty cluster (or nothing > -1000) -> 0.
+ * di2p_index_max_values additionally writes the maxima themselves with empty clusters zeroed,
+ * i.e. data.gather(2,max_idx) * mask_row_max of models/networks_pc.py:91-92,103-104 (max_idx may
+ * be NULL there; mask f32[B,K] = mask_row_max from di2p_cluster_stats, or NULL = "a node is
+ * non-empty iff something beat the floor").  `workspace` must hold B*C*K uint64 (scratch, contents undefined after). */
+int di2p_index_max_forward(const float* data, const int32_t* index, int32_t* max_idx,
+                           int B, int C, int N, int K, void* workspace, void* stream);
+int di2p_index_max_values(const float* data, const int32_t* index, const float* mask, float* max_val,
+                          int32_t* max_idx, int B, int C, int N, int K, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ball_query -- replaces models/ball_query_ext: ball_query.cpp:33-39 (forward_cuda_shared_mem),
+ * kernel ball_query_cuda.cu:11-50.  node_to_point_dist f32[B,M,N] -> i32[B,M,K]: first K point
+ * ids (ascending n) with dist <= radius, cyclically padded; all zero when none. */
+int di2p_ball_query_forward(const float* node_to_point_dist, int32_t* out_idx, float radius, int K,
+                            int B, int M, int N, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Point <-> node kernels of PCEncoder / KeypointDetector.
+ *
+ * di2p_knn_nodes: the dense-distance + torch.topk(k smallest, sorted) idiom of
+ *   models/networks_pc.py:61-65, models/networks_united.py:158-161,176-178,
+ *   models/layers_pc.py:798-799.   query f32[B,3,Nq], nodes f32[B,3,M] ->
+ *   idx i32[B,Nq,k] ascending distance, ties -> lower node id.  weights (may be NULL) f32[B,Nq,k]
+ *   = 1 - d_k/sum_j d_j, the interpolation weights of networks_united.py:97-98.
+ *   k <= 16, M <= 1024.
+ * di2p_cluster_stats: networks_pc.py:66-76.  pc f32[B,3,N], knn idx (nearest = idx[b,n,0], row
+ *   stride idx_stride) -> cluster_mean f32[B,3,M] = sum/(count+1e-5), mask f32[B,M] (1 if the
+ *   node owns >=1 point), min_idx i32[B,N] (compact copy of the nearest id).
+ * di2p_build_point_input: networks_pc.py:79-85.  -> pc_centers f32[B,3,N],
+ *   augmented f32[B,7,N] = cat(pc - centers, intensity, sn).
+ * di2p_interpolate: networks_united.py:90-103 (upsample_by_interpolation given idx+weights):
+ *   feats f32[B,C,M] -> out f32[B,C,Nq] = sum_k w[b,n,k] * feats[b,c,idx[b,n,k]].
+ * di2p_gather_neighbors: layers_pc.py:800-807 coordinates part: out f32[B,3,Mq*K] =
+ *   database[:, idx] - query.
+ * di2p_argmax_channels: multimodal_classifier.py:115-116.  scores f32[B,C,N] -> i32[B,N], first
+ *   maximum wins. */
+int di2p_knn_nodes(const float* query, const float* nodes, int32_t* idx, float* weights,
+                   int B, int Nq, int M, int k, void* stream);
+int di2p_cluster_stats(const float* pc, const int32_t* knn_idx, int idx_stride, float* cluster_mean,
+                       float* mask, int32_t* min_idx, int B, int N, int M, void* stream);
+int di2p_build_point_input(const float* pc, const float* intensity, const float* sn,
+                           const float* cluster_mean, const int32_t* min_idx, float* pc_centers,
+                           float* augmented, int B, int N, int M, void* stream);
+int di2p_interpolate(const float* feats, const int32_t* idx, const float* weights, float* out,
+                     int B, int C, int M, int Nq, int k, void* stream);
+int di2p_gather_neighbors(const float* database, const float* query, const int32_t* idx, float* out,
+                          int B, int Md, int Mq, int K, void* stream);
+int di2p_argmax_channels(const float* scores, int32_t* out, int B, int C, int N, long long batch_stride /* elements; 0 = C*N */, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pointwise contraction = EquivariantLayer / MyConv2d(1x1) (+BN eval +ReLU) of
+ * models/layers_pc.py:259-342, :110-190, with the torch.cat / expand / gather feeding it
+ * (networks_pc.py:98, layers_pc.py:808-813, networks_united.py:139-197) folded into the operand
+ * loader.  fp32 in, fp32 MFMA (v_mfma_f32_32x32x2_f32) accumulate, fp32 out.
+ *
+ *   Y[b,m,n'] = epi( sum_k Wt[k,m] * X[b,k,n] )        n' = n, or n / group_max when group_max > 1
+ *   epi(a)    = relu?( scale[m]*(a + batch_bias[b,m] + sum_t sum_j gw_t[b,n,j]*G_t[b,m,gidx_t[b,n,j]]) + shift[m] )
+ *   (scale/shift = folded BatchNorm(eval) + conv bias; the batch_bias and gathered terms are part of
+ *   the pre-activation, i.e. they stand for input channels that were never materialised)
+ *
+ * X is the virtual concatenation along k of up to DI2P_MAX_SRC sources.  Wt is the layer weight
+ * transposed to [K,M] (packed once at load time).  group_max > 1 takes the max over each run of
+ * `group_max` consecutive columns (torch.max(dim=3) of layers_pc.py:811,816). */
+#define DI2P_MAX_SRC 3
+enum { DI2P_SRC_DENSE = 0,   /* X[b,c,n]      = ptr[b*batch_stride + c*row_stride + n]            */
+       DI2P_SRC_GATHER = 1,  /* X[b,c,n]      = ptr[b*batch_stride + c*row_stride + gidx[b,n]]    */
+       DI2P_SRC_GROUP = 2    /* X[b,c,n]      = ptr[b*batch_stride + c*row_stride + n / group]    */ };
+typedef struct {
+    const float* ptr;
+    const int32_t* gidx;     /* GATHER: i32[B, N] (batch stride = N) */
+    long long batch_stride;  /* elements */
+    int row_stride;          /* elements */
+    int channels;
+    int mode;
+    int group;               /* GROUP mode divisor */
+    int pad_;
+} di2p_src_t;
+
+typedef struct {
+    const float* scale;        /* [M] or NULL (=1) */
+    const float* shift;        /* [M] or NULL (=0) */
+    const float* batch_bias;   /* [B,M] or NULL    */
+    int relu;
+    int group_max;             /* 1 = none */
+    /* optional gathered add (per_point_pn layer 0 with W*interp == interp(W*nodes)):            */
+    const float* g_table[2];   /* each f32[B,M,g_nodes] or NULL */
+    const int32_t* g_idx[2];   /* i32[B,N,g_k] */
+    const float* g_w[2];       /* f32[B,N,g_k] */
+    int g_nodes[2];
+    int g_k;
+} di2p_epilogue_t;
+
+int di2p_pointwise_gemm(const di2p_src_t* srcs_host, int n_src, const float* Wt, float* Y,
+                        int B, int M, int K, int N, const di2p_epilogue_t* epi_host, void* stream);
+
+/* Y[b,m] = sum_k Wt[k0+k, m] * v[b,k]  (the broadcast part of a concatenated input, folded into
+ * batch_bias: networks_united.py:139-155,170-187 expand()s).  v f32[B,Kv]. */
+int di2p_batch_gemv(const float* Wt, int M, int k0, const float* v, int Kv, float* out, int B, void* stream);
+
+/* Batched attention contraction of networks_united.py:147-150,170-174:
+ * out[b,c,m] = (1/HW) * sum_hw feat[b,c,hw] * score[b,hw,m]. */
+int di2p_attention_pool(const float* feat, const float* score, float* out, int B, int C, int HW, int Mn, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Image branch: ResNet-34 of models/resnet.py:56-72,125-216 (BasicBlock conv-bn-relu, residual
+ * add, 7x7/2 stem, 3x3/2 max-pool, global average pool) as implicit-GEMM convolutions on fp32
+ * MFMA with the BN(eval)+residual+ReLU epilogue fused.
+ *   x f32[B,Cin,H,W] (NCHW), Wt f32[Cin*KH*KW, Cout] (weight[co,ci,kh,kw] transposed), y
+ *   f32[B,Cout,OH,OW];  y = relu?( scale*conv(x) + shift + residual ). */
+int di2p_conv2d(const float* x, const float* Wt, const float* scale, const float* shift,
+                const float* residual, float* y, int B, int Cin, int H, int W, int Cout,
+                int KH, int KW, int stride, int pad, int relu, void* stream);
+int di2p_maxpool3x3s2(const float* x, float* y, int B, int C, int H, int W, void* stream);
+int di2p_global_avgpool(const float* x, float* y, int B, int C, int HW, void* stream);
+/* out[b,c] = max_n x[b,c,n]  (networks_pc.py:115) */
+int di2p_channel_max(const float* x, float* y, int B, int C, int N, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Registration: replaces evaluation/frustum_reg (registration.cpp:9-186 solvePGivenK, bound at
+ * :190-206) + Ceres, and the 60-restart process fan-out of evaluation/registration_lsq.py:142-186.
+ *
+ * di2p_initial_guess: registration_lsq.py:196-220 on device.  points f64[F,3,N], labels
+ *   i32[F,N] -> yaw0 f64[F]; labels_out i32[F,N] = label, or -1 for points removed by the front
+ *   filter (the solver skips labels not in {0,1}, registration.cpp:87-125); has_inside i32[F].
+ * di2p_solve_batched: F frames x R hypotheses.  One wavefront per hypothesis; Cauchy-robust
+ *   Levenberg-Marquardt with box bounds on t (see DESIGN.md for the exact algorithm statement).
+ *   points f64[F,3,N], labels i32[F,N], K f64[F,3,3] (fx,fy,cx,cy used), init_y f64[F,R],
+ *   init_T f64[F,R,3], lb/ub f64[3] HOST arrays, is_2d: 4 params [ry,tx,ty,tz] else 6
+ *   [angle-axis, t].  Outputs: params f64[F,R,np], cost f64[F,R], iters i32[F,R].
+ *   If yaw0 != NULL it is added to init_y per frame (restart noise drawn before yaw0 is known).
+ * di2p_select_best: argmin cost over R per frame (ties -> lowest r; frames with has_inside==0 get
+ *   identity and cost 1e4, registration_lsq.py:329-332) -> best i32[F], P f64[F,4,4], cost f64[F].
+ * di2p_solver_residuals: Problem::Evaluate of registration.cpp:150-155 at given params:
+ *   loss-corrected residuals in point order (3 per label-1 point, 1 per label-0 point), compacted
+ *   per frame into residuals f64[F, 3N] with counts i32[F]; cost f64[F]. */
+int di2p_initial_guess(const double* points, const int32_t* labels, double* yaw0, int32_t* labels_out,
+                       int32_t* has_inside, int F, int N, void* stream);
+int di2p_solve_batched(const double* points, const int32_t* labels, const double* K,
+                       const double* init_y, const double* init_T, const double* yaw0,
+                       double H, double W, const double* lb_host, const double* ub_host,
+                       int max_iter, int is_2d, int F, int R, int N,
+                       double* params, double* cost, int32_t* iters, void* stream);
+/* Same solver reading the points as f32 [F,3,N] (the network's own pc tensor; widening to f64 is
+ * exact, so results are bit-identical to di2p_solve_batched on the widened copy). */
+int di2p_solve_batched_f32(const float* points, const int32_t* labels, const double* K,
+                           const double* init_y, const double* init_T, const double* yaw0,
+                           double H, double W, const double* lb_host, const double* ub_host,
+                           int max_iter, int is_2d, int F, int R, int N,
+                           double* params, double* cost, int32_t* iters, void* stream);
+int di2p_select_best(const double* params, const double* cost, const int32_t* has_inside, int is_2d,
+                     int F, int R, int32_t* best, double* P, double* best_cost, void* stream);
+int di2p_solver_residuals(const double* points, const int32_t* labels, const double* K,
+                          const double* params, double H, double W, int is_2d, int F, int N,
+                          double* residuals, int32_t* counts, double* cost, void* stream);
+
+/* f32 -> f64 widening copy of the point cloud for the solver ([B,3,N]) and i32 label passthrough
+ * are done by the caller; helper for the fused pipeline: */
+int di2p_f32_to_f64(const float* in, double* out, long long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPI2P_HIP_H */

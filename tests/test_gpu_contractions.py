@@ -1,0 +1,128 @@
+"""GPU parity of the fp32-MFMA contractions (pointwise GEMM with its virtual-concat loader and fused
+epilogues, implicit-GEMM conv, pooling) vs plain PyTorch fp32 on CPU.  Tolerance: fp32 round-off of a
+K-term dot product, |err| <= 2e-6 * K^0.5 * max|out| + 1e-6 (stated per test)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _tol(ref, K):
+    return 3e-6 * (K ** 0.5) * float(ref.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("B,M,K,N", [(2, 32, 7, 1000), (1, 64, 64, 4096), (2, 128, 96, 777), (3, 256, 67, 2048),
+                                      (1, 1024, 300, 128), (2, 2, 128, 513), (1, 82, 256, 640), (1, 33, 17, 65)])
+def test_pointwise_gemm_dense(dev, B, M, K, N):
+    from deepi2p_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    x, W = torch.randn(B, K, N, generator=g), torch.randn(M, K, generator=g) / K ** 0.5
+    scale, shift = torch.rand(M, generator=g) + 0.5, torch.randn(M, generator=g)
+    y = ops.pointwise_gemm([ops.Src(x.to(dev))], W.t().contiguous().to(dev), M, N, scale=scale.to(dev),
+                           shift=shift.to(dev), relu=True).cpu()
+    ref = torch.relu(torch.einsum("mk,bkn->bmn", W, x) * scale.view(1, M, 1) + shift.view(1, M, 1))
+    assert (y - ref).abs().max() <= _tol(ref, K)
+
+
+def test_pointwise_gemm_transpose_detecting(dev):
+    """A = identity-like weights with an ASYMMETRIC input: catches row/col swaps in the MFMA C layout."""
+    from deepi2p_amd import ops
+    M = K = 64
+    N = 128
+    x = (torch.arange(K).view(1, K, 1) * 1000.0 + torch.arange(N).view(1, 1, N)).contiguous()
+    y = ops.pointwise_gemm([ops.Src(x.to(dev))], torch.eye(K).to(dev), M, N).cpu()
+    assert torch.equal(y, x)
+
+
+def test_pointwise_gemm_concat_gather_group_bias(dev):
+    from deepi2p_amd import _lib, ops
+    g = torch.Generator().manual_seed(1)
+    B, N, Mn, grp = 2, 2048, 128, 16
+    a = torch.randn(B, 3, N, generator=g)                       # dense
+    tab = torch.randn(B, 64, Mn, generator=g)                   # gathered by index
+    gi = torch.randint(0, Mn, (B, N), generator=g, dtype=torch.int32)
+    grpsrc = torch.randn(B, 20, N // grp, generator=g)          # group-broadcast
+    bvec = torch.randn(B, 40, generator=g)                      # broadcast channels -> batch bias
+    K, M = 3 + 64 + 20 + 40, 96
+    W = torch.randn(M, K, generator=g) / K ** 0.5
+    Wt = W.t().contiguous().to(dev)
+    Wt_dense = torch.cat((Wt[:87],), 0).contiguous()
+    bias = ops.batch_gemv(Wt, 87, bvec.to(dev))
+    y = ops.pointwise_gemm([ops.Src(a.to(dev)), ops.Src(tab.to(dev), _lib.SRC_GATHER, gidx=gi.to(dev)),
+                            ops.Src(grpsrc.to(dev), _lib.SRC_GROUP, group=grp)], Wt_dense, M, N, batch_bias=bias).cpu()
+    full = torch.cat((a, torch.gather(tab, 2, gi.long().unsqueeze(1).expand(B, 64, N)),
+                      grpsrc.repeat_interleave(grp, dim=2), bvec.unsqueeze(2).expand(B, 40, N)), dim=1)
+    ref = torch.einsum("mk,bkn->bmn", W, full)
+    assert (y - ref).abs().max() <= _tol(ref, K)
+    # fused max over groups of 16 consecutive columns (torch.max(dim=3) of layers_pc.py:811,816)
+    ym = ops.pointwise_gemm([ops.Src(full.to(dev))], Wt, M, N, relu=True, group_max=grp).cpu()
+    refm = torch.relu(ref).view(B, M, N // grp, grp).max(dim=3)[0]
+    assert (ym - refm).abs().max() <= _tol(ref, K)
+
+
+def test_pointwise_gemm_gathered_add(dev):
+    """per_point_pn layer 0: W @ cat(interp_a, interp_b, x) == gathered per-node products + W_x @ x."""
+    from deepi2p_amd import ops
+    g = torch.Generator().manual_seed(2)
+    B, N, Ma, Mb, M = 2, 1500, 128, 128, 128
+    fa, fb = torch.randn(B, 128, Ma, generator=g), torch.randn(B, 512, Mb, generator=g)
+    x = torch.randn(B, 96, N, generator=g)
+    ia = torch.randint(0, Ma, (B, N, 3), generator=g, dtype=torch.int32)
+    ib = torch.randint(0, Mb, (B, N, 3), generator=g, dtype=torch.int32)
+    wa, wb = torch.rand(B, N, 3, generator=g), torch.rand(B, N, 3, generator=g)
+    W = torch.randn(M, 736, generator=g) / 736 ** 0.5
+    scale, shift = torch.rand(M, generator=g) + 0.5, torch.randn(M, generator=g)
+    Wt = W.t().contiguous().to(dev)
+    Ga = ops.pointwise_gemm([ops.Src(fa.to(dev))], Wt[0:128], M, Ma)
+    Gb = ops.pointwise_gemm([ops.Src(fb.to(dev))], Wt[128:640], M, Mb)
+    y = ops.pointwise_gemm([ops.Src(x.to(dev))], Wt[640:736], M, N, scale=scale.to(dev), shift=shift.to(dev), relu=True,
+                           gathered=[(Ga, ia.to(dev), wa.to(dev)), (Gb, ib.to(dev), wb.to(dev))]).cpu()
+
+    def interp(f, i, w):
+        Bc, C, Mn = f.shape
+        gth = torch.gather(f.unsqueeze(3).expand(Bc, C, Mn, 3), 2, i.long().unsqueeze(1).expand(Bc, C, N, 3))
+        return (w.unsqueeze(1) * gth).sum(3)
+    full = torch.cat((interp(fa, ia, wa), interp(fb, ib, wb), x), dim=1)
+    ref = torch.relu(torch.einsum("mk,bkn->bmn", W, full) * scale.view(1, M, 1) + shift.view(1, M, 1))
+    assert (y - ref).abs().max() <= _tol(ref, 736) * 2
+
+
+def test_attention_pool(dev):
+    from deepi2p_amd import ops
+    g = torch.Generator().manual_seed(3)
+    feat, score = torch.randn(2, 256, 320, generator=g), torch.randn(2, 320, 128, generator=g)
+    out = ops.attention_pool(feat.to(dev), score.to(dev)).cpu()
+    ref = torch.mean(feat.unsqueeze(3) * score.unsqueeze(1), dim=2)           # the reference's formulation
+    assert (out - ref).abs().max() <= _tol(ref, 320)
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p", [(2, 3, 64, 128, 64, 7, 2, 3), (2, 64, 16, 32, 64, 3, 1, 1),
+                                                  (1, 64, 16, 32, 128, 3, 2, 1), (2, 64, 16, 32, 128, 1, 2, 0),
+                                                  (3, 256, 5, 16, 512, 3, 2, 1), (1, 512, 5, 16, 512, 3, 1, 1),
+                                                  (1, 5, 9, 11, 7, 3, 1, 1)])
+def test_conv2d(dev, B, Cin, H, W, Cout, k, s, p):
+    from deepi2p_amd import ops
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    ref0 = F.conv2d(x, w, None, stride=s, padding=p) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    res = torch.randn(ref0.shape, generator=g)
+    Wt = w.reshape(Cout, -1).t().contiguous().to(dev)
+    y = ops.conv2d(x.to(dev), Wt, scale.to(dev), shift.to(dev), k, k, s, p, True, residual=res.to(dev)).cpu()
+    ref = torch.relu(ref0 + res)
+    assert y.shape == ref.shape
+    assert (y - ref).abs().max() <= _tol(ref0, Cin * k * k)
+    y2 = ops.conv2d(x.to(dev), Wt, scale.to(dev), shift.to(dev), k, k, s, p, False).cpu()
+    assert (y2 - ref0).abs().max() <= _tol(ref0, Cin * k * k)
+
+
+def test_pools(dev):
+    from deepi2p_amd import ops
+    x = torch.randn(2, 64, 32, 64)
+    assert torch.equal(ops.maxpool3x3s2(x.to(dev)).cpu(), F.max_pool2d(x, 3, 2, 1))
+    x2 = torch.randn(2, 7, 33, 65)
+    assert torch.equal(ops.maxpool3x3s2(x2.to(dev)).cpu(), F.max_pool2d(x2, 3, 2, 1))
+    y = torch.randn(3, 512, 5, 16)
+    torch.testing.assert_close(ops.global_avgpool(y.to(dev)).cpu(), F.adaptive_avg_pool2d(y, 1), rtol=1e-5, atol=1e-6)

@@ -1,0 +1,116 @@
+"""GPU parity of the whole classification network (HIP kernels behind deepi2p_amd.networks) against
+  (1) golden vectors produced by the IMPORTED REFERENCE (tests/golden/make_golden.py), and
+  (2) the oracle restatement on fresh seeded inputs.
+Stated tolerances: |dlogit| <= 1e-3 * max|logit| ; label flips < 0.1 % ; 3-NN indices equal except
+at distance ties."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import network_torch as nt
+
+pytestmark = pytest.mark.gpu
+REL = 1e-3
+
+
+def _detector(dev, N, H, W, fine):
+    from deepi2p_amd.networks import KeypointDetector
+    opt = nt.OptLike(N, H, W, fine)
+    det = KeypointDetector(opt)
+    det.load_state_dict(nt.synthetic_state_dict(opt))
+    return det.to(dev).eval(), opt
+
+
+def _close(a, b, name, rel=REL):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    assert a.shape == b.shape, name
+    err = float((a - b).abs().max())
+    lim = rel * float(b.abs().max()) + 1e-7
+    assert err <= lim, "%s: max err %.3g > %.3g" % (name, err, lim)
+
+
+@pytest.mark.parametrize("fname", ["network_golden.npz", "network_coarse_golden.npz"])
+def test_network_vs_reference_golden(dev, golden, fname):
+    g = golden(fname)
+    B, N, H, W, fine = [int(v) for v in g["meta"]]
+    det, opt = _detector(dev, N, H, W, bool(fine))
+    t = {k: torch.from_numpy(g[k]).to(dev) for k in ("pc", "intensity", "sn", "node_a", "node_b", "img")}
+    enc = det.pc_encoder(t["pc"], t["intensity"], t["sn"], t["node_a"], t["node_b"])
+    assert enc[2].dtype == torch.int64
+    for i, name in enumerate(["pc_centers", "cluster_mean", None, "first_pn_out", "second_pn_out", "node_a_features",
+                              "node_b_features", "global_feature"]):
+        if name:
+            _close(enc[i], g[name], name)
+    mism = (enc[2].cpu().numpy() != g["min_k_idx"]).mean()
+    assert mism < 2e-3, "3-NN index mismatch rate %.4f" % mism
+    s16, s32, glob = det.img_encoder(t["img"])
+    _close(s16, g["s16"], "s16"); _close(s32, g["s32"], "s32"); _close(glob, g["img_global"], "img_global")
+    out = det(t["pc"], t["intensity"], t["sn"], t["node_a"], t["node_b"], t["img"])
+    coarse = out[0] if fine else out
+    _close(coarse, g["coarse"], "coarse logits")
+    flips = (coarse.argmax(1).cpu().numpy() != g["coarse"].argmax(1)).mean()
+    assert flips < 1e-3, "coarse label flip rate %.4f" % flips
+    if fine:
+        _close(out[1], g["fine"], "fine logits")
+        assert (out[1].argmax(1).cpu().numpy() != g["fine"].argmax(1)).mean() < 1e-3
+
+
+def test_network_vs_oracle_fresh_inputs(dev):
+    """Different seed, KITTI-like geometry, B=1, N=2048, 96x160: logits and argmax labels vs the oracle."""
+    from deepi2p_amd import synthetic
+    from deepi2p_amd.networks import MMClassifer
+    N, H, W = 2048, 96, 160
+    batch = synthetic.make_batch(11, 1, N=N, H=H, W=W)
+    opt = nt.OptLike(N, H, W, True)
+    opt.device = dev
+    sd = nt.synthetic_state_dict(opt, seed=3)
+    mm = MMClassifer(opt)
+    mm.detector.load_state_dict({("module." + k): v for k, v in sd.items()} if False else sd)
+    cpu = {k: torch.from_numpy(batch[k]) for k in ("pc", "intensity", "sn", "node_a", "node_b", "img")}
+    mm.set_input(cpu["pc"], cpu["intensity"], cpu["sn"], cpu["node_a"], cpu["node_b"], torch.zeros(1, 3, 4),
+                 cpu["img"], torch.from_numpy(batch["K"]).float())
+    cp, fp = mm.inference_pass()
+    assert cp.dtype == torch.int64 and cp.shape == (1, N)
+    with torch.no_grad():
+        coarse, fine = nt.keypoint_detector(sd, opt, cpu["pc"], cpu["intensity"], cpu["sn"], cpu["node_a"], cpu["node_b"], cpu["img"])
+    out = mm.forward(mm.pc, mm.intensity, mm.sn, mm.node_a, mm.node_b, mm.img)
+    _close(out[0], coarse, "coarse"); _close(out[1], fine, "fine")
+    assert (cp.cpu() != coarse.argmax(1)).float().mean() < 1e-3
+    assert (fp.cpu() != fine.argmax(1)).float().mean() < 1e-3
+
+
+def test_checkpoint_key_compat_module_prefix(dev, tmp_path):
+    """load_model accepts DataParallel ('module.') checkpoints (util/pytorch_helper.py:24-33)."""
+    from deepi2p_amd.networks import MMClassiferCoarse
+    opt = nt.OptLike(512, 64, 64, False)
+    opt.device = dev
+    sd = nt.synthetic_state_dict(opt)
+    path = tmp_path / "ckpt.pth"
+    torch.save({"module." + k: v for k, v in sd.items()}, path)
+    mm = MMClassiferCoarse(opt)
+    mm.load_model(str(path))
+    got = mm.detector.state_dict()
+    assert list(got.keys()) == list(sd.keys())
+    assert all(torch.equal(got[k].cpu(), sd[k]) for k in sd)
+
+
+def test_pcencoder_rejects_wrong_N(dev):
+    det, opt = _detector(dev, 512, 64, 64, False)
+    x = torch.zeros(1, 3, 256, device=dev)
+    with pytest.raises(RuntimeError):
+        det.pc_encoder(x, x[:, :1], x, x[:, :, :128].contiguous(), x[:, :, :128].contiguous())
+
+
+def test_full_size_forward_properties(dev):
+    """BASELINE config-2 shape (N=20480, 160x512, coarse head), B=4: finite outputs, batch independence
+    (frame b's logits do not depend on its batch neighbours) and determinism."""
+    from deepi2p_amd import synthetic
+    det, opt = _detector(dev, 20480, 160, 512, False)
+    batch = synthetic.make_batch(5, 4)
+    t = {k: torch.from_numpy(batch[k]).to(dev) for k in ("pc", "intensity", "sn", "node_a", "node_b", "img")}
+    out = det(t["pc"], t["intensity"], t["sn"], t["node_a"], t["node_b"], t["img"])
+    assert out.shape == (4, 2, 20480) and torch.isfinite(out).all()
+    out2 = det(t["pc"], t["intensity"], t["sn"], t["node_a"], t["node_b"], t["img"])
+    assert torch.equal(out, out2)
+    one = det(*[t[k][2:3].contiguous() for k in ("pc", "intensity", "sn", "node_a", "node_b", "img")])
+    assert torch.equal(one[0], out[2])
