@@ -94,9 +94,17 @@ def main():
     restarts = pipe.draw(B, dev)
     torch.cuda.synchronize()
 
+    # The weights are random-init (no checkpoints exist here), so the network's argmax labels carry no frustum
+    # information (typically "all outside", for which the reference skips the solver, registration_lsq.py:329-332).
+    # Per SURVEY.md 8(d) the solver therefore consumes the synthetic labels = exact frustum labels with 5 % random
+    # flips; the network forward + argmax still run in full inside the timed step and their output is kept.
+    solver_labels = torch.from_numpy(batch["labels"]).to(dev)
+
     def step():
-        labels = mm.inference_pass()                       # network + argmax  (i64, reference API)
-        return pipe(mm.pc, labels.to(torch.int32), K64, restarts)
+        pred = mm.inference_labels()                       # image + point + fusion network, argmax (i32 [B,N])
+        o = pipe(mm.pc, solver_labels, K64, restarts)
+        o["pred"] = pred
+        return o
 
     def sync_all():
         if world > 1:
@@ -160,7 +168,8 @@ def main():
             "metric": "frames/sec (img+pc infer + 60-restart GN pose) KITTI 20k-pt, 1/2/4/8 GPU",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 network (fp32-input MFMA) + f64 solver", "data": "synthetic",
+            "dtype": "f32 network (fp32-input MFMA) + f64 solver",
+            "data": "synthetic frames, random-init closed-form weights; solver labels = GT frustum labels with 5% flips (SURVEY 8d)",
             "config": {"workload": "BASELINE configs[1]: KITTI 20480-pt / 160x512, batch %d per GPU, coarse classification "
                                    "+ %d-restart 2D GN/LM solver, max_iter 500" % (B, R),
                        "frames_per_gpu_per_step": B, "points": N, "image": [H, W], "restarts": R, "parallelism": "dp%d" % world},
@@ -175,7 +184,13 @@ def main():
 def pose_check(out, batch):
     """Sanity (not parity): the network has random weights, so its labels are meaningless; report only that the
     solver ran to completion on them."""
-    return {"mean_iters": float(out["iters"].float().mean()), "frames_with_inside_points": int((out["best"] >= 0).sum())}
+    from oracle import frustum_lm as flm
+    P = out["P"].cpu().numpy()
+    errs = [flm.get_P_diff(P[i], batch["P_gt"][i]) for i in range(P.shape[0])]
+    ok = sum(1 for t, r in errs if t < 2.0 and r < 5.0)
+    return {"mean_iters": float(out["iters"].float().mean()), "frames_with_inside_points": int((out["best"] >= 0).sum()),
+            "frames_within_2m_5deg_of_gt": ok, "frames": int(P.shape[0]),
+            "network_pred_inside_fraction": float((out["pred"] == 1).float().mean())}
 
 
 def run_cpu_baseline(batch, sd, opt, H, W, R):
@@ -183,7 +198,8 @@ def run_cpu_baseline(batch, sd, opt, H, W, R):
     from oracle import frustum_lm as flm
     from oracle import network_torch as nt
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    net_threads = min(cores, 32)      # torch CPU ops stop scaling (and regress) far below the box's 256 threads
+    torch.set_num_threads(net_threads)
     nb = 2
     t = {k: torch.from_numpy(batch[k][:nb]) for k in ("pc", "intensity", "sn", "node_a", "node_b", "img")}
     with torch.no_grad():
@@ -193,7 +209,7 @@ def run_cpu_baseline(batch, sd, opt, H, W, R):
         t_net = (time.perf_counter() - t0) / nb
     labels = logits.argmax(1).numpy().astype(np.int32)
     pc = batch["pc"][0].astype(np.float64)
-    lab = labels[0] if labels[0].sum() > 0 else batch["labels"][0]
+    lab = batch["labels"][0]          # same synthetic solver labels as the GPU leg
     _, y0, pcf, labf = flm.get_initial_guess(pc, lab)
     rng = np.random.default_rng(0)
     ys, Ts = flm.draw_restarts(rng, R, y0, 10 * math.pi / 180, 10)
@@ -202,7 +218,7 @@ def run_cpu_baseline(batch, sd, opt, H, W, R):
     t_sol = time.perf_counter() - t0
     return {"value": 1.0 / (t_net + t_sol), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "network: %d frames (torch fp32, %d threads, %.2f s/frame); solver: 1 frame x %d restarts over %d threads "
-                      "(%.2f s, mean %.1f LM iterations)" % (nb, cores, t_net, R, cores, t_sol, float(iters.mean()))}
+                      "(%.2f s, mean %.1f LM iterations)" % (nb, net_threads, t_net, R, cores, t_sol, float(iters.mean()))}
 
 
 if __name__ == "__main__":

@@ -53,14 +53,14 @@ _SIGS = {
     "di2p_channel_max": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "di2p_initial_guess": [c_void_p] * 5 + [c_int, c_int, c_void_p],
     "di2p_solve_batched": [c_void_p] * 6 + [c_double, c_double, ctypes.POINTER(c_double), ctypes.POINTER(c_double)]
-                          + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_void_p],
+                          + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "di2p_solve_batched_f32": [c_void_p] * 6 + [c_double, c_double, ctypes.POINTER(c_double), ctypes.POINTER(c_double)]
-                              + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_void_p],
+                              + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "di2p_select_best": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "di2p_solver_residuals": [c_void_p] * 4 + [c_double, c_double, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "di2p_f32_to_f64": [c_void_p, c_void_p, c_ll, c_void_p],
 }
-EXPORTS = sorted(list(_SIGS) + ["di2p_last_error", "di2p_version"])
+EXPORTS = sorted(list(_SIGS) + ["di2p_last_error", "di2p_version", "di2p_solve_workspace_bytes"])
 
 
 def load():
@@ -78,6 +78,8 @@ def load():
             fn.restype = c_int
         lib.di2p_last_error.restype = ctypes.c_char_p
         lib.di2p_version.restype = c_int
+        lib.di2p_solve_workspace_bytes.restype = c_ll
+        lib.di2p_solve_workspace_bytes.argtypes = [c_int, c_int]
         _lib = lib
     return _lib
 

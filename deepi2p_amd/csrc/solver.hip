@@ -19,6 +19,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -85,17 +86,177 @@ __device__ __forceinline__ void make_rot(const double* x, Rot<NP>& r) {
     }
 }
 
-// One sweep over the frame's points: cost (1/2 sum rho), and if FULL the loss-corrected J^T r and
-// J^T J.  Returns false (wave-uniform) if anything was non-finite.
-template <int NP, bool FULL, typename PT>
-__device__ __forceinline__ bool sweep(const PT* __restrict__ px_, const PT* __restrict__ py_, const PT* __restrict__ pz_,
-                                      const int* __restrict__ labels, int N, const Cam& k, const double* x, double& cost_out,
-                                      double* g, double* A) {
+// Packed, front-filtered point records: ONE aligned vector load per point per sweep.
+//   PT=float : float4 {x, y, z, label bits}            (16 B)
+//   PT=double: {double x, y, z; long long label}       (32 B)
+// Points whose label is not 0/1 (incl. the -1 the front filter writes) are dropped here once, in stable
+// order, so the hot sweeps never see them (registration.cpp:87-125 skips them per residual block).
+template <typename PT> struct Rec;
+template <> struct __attribute__((aligned(16))) Rec<float> { float x, y, z; int lab; };
+template <> struct __attribute__((aligned(16))) Rec<double> { double x, y, z; long long lab; };
+
+template <typename PT>
+__global__ __launch_bounds__(256) void pack_kernel(const PT* __restrict__ points, const int* __restrict__ labels, int N,
+                                                   Rec<PT>* __restrict__ packed, int* __restrict__ counts) {
+    __shared__ int s_scan[256];
+    __shared__ int s_base;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const PT* px = points + (long long)f * 3 * N;
+    const int* lab = labels + (long long)f * N;
+    Rec<PT>* out = packed + (long long)f * N;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int n0 = 0; n0 < N; n0 += 256) {
+        const int n = n0 + tid;
+        const int l = n < N ? lab[n] : -1;
+        const int keep = (l == 0 || l == 1) ? 1 : 0;
+        s_scan[tid] = keep;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int v = tid >= o ? s_scan[tid - o] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        if (keep) {
+            Rec<PT> r;
+            r.x = px[n]; r.y = px[N + n]; r.z = px[2 * (long long)N + n]; r.lab = l;
+            out[s_base + s_scan[tid] - 1] = r;
+        }
+        __syncthreads();
+        if (tid == 255) s_base += s_scan[255];
+        __syncthreads();
+    }
+    if (tid == 0) counts[f] = s_base;
+}
+
+// ----------------------------------------------------------------------------------------------
+// One sweep over the frame's records by the 4 waves of a hypothesis' workgroup.
+//   phase A (every record, cheap): rotate, translate, one fp64 reciprocal, project, and decide whether the
+//     point is ACTIVE (non-zero residual or Jacobian row).  Near a solution ~5 % of the points are.
+//   compaction: active record ids go to a per-wave LDS queue (ballot + popcount positions); whenever 64 are
+//     queued the wave evaluates them DENSELY (phase B) -- without this, divergence makes every lane pay the
+//     log1p + 4x4 normal-equation update for every record, because some lane of 64 is always active.
+//   phase B (active records only): residual rows, analytic Jacobian rows, Cauchy corrector, cost and J^T J /
+//     J^T r accumulation in registers.
+//   reduction: xor-butterfly inside each wave, then the 4 wave partials are combined through LDS in a FIXED
+//     order by every thread, so all 256 threads hold bit-identical sums and the LM control flow that
+//     follows is workgroup-uniform.
+constexpr int QCAP = 320;        // per-wave queue capacity (>= 63 carried + 4*64 pushed per batch)
+
+template <int NP, int WPH>   // WPH = waves per hypothesis (workgroup = WPH*64 threads)
+struct SweepShared {
+    double red[WPH][Tri<NP>::N + NP + 2];
+    int queue[WPH][QCAP];
+};
+
+template <int NP, typename PT>
+__device__ __forceinline__ void project(const Rec<PT>& rc, const Rot<NP>& rot, double tx, double ty, double tz, const Cam& k,
+                                        double& X, double& Y, double& Z, double& qx, double& qz, double& p0, double& p1,
+                                        double& p2, double& iz, double& pix_x, double& pix_y) {
+    X = (double)rc.x; Y = (double)rc.y; Z = (double)rc.z;
+    double qy;
+    if (NP == 4) {
+        qx = rot.R[0] * X + rot.R[2] * Z; qy = Y; qz = rot.R[6] * X + rot.R[8] * Z;
+    } else {
+        qx = rot.R[0] * X + rot.R[1] * Y + rot.R[2] * Z;
+        qy = rot.R[3] * X + rot.R[4] * Y + rot.R[5] * Z;
+        qz = rot.R[6] * X + rot.R[7] * Y + rot.R[8] * Z;
+    }
+    p0 = qx + tx; p1 = qy + ty; p2 = qz + tz;
+    iz = 1.0 / p2;                                   // the one fp64 division per record
+    pix_x = p0 * k.fx * iz + k.cx;
+    pix_y = p1 * k.fy * iz + k.cy;
+}
+
+template <int NP, typename PT>
+__device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& rot, const double* x, const Cam& k, double& cost,
+                                            double* lg, double* lA, bool& bad) {
     constexpr int TOFF = NP == 4 ? 1 : 3;
+    double X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y;
+    project<NP, PT>(rc, rot, x[TOFF], x[TOFF + 1], x[TOFF + 2], k, X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y);
+    const double hw = k.W1 * 0.5, hh = k.H1 * 0.5;
+    // residual rows as (value, d/dpix_x, d/dpix_y, d/dp2 direct) -- at most 3 rows
+    double rv[3], sx[3], sy[3], sz[3];
+    int nr;
+    if ((int)rc.lab == 1) {
+        nr = 3;
+        const double a0 = -pix_x, b0 = pix_x - k.W1;
+        rv[0] = (a0 < 0.0 ? 0.0 : a0) + (b0 < 0.0 ? 0.0 : b0);
+        sx[0] = (a0 < 0.0 ? 0.0 : -1.0) + (b0 < 0.0 ? 0.0 : 1.0); sy[0] = 0.0; sz[0] = 0.0;
+        const double a1 = -pix_y, b1 = pix_y - k.H1;
+        rv[1] = (a1 < 0.0 ? 0.0 : a1) + (b1 < 0.0 ? 0.0 : b1);
+        sy[1] = (a1 < 0.0 ? 0.0 : -1.0) + (b1 < 0.0 ? 0.0 : 1.0); sx[1] = 0.0; sz[1] = 0.0;
+        const double a2 = -p2;
+        rv[2] = (a2 < 0.0 ? 0.0 : a2) * 100.0;
+        sz[2] = a2 < 0.0 ? 0.0 : -100.0; sx[2] = 0.0; sy[2] = 0.0;
+    } else {
+        nr = 1;
+        const double ex = pix_x - hw, ey = pix_y - hh;
+        const double dx = hw - fabs(ex), dy = hh - fabs(ey);
+        rv[0] = dx + dy;                       // only active outside-points get here
+        sx[0] = ex < 0.0 ? 1.0 : -1.0;
+        sy[0] = ey < 0.0 ? 1.0 : -1.0;
+        sz[0] = 0.0;
+        rv[1] = rv[2] = 0.0; sx[1] = sx[2] = sy[1] = sy[2] = sz[1] = sz[2] = 0.0;
+    }
+    double s = 0.0;
+    for (int i = 0; i < nr; ++i) s += rv[i] * rv[i];
+    if (!isfinite(s)) bad = true;
+    if (s > 0.0) cost += 0.5 * log1p(s);
+    const double rho1 = 1.0 / (1.0 + s);
+    const double ax = k.fx * iz, bx = -k.fx * p0 * iz * iz;   // dpix_x = ax*dp0 + bx*dp2
+    const double ay = k.fy * iz, by = -k.fy * p1 * iz * iz;   // dpix_y = ay*dp1 + by*dp2
+    double dp0[NP], dp1[NP], dp2[NP];
+    if (NP == 4) {
+        dp0[0] = qz; dp1[0] = 0.0; dp2[0] = -qx;              // d/dtheta of Ry(theta) X
+        if (!(x[0] * x[0] > DBL_EPSILON)) { dp0[0] = Z; dp2[0] = -X; }   // first-order branch
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            dp0[i] = rot.dR[i][0] * X + rot.dR[i][1] * Y + rot.dR[i][2] * Z;
+            dp1[i] = rot.dR[i][3] * X + rot.dR[i][4] * Y + rot.dR[i][5] * Z;
+            dp2[i] = rot.dR[i][6] * X + rot.dR[i][7] * Y + rot.dR[i][8] * Z;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { dp0[TOFF + i] = i == 0 ? 1.0 : 0.0; dp1[TOFF + i] = i == 1 ? 1.0 : 0.0; dp2[TOFF + i] = i == 2 ? 1.0 : 0.0; }
+    for (int i = 0; i < nr; ++i) {
+        if (sx[i] == 0.0 && sy[i] == 0.0 && sz[i] == 0.0) continue;
+        double J[NP];
+#pragma unroll
+        for (int a = 0; a < NP; ++a) {
+            const double dpx = ax * dp0[a] + bx * dp2[a];
+            const double dpy = ay * dp1[a] + by * dp2[a];
+            J[a] = sx[i] * dpx + sy[i] * dpy + sz[i] * dp2[a];
+            if (!isfinite(J[a])) bad = true;
+        }
+        const double wr = rho1 * rv[i];
+#pragma unroll
+        for (int a = 0; a < NP; ++a) {
+            lg[a] += wr * J[a];
+            const double wa = rho1 * J[a];
+#pragma unroll
+            for (int b = 0; b <= a; ++b) lA[a * (a + 1) / 2 + b] += wa * J[b];
+        }
+    }
+}
+
+// Leaves the 4 wave partials {cost, g[NP], A[tri], bad} in sh.red[wave][*]; the caller combines them after a
+// barrier.  Records are prefetched one batch (U per lane) ahead so a batch's arithmetic covers the next
+// batch's L2/HBM latency.
+template <int NP, typename PT, int WPH, int U>   // U = records per lane per batch
+__device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, int cnt, const Cam& k, const double* x,
+                                      SweepShared<NP, WPH>& sh) {
+    constexpr int TOFF = NP == 4 ? 1 : 3;
+    constexpr int NV = Tri<NP>::N + NP + 2;
     Rot<NP> rot;
     make_rot<NP>(x, rot);
     const double tx = x[TOFF], ty = x[TOFF + 1], tz = x[TOFF + 2];
-    const int lane = threadIdx.x & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int* queue = sh.queue[wave];
+    int qn = 0;  // wave-uniform
     double cost = 0.0;
     double lg[NP], lA[Tri<NP>::N];
 #pragma unroll
@@ -104,103 +265,64 @@ __device__ __forceinline__ bool sweep(const PT* __restrict__ px_, const PT* __re
     for (int i = 0; i < Tri<NP>::N; ++i) lA[i] = 0.0;
     bool bad = false;
     const double hw = k.W1 * 0.5, hh = k.H1 * 0.5;
-    for (int n = lane; n < N; n += 64) {
-        const int lab = labels[n];
-        if (lab != 0 && lab != 1) continue;
-        const double X = (double)px_[n], Y = (double)py_[n], Z = (double)pz_[n];
-        double qx, qy, qz;
-        if (NP == 4) {
-            qx = rot.R[0] * X + rot.R[2] * Z; qy = Y; qz = rot.R[6] * X + rot.R[8] * Z;
-        } else {
-            qx = rot.R[0] * X + rot.R[1] * Y + rot.R[2] * Z;
-            qy = rot.R[3] * X + rot.R[4] * Y + rot.R[5] * Z;
-            qz = rot.R[6] * X + rot.R[7] * Y + rot.R[8] * Z;
+    constexpr int span = WPH * 64 * U;
+    Rec<PT> nxt[U];
+    auto fetch = [&](int base) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int n = base + u * (WPH * 64) + tid;
+            if (n < cnt) nxt[u] = recs[n]; else { nxt[u].x = 0; nxt[u].y = 0; nxt[u].z = 1; nxt[u].lab = -1; }
         }
-        const double p0 = qx + tx, p1 = qy + ty, p2 = qz + tz;
-        const double pix_x = p0 * k.fx / p2 + k.cx;
-        const double pix_y = p1 * k.fy / p2 + k.cy;
-        // residual rows as (value, d/dpix_x, d/dpix_y, d/dp2 direct) -- at most 3 rows
-        double rv[3], sx[3], sy[3], sz[3];
-        int nr;
-        if (lab == 1) {
-            nr = 3;
-            const double a0 = -pix_x, b0 = pix_x - k.W1;
-            rv[0] = (a0 < 0.0 ? 0.0 : a0) + (b0 < 0.0 ? 0.0 : b0);
-            sx[0] = (a0 < 0.0 ? 0.0 : -1.0) + (b0 < 0.0 ? 0.0 : 1.0); sy[0] = 0.0; sz[0] = 0.0;
-            const double a1 = -pix_y, b1 = pix_y - k.H1;
-            rv[1] = (a1 < 0.0 ? 0.0 : a1) + (b1 < 0.0 ? 0.0 : b1);
-            sy[1] = (a1 < 0.0 ? 0.0 : -1.0) + (b1 < 0.0 ? 0.0 : 1.0); sx[1] = 0.0; sz[1] = 0.0;
-            const double a2 = -p2;
-            rv[2] = (a2 < 0.0 ? 0.0 : a2) * 100.0;
-            sz[2] = a2 < 0.0 ? 0.0 : -100.0; sx[2] = 0.0; sy[2] = 0.0;
-        } else {
-            nr = 1;
-            const double ex = pix_x - hw, ey = pix_y - hh;
-            const double dx = hw - fabs(ex), dy = hh - fabs(ey);
-            // fmax(v,0)/v is NaN at v == 0 (registration_2d.hpp:53,56,58): evaluation failure
-            if (dx == 0.0 || dy == 0.0 || p2 == 0.0) bad = true;
-            const bool act = dx > 0.0 && dy > 0.0 && p2 > 0.0;
-            rv[0] = act ? dx + dy : 0.0;
-            sx[0] = act ? (ex < 0.0 ? 1.0 : -1.0) : 0.0;
-            sy[0] = act ? (ey < 0.0 ? 1.0 : -1.0) : 0.0;
-            sz[0] = 0.0;
+    };
+    fetch(0);
+    for (int base = 0; base < cnt; base += span) {
+        Rec<PT> rec[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) rec[u] = nxt[u];
+        if (base + span < cnt) fetch(base + span);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int lab = (int)rec[u].lab;
+            double X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y;
+            project<NP, PT>(rec[u], rot, tx, ty, tz, k, X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y);
+            bool act = false;
+            if (lab == 1) {
+                act = !(-pix_x < 0.0) || !(pix_x - k.W1 < 0.0) || !(-pix_y < 0.0) || !(pix_y - k.H1 < 0.0) || !(-p2 < 0.0);
+            } else if (lab == 0) {
+                const double dx = hw - fabs(pix_x - hw), dy = hh - fabs(pix_y - hh);
+                // fmax(v,0)/v is NaN at v == 0 (registration_2d.hpp:53,56,58): evaluation failure
+                if (dx == 0.0 || dy == 0.0 || p2 == 0.0) bad = true;
+                if (!isfinite(pix_x) || !isfinite(pix_y)) bad = true;
+                act = dx > 0.0 && dy > 0.0 && p2 > 0.0;
+            }
+            const unsigned long long bal = __ballot(act);
+            if (act) queue[qn + __popcll(bal & lt)] = base + u * (WPH * 64) + tid;
+            qn += __popcll(bal);
         }
-        double s = 0.0;
-        for (int i = 0; i < nr; ++i) s += rv[i] * rv[i];
-        if (!isfinite(s) || !isfinite(pix_x) || !isfinite(pix_y)) bad = true;
-        bool any_j = false;
-        for (int i = 0; i < nr; ++i) any_j |= (sx[i] != 0.0) | (sy[i] != 0.0) | (sz[i] != 0.0);
-        if (s > 0.0) cost += 0.5 * log1p(s);
-        if (FULL && any_j) {
-            const double rho1 = 1.0 / (1.0 + s);
-            const double iz = 1.0 / p2;
-            const double ax = k.fx * iz, bx = -k.fx * p0 * iz * iz;   // dpix_x = ax*dp0 + bx*dp2
-            const double ay = k.fy * iz, by = -k.fy * p1 * iz * iz;   // dpix_y = ay*dp1 + by*dp2
-            // dp/dparam : rotation part
-            double dp0[NP], dp1[NP], dp2[NP];
-            if (NP == 4) {
-                dp0[0] = qz; dp1[0] = 0.0; dp2[0] = -qx;      // d/dtheta of Ry(theta) x  (first-order branch: (Z, 0, -X) = same form)
-                if (!(x[0] * x[0] > DBL_EPSILON)) { dp0[0] = Z; dp2[0] = -X; }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    dp0[i] = rot.dR[i][0] * X + rot.dR[i][1] * Y + rot.dR[i][2] * Z;
-                    dp1[i] = rot.dR[i][3] * X + rot.dR[i][4] * Y + rot.dR[i][5] * Z;
-                    dp2[i] = rot.dR[i][6] * X + rot.dR[i][7] * Y + rot.dR[i][8] * Z;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { dp0[TOFF + i] = i == 0 ? 1.0 : 0.0; dp1[TOFF + i] = i == 1 ? 1.0 : 0.0; dp2[TOFF + i] = i == 2 ? 1.0 : 0.0; }
-            for (int i = 0; i < nr; ++i) {
-                if (sx[i] == 0.0 && sy[i] == 0.0 && sz[i] == 0.0) continue;
-                double J[NP];
-#pragma unroll
-                for (int a = 0; a < NP; ++a) {
-                    const double dpx = ax * dp0[a] + bx * dp2[a];
-                    const double dpy = ay * dp1[a] + by * dp2[a];
-                    J[a] = sx[i] * dpx + sy[i] * dpy + sz[i] * dp2[a];
-                    if (!isfinite(J[a])) bad = true;
-                }
-                const double wr = rho1 * rv[i];
-#pragma unroll
-                for (int a = 0; a < NP; ++a) {
-                    lg[a] += wr * J[a];
-                    const double wa = rho1 * J[a];
-#pragma unroll
-                    for (int b = 0; b <= a; ++b) lA[a * (a + 1) / 2 + b] += wa * J[b];
-                }
-            }
+        // drain: dense evaluation of queued active records, 64 at a time (the remainder on the last batch)
+        const bool last = base + span >= cnt;
+        while (qn >= 64 || (last && qn > 0)) {
+            // LDS ops of one wave retire in order; only the compiler must not reorder them
+            __builtin_amdgcn_wave_barrier();
+            const int n = lane < qn ? queue[lane] : -1;
+            const int carry = (lane + 64 < qn) ? queue[lane + 64] : 0;
+            __builtin_amdgcn_wave_barrier();
+            if (lane + 64 < qn) queue[lane] = carry;      // (entries beyond 128 are shifted on later rounds)
+            for (int j = 128 + lane; j < qn; j += 64) { const int c2 = queue[j]; queue[j - 64] = c2; }
+            qn = qn > 64 ? qn - 64 : 0;
+            __builtin_amdgcn_wave_barrier();
+            if (n >= 0) eval_active<NP, PT>(recs[n], rot, x, k, cost, lg, lA, bad);
         }
     }
-    cost_out = wave_sum(cost);
-    if (FULL) {
+
+    double* mine = sh.red[wave];
+    double v = wave_sum(cost);
+    if (lane == 0) mine[0] = v;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) g[i] = wave_sum(lg[i]);
+    for (int i = 0; i < NP; ++i) { v = wave_sum(lg[i]); if (lane == 0) mine[1 + i] = v; }
 #pragma unroll
-        for (int i = 0; i < Tri<NP>::N; ++i) A[i] = wave_sum(lA[i]);
-    }
-    const bool any_bad = __any(bad) != 0;
-    return !any_bad && isfinite(cost_out);
+    for (int i = 0; i < Tri<NP>::N; ++i) { v = wave_sum(lA[i]); if (lane == 0) mine[1 + NP + i] = v; }
+    if (lane == 0) mine[NV - 1] = (__any(bad) != 0) ? 1.0 : 0.0;
 }
 
 template <int NP>
@@ -261,173 +383,194 @@ __device__ __forceinline__ double grad_max_norm(const double* x, const double* g
 
 struct Bounds { double lb[3], ub[3]; };
 
-template <int NP, typename PT>
-__global__ __launch_bounds__(256) void solve_kernel(const PT* __restrict__ points, const int* __restrict__ labels,
-                                                    const double* __restrict__ Kmat, const double* __restrict__ init_y,
-                                                    const double* __restrict__ init_T, const double* __restrict__ yaw0,
-                                                    double H, double W, Bounds bnd, int max_iter, int R, int N,
-                                                    double* __restrict__ params_out, double* __restrict__ cost_out,
-                                                    int* __restrict__ iters_out) {
-    constexpr int TOFF = NP == 4 ? 1 : 3;
-    constexpr int NT = Tri<NP>::N;
-    const int f = blockIdx.y;
-    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (r >= R) return;  // whole wave exits
-    const PT* px = points + (long long)f * 3 * N;
-    const PT* py = px + N;
-    const PT* pz = py + N;
-    const int* lab = labels + (long long)f * N;
-    const double* Kf = Kmat + (long long)f * 9;
-    const Cam k{Kf[0], Kf[4], Kf[2], Kf[5], H - 1.0, W - 1.0};
-
+// Levenberg-Marquardt state of one hypothesis.  Lives ONCE per workgroup in LDS; thread 0 advances it between
+// sweeps (a few hundred scalar flops), so the sweep's register budget is not shared with it.
+enum { PH_INIT = 0, PH_TRIAL = 1, PH_RESWEEP = 2 };
+template <int NP>
+struct LMState {
+    double x[NP], g[NP], A[Tri<NP>::N], S[NP], diag[NP], delta[NP], xe[NP];
     double lb[NP], ub[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) { lb[i] = -DBL_MAX; ub[i] = DBL_MAX; }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { lb[TOFF + i] = bnd.lb[i]; ub[TOFF + i] = bnd.ub[i]; }
+    double cost, gmax, radius, decrease, gd, dmax, t, f1, model_change;
+    int iter, nsweep, invalid_run, ls_it, phase, reuse_diag, ok1, done, max_iter;
+};
 
-    double x[NP];
-    const long long hr = (long long)f * R + r;
-    const double y0 = init_y[hr] + (yaw0 ? yaw0[f] : 0.0);
-    if (NP == 4) { x[0] = y0; } else { x[0] = 0.0; x[1] = y0; x[2] = 0.0; }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) x[TOFF + i] = init_T[hr * 3 + i];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) x[i] = fmin(fmax(x[i], lb[i]), ub[i]);
-
-    const double kMinDiag = 1e-6, kMaxDiag = 1e32, kMaxRadius = 1e16, kMinRadius = 1e-32;
-    const double kMinRelDec = 1e-3, kFuncTol = 1e-6, kGradTol = 1e-10, kParamTol = 1e-8;
-
-    double cost, g[NP], A[NT];
-    int iter = 0;
-    bool ok = sweep<NP, true, PT>(px, py, pz, lab, N, k, x, cost, g, A);
-    if (ok) {
-        double S[NP];
-#pragma unroll
-        for (int i = 0; i < NP; ++i) S[i] = 1.0 / (1.0 + sqrt(A[i * (i + 1) / 2 + i]));
-        double gmax = grad_max_norm<NP>(x, g, lb, ub);
-        double radius = 1e4, decrease = 2.0;
-        bool reuse_diag = false;
-        double diag[NP];
-#pragma unroll
-        for (int i = 0; i < NP; ++i) diag[i] = 0.0;
-        int invalid_run = 0;
-        for (;;) {
-            if (iter >= max_iter) break;
-            if (gmax <= kGradTol) break;
-            if (radius <= kMinRadius) break;
-            ++iter;
-            double As[NT], gs[NP], M[NT], rhs[NP], ds[NP];
-#pragma unroll
+template <int NP>
+__device__ void lm_begin_iteration(LMState<NP>& st) {
+    constexpr int NT = Tri<NP>::N;
+    const double kMinDiag = 1e-6, kMaxDiag = 1e32, kMinRadius = 1e-32, kGradTol = 1e-10;
+    for (;;) {
+        if (st.iter >= st.max_iter || st.gmax <= kGradTol || st.radius <= kMinRadius) { st.done = 1; return; }
+        ++st.iter;
+        double As[NT], gs[NP], M[NT], rhs[NP], ds[NP];
+        for (int a = 0; a < NP; ++a) {
+            gs[a] = st.S[a] * st.g[a];
+            for (int b = 0; b <= a; ++b) As[a * (a + 1) / 2 + b] = st.S[a] * st.A[a * (a + 1) / 2 + b] * st.S[b];
+        }
+        if (!st.reuse_diag)
+            for (int a = 0; a < NP; ++a) st.diag[a] = fmin(fmax(As[a * (a + 1) / 2 + a], kMinDiag), kMaxDiag);
+        for (int i = 0; i < NT; ++i) M[i] = As[i];
+        for (int a = 0; a < NP; ++a) { M[a * (a + 1) / 2 + a] += st.diag[a] / st.radius; rhs[a] = -gs[a]; }
+        bool valid = chol_solve<NP>(M, rhs, ds);
+        double model_change = 0.0;
+        if (valid) {
+            double q = 0.0, l = 0.0;
             for (int a = 0; a < NP; ++a) {
-                gs[a] = S[a] * g[a];
-#pragma unroll
-                for (int b = 0; b <= a; ++b) As[a * (a + 1) / 2 + b] = S[a] * A[a * (a + 1) / 2 + b] * S[b];
+                l += ds[a] * gs[a];
+                for (int b = 0; b < NP; ++b) q += ds[a] * As[tri<NP>(a, b)] * ds[b];
             }
-            if (!reuse_diag) {
-#pragma unroll
-                for (int a = 0; a < NP; ++a) diag[a] = fmin(fmax(As[a * (a + 1) / 2 + a], kMinDiag), kMaxDiag);
-            }
-#pragma unroll
-            for (int i = 0; i < NT; ++i) M[i] = As[i];
-#pragma unroll
-            for (int a = 0; a < NP; ++a) { M[a * (a + 1) / 2 + a] += diag[a] / radius; rhs[a] = -gs[a]; }
-            bool valid = chol_solve<NP>(M, rhs, ds);
-            double model_change = 0.0;
-            if (valid) {
-                double q = 0.0, l = 0.0;
-#pragma unroll
-                for (int a = 0; a < NP; ++a) {
-                    l += ds[a] * gs[a];
-#pragma unroll
-                    for (int b = 0; b < NP; ++b) q += ds[a] * As[tri<NP>(a, b)] * ds[b];
-                }
-                model_change = -(l + 0.5 * q);
-                valid = model_change > 0.0;
-            }
-            if (!valid) {
-                if (++invalid_run >= 5) break;
-                radius /= decrease; decrease *= 2.0; reuse_diag = true;
-                continue;
-            }
-            invalid_run = 0;
-            double delta[NP];
-#pragma unroll
-            for (int a = 0; a < NP; ++a) delta[a] = ds[a] * S[a];
-            // projected Armijo search; every trial carries its normal equations (gT, AT)
-            double gd = 0.0, dmax = 0.0;
-#pragma unroll
-            for (int a = 0; a < NP; ++a) { gd += g[a] * delta[a]; dmax = fmax(dmax, fabs(delta[a])); }
-            double t = 1.0, ft, gT[NP], AT[NT], xc[NP];
-            plus_proj<NP>(x, delta, t, lb, ub, xc);
-            bool okv = sweep<NP, true, PT>(px, py, pz, lab, N, k, xc, ft, gT, AT);
-            const double f1 = okv ? ft : DBL_MAX;   // the unscaled candidate (used when the search fails) is this first trial
-            const bool ok1 = okv;
-            int ls_it = 0;
-            bool success = false;
-            for (;;) {
-                if (okv && ft <= cost + 1e-4 * gd * t) { success = true; break; }
-                if (++ls_it >= 20) break;
-                const double lo = 1e-3 * t, hi = 0.6 * t;
-                double tn;
-                if (!okv) {
-                    tn = fmin(fmax(0.5 * t, lo), hi);
-                } else {
-                    const double a2 = (ft - cost - gd * t) / (t * t);
-                    const double qlo = cost + gd * lo + a2 * lo * lo, qhi = cost + gd * hi + a2 * hi * hi;
-                    tn = qlo <= qhi ? lo : hi;
-                    if (a2 > 0.0) {
-                        const double sc = -gd / (2.0 * a2);
-                        const double qsc = cost + gd * sc + a2 * sc * sc;
-                        const double qtn = qlo <= qhi ? qlo : qhi;
-                        if (sc > lo && sc < hi && qsc < qtn) tn = sc;
-                    }
-                }
-                if (tn * dmax < 1e-9) break;
-                t = tn;
-                plus_proj<NP>(x, delta, t, lb, ub, xc);
-                okv = sweep<NP, true, PT>(px, py, pz, lab, N, k, xc, ft, gT, AT);
-            }
-            double cand_cost;
-            bool cand_ok;
-            if (!success) {  // delta stays unscaled: the candidate is the first trial point (rare: re-sweep it)
-                cand_cost = f1; cand_ok = ok1;
-                if (ls_it > 0) {
-                    plus_proj<NP>(x, delta, 1.0, lb, ub, xc);
-                    double fdummy;
-                    sweep<NP, true, PT>(px, py, pz, lab, N, k, xc, fdummy, gT, AT);
-                }
-            } else {
-                cand_cost = ft; cand_ok = true;
-            }
-            double step_norm = 0.0, x_norm = 0.0;
-#pragma unroll
-            for (int a = 0; a < NP; ++a) { step_norm += (x[a] - xc[a]) * (x[a] - xc[a]); x_norm += x[a] * x[a]; }
-            step_norm = sqrt(step_norm); x_norm = sqrt(x_norm);
-            if (step_norm <= kParamTol * (x_norm + kParamTol)) break;
-            if (fabs(cost - cand_cost) <= kFuncTol * cost) break;
-            const double rel = (cost - cand_cost) / model_change;
-            if (rel > kMinRelDec) {
-                if (!cand_ok) break;  // (cannot happen: cand_cost would be DBL_MAX)
-#pragma unroll
-                for (int a = 0; a < NP; ++a) { x[a] = xc[a]; g[a] = gT[a]; }
-#pragma unroll
-                for (int i = 0; i < NT; ++i) A[i] = AT[i];
-                cost = cand_cost;
-                gmax = grad_max_norm<NP>(x, g, lb, ub);
-                const double w = 2.0 * rel - 1.0;
-                radius = fmin(kMaxRadius, radius / fmax(1.0 / 3.0, 1.0 - w * w * w));
-                decrease = 2.0; reuse_diag = false;
-            } else {
-                radius /= decrease; decrease *= 2.0; reuse_diag = true;
+            model_change = -(l + 0.5 * q);
+            valid = model_change > 0.0;
+        }
+        if (!valid) {
+            if (++st.invalid_run >= 5) { st.done = 1; return; }
+            st.radius /= st.decrease; st.decrease *= 2.0; st.reuse_diag = 1;
+            continue;
+        }
+        st.invalid_run = 0;
+        st.model_change = model_change;
+        double gd = 0.0, dmax = 0.0;
+        for (int a = 0; a < NP; ++a) {
+            st.delta[a] = ds[a] * st.S[a];
+            gd += st.g[a] * st.delta[a];
+            dmax = fmax(dmax, fabs(st.delta[a]));
+        }
+        st.gd = gd; st.dmax = dmax; st.t = 1.0; st.ls_it = 0;
+        plus_proj<NP>(st.x, st.delta, 1.0, st.lb, st.ub, st.xe);
+        st.phase = PH_TRIAL;
+        return;   // needs a sweep at xe
+    }
+}
+
+// candidate (xe, cand_cost, ge, Ae) against the current iterate: tolerance tests, accept / reject
+template <int NP>
+__device__ void lm_finish_iteration(LMState<NP>& st, double cand_cost, const double* ge, const double* Ae) {
+    const double kMaxRadius = 1e16, kMinRelDec = 1e-3, kFuncTol = 1e-6, kParamTol = 1e-8;
+    double step_norm = 0.0, x_norm = 0.0;
+    for (int a = 0; a < NP; ++a) { step_norm += (st.x[a] - st.xe[a]) * (st.x[a] - st.xe[a]); x_norm += st.x[a] * st.x[a]; }
+    step_norm = sqrt(step_norm); x_norm = sqrt(x_norm);
+    if (step_norm <= kParamTol * (x_norm + kParamTol)) { st.done = 1; return; }
+    if (fabs(st.cost - cand_cost) <= kFuncTol * st.cost) { st.done = 1; return; }
+    const double rel = (st.cost - cand_cost) / st.model_change;
+    if (rel > kMinRelDec) {
+        for (int a = 0; a < NP; ++a) { st.x[a] = st.xe[a]; st.g[a] = ge[a]; }
+        for (int i = 0; i < Tri<NP>::N; ++i) st.A[i] = Ae[i];
+        st.cost = cand_cost;
+        st.gmax = grad_max_norm<NP>(st.x, st.g, st.lb, st.ub);
+        const double w = 2.0 * rel - 1.0;
+        st.radius = fmin(kMaxRadius, st.radius / fmax(1.0 / 3.0, 1.0 - w * w * w));
+        st.decrease = 2.0; st.reuse_diag = 0;
+    } else {
+        st.radius /= st.decrease; st.decrease *= 2.0; st.reuse_diag = 1;
+    }
+    lm_begin_iteration<NP>(st);
+}
+
+// Called by thread 0 after every sweep with the combined sums of the point just evaluated (st.xe).
+template <int NP>
+__device__ void lm_after_sweep(LMState<NP>& st, bool ok, double fe, const double* ge, const double* Ae) {
+    ++st.nsweep;
+    if (st.phase == PH_INIT) {
+        st.cost = fe;
+        if (!ok) { st.done = 1; return; }
+        for (int a = 0; a < NP; ++a) { st.g[a] = ge[a]; st.S[a] = 1.0 / (1.0 + sqrt(Ae[a * (a + 1) / 2 + a])); }
+        for (int i = 0; i < Tri<NP>::N; ++i) st.A[i] = Ae[i];
+        st.gmax = grad_max_norm<NP>(st.x, st.g, st.lb, st.ub);
+        lm_begin_iteration<NP>(st);
+        return;
+    }
+    if (st.phase == PH_RESWEEP) {   // normal equations of the unscaled first trial, whose cost was kept in f1
+        lm_finish_iteration<NP>(st, st.f1, ge, Ae);
+        return;
+    }
+    // PH_TRIAL: projected Armijo search along delta
+    if (st.ls_it == 0) { st.f1 = ok ? fe : DBL_MAX; st.ok1 = ok; }
+    if (ok && fe <= st.cost + 1e-4 * st.gd * st.t) { lm_finish_iteration<NP>(st, fe, ge, Ae); return; }
+    bool give_up = ++st.ls_it >= 20;
+    double tn = 0.0;
+    if (!give_up) {
+        const double t = st.t, lo = 1e-3 * t, hi = 0.6 * t;
+        if (!ok) {
+            tn = fmin(fmax(0.5 * t, lo), hi);
+        } else {
+            const double a2 = (fe - st.cost - st.gd * t) / (t * t);
+            const double qlo = st.cost + st.gd * lo + a2 * lo * lo, qhi = st.cost + st.gd * hi + a2 * hi * hi;
+            tn = qlo <= qhi ? lo : hi;
+            if (a2 > 0.0) {
+                const double sc = -st.gd / (2.0 * a2);
+                const double qsc = st.cost + st.gd * sc + a2 * sc * sc;
+                const double qtn = qlo <= qhi ? qlo : qhi;
+                if (sc > lo && sc < hi && qsc < qtn) tn = sc;
             }
         }
+        if (tn * st.dmax < 1e-9) give_up = true;
     }
-    if ((threadIdx.x & 63) == 0) {
+    if (give_up) {   // delta stays unscaled: the candidate is the first trial point
+        plus_proj<NP>(st.x, st.delta, 1.0, st.lb, st.ub, st.xe);
+        if (st.ls_it > 1 || st.t != 1.0) { st.phase = PH_RESWEEP; return; }   // sums on hand belong to another point
+        lm_finish_iteration<NP>(st, st.f1, ge, Ae);
+        return;
+    }
+    st.t = tn;
+    plus_proj<NP>(st.x, st.delta, tn, st.lb, st.ub, st.xe);
+}
+
+template <int NP, typename PT, int MINW, int WPH, int U>
+__global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __restrict__ packed, const int* __restrict__ counts,
+                                                       const double* __restrict__ Kmat, const double* __restrict__ init_y,
+                                                       const double* __restrict__ init_T, const double* __restrict__ yaw0,
+                                                       double H, double W, Bounds bnd, int max_iter, int F, int R, int N,
+                                                       double* __restrict__ params_out, double* __restrict__ cost_out,
+                                                       int* __restrict__ iters_out, int* __restrict__ sweeps_out) {
+    constexpr int TOFF = NP == 4 ? 1 : 3;
+    constexpr int NT = Tri<NP>::N;
+    constexpr int NV = NT + NP + 2;
+    // 1-D grid, frame = block % F: the dispatcher places block b on XCD b % 8, so (for F % 8 == 0) all the
+    // hypotheses of a frame share one XCD's L2 and the frame's records are fetched from HBM once.
+    const int f = blockIdx.x % F;
+    const int r = blockIdx.x / F;            // one WPH-wave workgroup per hypothesis
+    __shared__ SweepShared<NP, WPH> sh;
+    __shared__ LMState<NP> st;
+    const Rec<PT>* recs = packed + (long long)f * N;
+    const int cnt = counts[f];
+    const double* Kf = Kmat + (long long)f * 9;
+    const Cam k{Kf[0], Kf[4], Kf[2], Kf[5], H - 1.0, W - 1.0};
+    const long long hr = (long long)f * R + r;
+
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < NP; ++i) { st.lb[i] = -DBL_MAX; st.ub[i] = DBL_MAX; }
+        for (int i = 0; i < 3; ++i) { st.lb[TOFF + i] = bnd.lb[i]; st.ub[TOFF + i] = bnd.ub[i]; }
+        const double y0 = init_y[hr] + (yaw0 ? yaw0[f] : 0.0);
+        if (NP == 4) { st.x[0] = y0; } else { st.x[0] = 0.0; st.x[1] = y0; st.x[2] = 0.0; }
+        for (int i = 0; i < 3; ++i) st.x[TOFF + i] = init_T[hr * 3 + i];
+        for (int i = 0; i < NP; ++i) { st.x[i] = fmin(fmax(st.x[i], st.lb[i]), st.ub[i]); st.xe[i] = st.x[i]; }
+        st.radius = 1e4; st.decrease = 2.0; st.reuse_diag = 0; st.invalid_run = 0; st.iter = 0; st.nsweep = 0;
+        st.phase = PH_INIT; st.done = 0; st.max_iter = max_iter; st.cost = 0.0; st.gmax = 0.0;
+    }
+    __syncthreads();
+    for (;;) {
+        double xe[NP];
 #pragma unroll
-        for (int i = 0; i < NP; ++i) params_out[hr * NP + i] = x[i];
-        cost_out[hr] = cost;
-        iters_out[hr] = iter;
+        for (int i = 0; i < NP; ++i) xe[i] = st.xe[i];
+        sweep<NP, PT, WPH, U>(recs, cnt, k, xe, sh);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double v[NV];
+            for (int i = 0; i < NV; ++i) {      // fixed-order combination of the wave partials
+                double t = sh.red[0][i];
+                for (int w = 1; w < WPH; ++w) t += sh.red[w][i];
+                v[i] = t;
+            }
+            const bool ok = v[NV - 1] == 0.0 && isfinite(v[0]);
+            lm_after_sweep<NP>(st, ok, v[0], v + 1, v + 1 + NP);
+        }
+        __syncthreads();
+        if (st.done) break;
+    }
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < NP; ++i) params_out[hr * NP + i] = st.x[i];
+        cost_out[hr] = st.cost;
+        iters_out[hr] = st.iter;
+        if (sweeps_out) sweeps_out[hr] = st.nsweep;
     }
 }
 
@@ -603,14 +746,31 @@ __global__ __launch_bounds__(256) void residuals_kernel(const double* __restrict
 template <typename PT>
 int launch_solve(const PT* points, const int* labels, const double* K, const double* init_y, const double* init_T,
                  const double* yaw0, double H, double W, const double* lb, const double* ub, int max_iter, int is_2d, int F,
-                 int R, int N, double* params, double* cost, int* iters, hipStream_t st) {
+                 int R, int N, double* params, double* cost, int* iters, int* sweeps, void* workspace, hipStream_t st) {
     Bounds b;
     for (int i = 0; i < 3; ++i) { b.lb[i] = lb[i]; b.ub[i] = ub[i]; }
-    const dim3 grid(di2p_cdiv(R, 4), F), block(256);
-    if (is_2d)
-        hipLaunchKernelGGL((solve_kernel<4, PT>), grid, block, 0, st, points, labels, K, init_y, init_T, yaw0, H, W, b, max_iter, R, N, params, cost, iters);
-    else
-        hipLaunchKernelGGL((solve_kernel<6, PT>), grid, block, 0, st, points, labels, K, init_y, init_T, yaw0, H, W, b, max_iter, R, N, params, cost, iters);
+    int* counts = (int*)workspace;
+    Rec<PT>* packed = (Rec<PT>*)((char*)workspace + (((size_t)F * sizeof(int) + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(pack_kernel<PT>, dim3(F), dim3(256), 0, st, points, labels, N, packed, counts);
+    // DI2P_SOLVER_CFG=<waves per hypothesis><records per lane per batch><min waves/SIMD>, e.g. 443 (default)
+    static int cfg = -1;
+    if (cfg < 0) { const char* e = getenv("DI2P_SOLVER_CFG"); cfg = e ? atoi(e) : 443; }
+    const dim3 grid(R * F);
+#define DI2P_LAUNCH_SOLVE(NPV, MW, WP, UU) hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP, UU>), grid, dim3(WP * 64), 0, st, packed, counts, K, init_y, init_T, yaw0, H, W, b, max_iter, F, R, N, params, cost, iters, sweeps)
+    if (is_2d) {
+        switch (cfg) {
+            case 442: DI2P_LAUNCH_SOLVE(4, 2, 4, 4); break;
+            case 423: DI2P_LAUNCH_SOLVE(4, 3, 4, 2); break;
+            case 822: DI2P_LAUNCH_SOLVE(4, 2, 8, 2); break;
+            case 842: DI2P_LAUNCH_SOLVE(4, 2, 8, 4); break;
+            case 824: DI2P_LAUNCH_SOLVE(4, 4, 8, 2); break;
+            case 1624: DI2P_LAUNCH_SOLVE(4, 4, 16, 2); break;
+            default: DI2P_LAUNCH_SOLVE(4, 3, 4, 4); break;
+        }
+    } else {
+        DI2P_LAUNCH_SOLVE(6, 2, 4, 2);
+    }
+#undef DI2P_LAUNCH_SOLVE
     return 0;
 }
 
@@ -619,22 +779,22 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
 extern "C" int di2p_solve_batched(const double* points, const int32_t* labels, const double* K, const double* init_y,
                                   const double* init_T, const double* yaw0, double H, double W, const double* lb_host,
                                   const double* ub_host, int max_iter, int is_2d, int F, int R, int N, double* params,
-                                  double* cost, int32_t* iters, void* stream) {
-    DI2P_CHECK_ARG(points && labels && K && init_y && init_T && lb_host && ub_host && params && cost && iters, "null pointer");
+                                  double* cost, int32_t* iters, int32_t* sweeps, void* workspace, void* stream) {
+    DI2P_CHECK_ARG(points && labels && K && init_y && init_T && lb_host && ub_host && params && cost && iters && workspace, "null pointer");
     DI2P_CHECK_ARG(F >= 0 && R >= 0 && N >= 0 && max_iter >= 0, "bad size");
     if (F == 0 || R == 0) return 0;
-    launch_solve<double>(points, labels, K, init_y, init_T, yaw0, H, W, lb_host, ub_host, max_iter, is_2d, F, R, N, params, cost, iters, (hipStream_t)stream);
+    launch_solve<double>(points, labels, K, init_y, init_T, yaw0, H, W, lb_host, ub_host, max_iter, is_2d, F, R, N, params, cost, iters, sweeps, workspace, (hipStream_t)stream);
     DI2P_RETURN_LAUNCH();
 }
 
 extern "C" int di2p_solve_batched_f32(const float* points, const int32_t* labels, const double* K, const double* init_y,
                                       const double* init_T, const double* yaw0, double H, double W, const double* lb_host,
                                       const double* ub_host, int max_iter, int is_2d, int F, int R, int N, double* params,
-                                      double* cost, int32_t* iters, void* stream) {
-    DI2P_CHECK_ARG(points && labels && K && init_y && init_T && lb_host && ub_host && params && cost && iters, "null pointer");
+                                      double* cost, int32_t* iters, int32_t* sweeps, void* workspace, void* stream) {
+    DI2P_CHECK_ARG(points && labels && K && init_y && init_T && lb_host && ub_host && params && cost && iters && workspace, "null pointer");
     DI2P_CHECK_ARG(F >= 0 && R >= 0 && N >= 0 && max_iter >= 0, "bad size");
     if (F == 0 || R == 0) return 0;
-    launch_solve<float>(points, labels, K, init_y, init_T, yaw0, H, W, lb_host, ub_host, max_iter, is_2d, F, R, N, params, cost, iters, (hipStream_t)stream);
+    launch_solve<float>(points, labels, K, init_y, init_T, yaw0, H, W, lb_host, ub_host, max_iter, is_2d, F, R, N, params, cost, iters, sweeps, workspace, (hipStream_t)stream);
     DI2P_RETURN_LAUNCH();
 }
 
@@ -664,4 +824,8 @@ extern "C" int di2p_solver_residuals(const double* points, const int32_t* labels
     else
         hipLaunchKernelGGL(residuals_kernel<6>, dim3(F), dim3(256), 0, (hipStream_t)stream, points, labels, K, params, H, W, N, residuals, counts, cost);
     DI2P_RETURN_LAUNCH();
+}
+
+extern "C" long long di2p_solve_workspace_bytes(int F, int N) {
+    return (((long long)F * 4 + 255) & ~255ll) + (long long)F * N * 32 + 256;
 }

@@ -396,6 +396,11 @@ class MMClassifer:
     def forward(self, pc, intensity, sn, node_a, node_b, img):
         return self.detector(pc, intensity, sn, node_a, node_b, img)
 
+    def inference_labels(self):
+        """Device-resident variant of inference_pass: coarse argmax as i32 [B,N] (what the solver consumes)."""
+        out = self.forward(self.pc, self.intensity, self.sn, self.node_a, self.node_b, self.img)
+        return ops.argmax_channels(out[0] if self.opt.is_fine_resolution else out)
+
     def inference_pass(self):
         out = self.forward(self.pc, self.intensity, self.sn, self.node_a, self.node_b, self.img)
         if self.opt.is_fine_resolution:

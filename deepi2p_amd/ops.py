@@ -224,7 +224,7 @@ def initial_guess(points64, labels):
     return yaw0, labels_out, has_inside
 
 
-def solve_batched(points, labels, K, init_y, init_T, H, W, lb, ub, max_iter, is_2d, yaw0=None):
+def solve_batched(points, labels, K, init_y, init_T, H, W, lb, ub, max_iter, is_2d, yaw0=None, sweeps=None):
     """points f64|f32 [F,3,N], labels i32[F,N], K f64[F,3,3], init_y f64[F,R], init_T f64[F,R,3]
     -> params f64[F,R,np], cost f64[F,R], iters i32[F,R]."""
     require_cuda(points, labels, K, init_y, init_T, yaw0)
@@ -241,8 +241,9 @@ def solve_batched(points, labels, K, init_y, init_T, H, W, lb, ub, max_iter, is_
     name = "di2p_solve_batched" if points.dtype == _f64 else "di2p_solve_batched_f32"
     if points.dtype not in (_f64, _f32):
         raise RuntimeError("points must be float64 or float32")
+    ws = torch.empty((_lib.load().di2p_solve_workspace_bytes(F, N),), dtype=torch.uint8, device=points.device)
     call(name, ptr(points), ptr(labels), ptr(K), ptr(init_y), ptr(init_T), ptr(yaw0), float(H), float(W), _dbl3(lb),
-         _dbl3(ub), int(max_iter), int(bool(is_2d)), F, R, N, ptr(params), ptr(cost), ptr(iters), stream())
+         _dbl3(ub), int(max_iter), int(bool(is_2d)), F, R, N, ptr(params), ptr(cost), ptr(iters), ptr(sweeps), ptr(ws), stream())
     return params, cost, iters
 
 

@@ -67,7 +67,7 @@ def make_frame(rng, N=20480, H=160, W=512, Ma=128, Mb=128, flip=0.05, with_image
     sn = rng.standard_normal((3, N))
     sn /= np.linalg.norm(sn, axis=0, keepdims=True)
     out = dict(pc=pc.astype(np.float32), intensity=rng.random((1, N)).astype(np.float32),
-               sn=sn.astype(np.float32), node_a=pc[:, na].astype(np.float32), node_b=pc[:, nb].astype(np.float32),
+               sn=sn.astype(np.float32), node_a=np.ascontiguousarray(pc[:, na], dtype=np.float32), node_b=np.ascontiguousarray(pc[:, nb], dtype=np.float32),
                K=K, P_gt=P, yaw_gt=yaw, t_gt=t, labels_gt=labels, labels=labels_noisy)
     if with_image:
         out["img"] = rng.uniform(0, 255, (3, H, W)).astype(np.float32)
@@ -77,4 +77,4 @@ def make_frame(rng, N=20480, H=160, W=512, Ma=128, Mb=128, flip=0.05, with_image
 def make_batch(seed, B, **kw):
     rng = np.random.default_rng(seed)
     frames = [make_frame(rng, **kw) for _ in range(B)]
-    return {k: np.stack([f[k] for f in frames], axis=0) for k in frames[0]}
+    return {k: np.ascontiguousarray(np.stack([np.asarray(f[k]) for f in frames], axis=0)) for k in frames[0]}

@@ -158,8 +158,9 @@ int di2p_channel_max(const float* x, float* y, int B, int C, int N, void* stream
  *   Levenberg-Marquardt with box bounds on t (see DESIGN.md for the exact algorithm statement).
  *   points f64[F,3,N], labels i32[F,N], K f64[F,3,3] (fx,fy,cx,cy used), init_y f64[F,R],
  *   init_T f64[F,R,3], lb/ub f64[3] HOST arrays, is_2d: 4 params [ry,tx,ty,tz] else 6
- *   [angle-axis, t].  Outputs: params f64[F,R,np], cost f64[F,R], iters i32[F,R].
+ *   [angle-axis, t].  Outputs: params f64[F,R,np], cost f64[F,R], iters i32[F,R], sweeps i32[F,R] (optional).
  *   If yaw0 != NULL it is added to init_y per frame (restart noise drawn before yaw0 is known).
+ *   workspace: di2p_solve_workspace_bytes(F, N) bytes of scratch (packed point records).
  * di2p_select_best: argmin cost over R per frame (ties -> lowest r; frames with has_inside==0 get
  *   identity and cost 1e4, registration_lsq.py:329-332) -> best i32[F], P f64[F,4,4], cost f64[F].
  * di2p_solver_residuals: Problem::Evaluate of registration.cpp:150-155 at given params:
@@ -171,14 +172,15 @@ int di2p_solve_batched(const double* points, const int32_t* labels, const double
                        const double* init_y, const double* init_T, const double* yaw0,
                        double H, double W, const double* lb_host, const double* ub_host,
                        int max_iter, int is_2d, int F, int R, int N,
-                       double* params, double* cost, int32_t* iters, void* stream);
+                       double* params, double* cost, int32_t* iters, int32_t* sweeps /* may be NULL: #passes over the points */, void* workspace, void* stream);
 /* Same solver reading the points as f32 [F,3,N] (the network's own pc tensor; widening to f64 is
  * exact, so results are bit-identical to di2p_solve_batched on the widened copy). */
 int di2p_solve_batched_f32(const float* points, const int32_t* labels, const double* K,
                            const double* init_y, const double* init_T, const double* yaw0,
                            double H, double W, const double* lb_host, const double* ub_host,
                            int max_iter, int is_2d, int F, int R, int N,
-                           double* params, double* cost, int32_t* iters, void* stream);
+                           double* params, double* cost, int32_t* iters, int32_t* sweeps /* may be NULL: #passes over the points */, void* workspace, void* stream);
+long long di2p_solve_workspace_bytes(int F, int N);
 int di2p_select_best(const double* params, const double* cost, const int32_t* has_inside, int is_2d,
                      int F, int R, int32_t* best, double* P, double* best_cost, void* stream);
 int di2p_solver_residuals(const double* points, const int32_t* labels, const double* K,
