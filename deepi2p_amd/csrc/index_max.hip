@@ -139,7 +139,8 @@ int launch(const float* data, const int* index, int* max_idx, float* max_val, co
 extern "C" int di2p_index_max_forward(const float* data, const int32_t* index, int32_t* max_idx, int B, int C, int N,
                                       int K, void* workspace, void* stream) {
     DI2P_CHECK_ARG(B >= 0 && C >= 0 && N >= 0 && K >= 0, "negative size");
-    DI2P_CHECK_ARG(B == 0 || C == 0 || K == 0 || (data && index && max_idx) || N == 0, "null pointer");
+    if (B == 0 || C == 0 || K == 0) return 0;
+    DI2P_CHECK_ARG((data && index && max_idx) || N == 0, "null pointer");
     if (launch(data, index, max_idx, nullptr, nullptr, B, C, N, K, workspace, (hipStream_t)stream)) return -1;
     DI2P_RETURN_LAUNCH();
 }
@@ -147,6 +148,7 @@ extern "C" int di2p_index_max_forward(const float* data, const int32_t* index, i
 extern "C" int di2p_index_max_values(const float* data, const int32_t* index, const float* mask, float* max_val,
                                      int32_t* max_idx, int B, int C, int N, int K, void* workspace, void* stream) {
     DI2P_CHECK_ARG(B >= 0 && C >= 0 && N > 0 && K >= 0, "bad size");
+    if (B == 0 || C == 0 || K == 0) return 0;
     if (launch(data, index, max_idx, max_val, mask, B, C, N, K, workspace, (hipStream_t)stream)) return -1;
     DI2P_RETURN_LAUNCH();
 }
