@@ -47,7 +47,7 @@ _SIGS = {
                             ctypes.POINTER(EpilogueT), c_void_p],
     "di2p_batch_gemv": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "di2p_attention_pool": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
-    "di2p_conv2d": [c_void_p] * 6 + [c_int] * 10 + [c_void_p],
+    "di2p_conv2d": [c_void_p] * 6 + [c_int] * 11 + [c_void_p],
     "di2p_maxpool3x3s2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "di2p_global_avgpool": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "di2p_channel_max": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
@@ -60,7 +60,7 @@ _SIGS = {
     "di2p_solver_residuals": [c_void_p] * 4 + [c_double, c_double, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "di2p_f32_to_f64": [c_void_p, c_void_p, c_ll, c_void_p],
 }
-EXPORTS = sorted(list(_SIGS) + ["di2p_last_error", "di2p_version", "di2p_solve_workspace_bytes"])
+EXPORTS = sorted(list(_SIGS) + ["di2p_last_error", "di2p_version", "di2p_solve_workspace_bytes", "di2p_solver_set_profile_buffer"])
 
 
 def load():
@@ -80,6 +80,8 @@ def load():
         lib.di2p_version.restype = c_int
         lib.di2p_solve_workspace_bytes.restype = c_ll
         lib.di2p_solve_workspace_bytes.argtypes = [c_int, c_int]
+        lib.di2p_solver_set_profile_buffer.restype = None
+        lib.di2p_solver_set_profile_buffer.argtypes = [c_void_p]
         _lib = lib
     return _lib
 

@@ -32,6 +32,7 @@ struct LoaderIm2col {
         ih0 = oh * stride - pad;
         iw0 = ow * stride - pad;
     }
+    __device__ __forceinline__ void begin_tile(int) {}
     __device__ __forceinline__ float load(int k) const {
         k = __builtin_amdgcn_readfirstlane(k);
         if (!valid || k >= K) return 0.0f;
@@ -42,6 +43,41 @@ struct LoaderIm2col {
         if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) return 0.0f;
         return xb[((long long)ci * H + ih) * W + iw];
     }
+};
+
+// Tap-major K order: k' = (kh*KW + kw)*Cin + ci with Cin % 16 == 0, so one 16-row K-step lies inside ONE filter
+// tap: the tap decode, the bounds test and the base address are computed once per K-step per lane, and the
+// staged rows are constant-stride (H*W) loads.  (The generic loader above pays two integer divisions per
+// staged element, which made the kernel VALU-bound at ~40 TF.)
+struct LoaderIm2colTap {
+    const float* x;
+    int Cin, H, W, OH, OW, KH, KW, stride, pad, K, Ntot;
+    const float* xb;
+    const float* tile_ptr;   // xb + (ci0*H + ih)*W + iw of the current K-step (nullptr: out of bounds)
+    int ih0, iw0, HW;
+    int ci0, kh, kw;         // wave-uniform walk over the taps
+    bool valid;
+    __device__ __forceinline__ void column(int j) {
+        valid = j < Ntot;
+        const int jj = valid ? j : 0;
+        const int opix = OH * OW;
+        const int b = jj / opix, pix = jj - b * opix;
+        const int oh = pix / OW, ow = pix - oh * OW;
+        HW = H * W;
+        xb = x + (long long)b * Cin * HW;
+        ih0 = oh * stride - pad;
+        iw0 = ow * stride - pad;
+        ci0 = -16; kh = 0; kw = 0;
+        tile_ptr = nullptr;
+    }
+    __device__ __forceinline__ void begin_tile(int) {
+        ci0 += 16;
+        if (ci0 >= Cin) { ci0 = 0; if (++kw == KW) { kw = 0; ++kh; } }
+        const int ih = ih0 + kh, iw = iw0 + kw;
+        const bool ok = valid && kh < KH && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        tile_ptr = ok ? xb + (ci0 * H + ih) * W + iw : nullptr;
+    }
+    __device__ __forceinline__ float load(int k) const { return tile_ptr ? tile_ptr[(k & 15) * HW] : 0.0f; }
 };
 
 struct EpiConv {
@@ -67,7 +103,7 @@ struct EpiConv {
     }
 };
 
-template <class Cfg>
+template <class Cfg, bool TAP>
 __global__ __launch_bounds__(Cfg::THREADS) void conv2d_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                const float* __restrict__ residual, float* __restrict__ y, int Cin,
@@ -76,18 +112,30 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv2d_kernel(const float* __res
     extern __shared__ float lds[];
     const int K = Cin * KH * KW;
     LoaderWtC la{Wt, K, Cout};
-    LoaderIm2col lb{x, Cin, H, W, OH, OW, KH, KW, stride, pad, K, Ntot, nullptr, 0, 0, false};
     EpiConv ep{scale, shift, residual, y, Cout, OH * OW, Ntot, relu};
-    mfma_gemm_block<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
+    if (TAP) {
+        LoaderIm2colTap lb;
+        lb.x = x; lb.Cin = Cin; lb.H = H; lb.W = W; lb.OH = OH; lb.OW = OW; lb.KH = KH; lb.KW = KW; lb.stride = stride;
+        lb.pad = pad; lb.K = K; lb.Ntot = Ntot;
+        mfma_gemm_block<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
+    } else {
+        LoaderIm2col lb{x, Cin, H, W, OH, OW, KH, KW, stride, pad, K, Ntot, nullptr, 0, 0, false};
+        mfma_gemm_block<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
+    }
 }
 
 template <class Cfg>
 void launch_conv(const float* x, const float* Wt, const float* scale, const float* shift, const float* residual, float* y,
                  int Cin, int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride, int pad, int Ntot, int relu,
-                 hipStream_t st) {
-    hipLaunchKernelGGL(conv2d_kernel<Cfg>, dim3(di2p_cdiv(Ntot, Cfg::BN), di2p_cdiv(Cout, Cfg::BM)), dim3(Cfg::THREADS),
-                       Cfg::LDS_FLOATS * sizeof(float), st, x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW,
-                       stride, pad, Ntot, relu);
+                 int tap_major, hipStream_t st) {
+    const dim3 grid(di2p_cdiv(Ntot, Cfg::BN), di2p_cdiv(Cout, Cfg::BM)), block(Cfg::THREADS);
+    const size_t lds = Cfg::LDS_FLOATS * sizeof(float);
+    if (tap_major)
+        hipLaunchKernelGGL((conv2d_kernel<Cfg, true>), grid, block, lds, st, x, Wt, scale, shift, residual, y, Cin, H, W, Cout,
+                           OH, OW, KH, KW, stride, pad, Ntot, relu);
+    else
+        hipLaunchKernelGGL((conv2d_kernel<Cfg, false>), grid, block, lds, st, x, Wt, scale, shift, residual, y, Cin, H, W, Cout,
+                           OH, OW, KH, KW, stride, pad, Ntot, relu);
 }
 
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int OH,
@@ -134,12 +182,14 @@ using CfgC64x64 = TileCfg<2, 2, 1, 1>;
 
 extern "C" int di2p_conv2d(const float* x, const float* Wt, const float* scale, const float* shift, const float* residual,
                            float* y, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int relu,
-                           void* stream) {
+                           int tap_major, void* stream) {
     DI2P_CHECK_ARG(x && Wt && scale && shift && y, "null pointer");
     DI2P_CHECK_ARG(B >= 0 && Cin >= 1 && H >= 1 && W >= 1 && Cout >= 1 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0, "bad size");
     if (B == 0) return 0;
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     DI2P_CHECK_ARG(OH >= 1 && OW >= 1, "empty output");
+    DI2P_CHECK_ARG(!tap_major || Cin % 16 == 0, "tap-major weights need Cin % 16 == 0");
+    DI2P_CHECK_ARG((long long)Cin * H * W < (1ll << 31), "per-image extent must fit 31 bits");
     const long long Ntot_ll = (long long)B * OH * OW;
     DI2P_CHECK_ARG(Ntot_ll < (1ll << 31), "too many output pixels");
     const int Ntot = (int)Ntot_ll;
@@ -148,11 +198,11 @@ extern "C" int di2p_conv2d(const float* x, const float* Wt, const float* scale, 
     const long long b128 = (long long)di2p_cdiv(Ntot, 128) * di2p_cdiv(Cout, 128);
     const long long b64x128 = (long long)di2p_cdiv(Ntot, 128) * di2p_cdiv(Cout, 64);
     if (Cout > 64 && b128 >= 512)
-        launch_conv<CfgC128x128>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, st);
+        launch_conv<CfgC128x128>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, tap_major, st);
     else if (b64x128 >= 384)
-        launch_conv<CfgC64x128>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, st);
+        launch_conv<CfgC64x128>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, tap_major, st);
     else
-        launch_conv<CfgC64x64>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, st);
+        launch_conv<CfgC64x64>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, tap_major, st);
     DI2P_RETURN_LAUNCH();
 }
 

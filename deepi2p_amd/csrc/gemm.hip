@@ -44,12 +44,14 @@ struct LoaderConcat {
             }
         }
     }
+    __device__ __forceinline__ void begin_tile(int) {}
     __device__ __forceinline__ float load(int k) const {
         k = __builtin_amdgcn_readfirstlane(k);  // a wave stages one panel row: k is wave-uniform
         if (!valid || k >= K) return 0.0f;
-        if (k < s.c_end[0]) return base[0][(long long)k * s.row_stride[0]];
-        if (DI2P_MAX_SRC > 1 && k < s.c_end[1]) return base[1][(long long)(k - s.c_end[0]) * s.row_stride[1]];
-        return base[2][(long long)(k - s.c_end[1]) * s.row_stride[2]];
+        // within-frame offsets fit 32 bits (checked on the host): no 64-bit multiplies in the hot loader
+        if (k < s.c_end[0]) return base[0][k * s.row_stride[0]];
+        if (DI2P_MAX_SRC > 1 && k < s.c_end[1]) return base[1][(k - s.c_end[0]) * s.row_stride[1]];
+        return base[2][(k - s.c_end[1]) * s.row_stride[2]];
     }
 };
 
@@ -142,6 +144,7 @@ struct LoaderScore {
     int HW, Mn, n;
     bool valid;
     __device__ __forceinline__ void column(int j) { n = j; valid = j < Mn; }
+    __device__ __forceinline__ void begin_tile(int) {}
     __device__ __forceinline__ float load(int k) const { return (valid && k < HW) ? score[(long long)k * Mn + n] : 0.0f; }
 };
 struct EpiMean {
@@ -204,6 +207,7 @@ extern "C" int di2p_pointwise_gemm(const di2p_src_t* srcs, int n_src, const floa
             DI2P_CHECK_ARG(srcs[i].ptr && srcs[i].channels > 0, "bad source");
             DI2P_CHECK_ARG(srcs[i].mode != DI2P_SRC_GATHER || srcs[i].gidx, "gather source without index");
             DI2P_CHECK_ARG(srcs[i].mode != DI2P_SRC_GROUP || srcs[i].group >= 1, "group source without group");
+            DI2P_CHECK_ARG((long long)srcs[i].channels * srcs[i].row_stride < (1ll << 31), "per-frame source extent must fit 31 bits");
             s.ptr[i] = srcs[i].ptr; s.gidx[i] = srcs[i].gidx; s.batch_stride[i] = srcs[i].batch_stride;
             s.row_stride[i] = srcs[i].row_stride; s.mode[i] = srcs[i].mode; s.group[i] = srcs[i].group > 0 ? srcs[i].group : 1;
             ctot += srcs[i].channels;

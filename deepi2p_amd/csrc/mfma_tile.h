@@ -28,7 +28,7 @@ struct TileCfg {
 };
 
 // LoaderA: float load(int k, int m)             (k < K, m < M checked by the loader)
-// LoaderB: void  column(int j) ; float load(int k)
+// LoaderB: void  column(int j) ; void begin_tile(int k0) (called once per K-step, in order) ; float load(int k)
 // Epi    : void  store(int m, int j, float acc)  -- called for every valid (m, j)
 template <class Cfg, class LoaderA, class LoaderB, class Epi>
 __device__ __forceinline__ void mfma_gemm_block(float* lds, LoaderA& la, LoaderB& lb, Epi& epi, int K, int m_blk, int j_blk) {
@@ -57,6 +57,7 @@ __device__ __forceinline__ void mfma_gemm_block(float* lds, LoaderA& la, LoaderB
 
     auto gload = [&](int t) {
         const int k0 = t * BK;
+        lb.begin_tile(k0);
 #pragma unroll
         for (int p = 0; p < Cfg::A_PASSES; ++p) ra[p] = la.load(k0 + a_row0 + p * Cfg::A_RPP, m_blk + a_col);
 #pragma unroll

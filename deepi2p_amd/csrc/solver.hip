@@ -246,8 +246,8 @@ __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& ro
 // barrier.  Records are prefetched one batch (U per lane) ahead so a batch's arithmetic covers the next
 // batch's L2/HBM latency.
 template <int NP, typename PT, int WPH, int U>   // U = records per lane per batch
-__device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, int cnt, const Cam& k, const double* x,
-                                      SweepShared<NP, WPH>& sh) {
+__device__ __forceinline__ int sweep(const Rec<PT>* __restrict__ recs, int cnt, const Cam& k, const double* x,
+                                     SweepShared<NP, WPH>& sh) {
     constexpr int TOFF = NP == 4 ? 1 : 3;
     constexpr int NV = Tri<NP>::N + NP + 2;
     Rot<NP> rot;
@@ -257,6 +257,7 @@ __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, int cnt,
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int* queue = sh.queue[wave];
     int qn = 0;  // wave-uniform
+    int n_active = 0;
     double cost = 0.0;
     double lg[NP], lA[Tri<NP>::N];
 #pragma unroll
@@ -309,6 +310,7 @@ __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, int cnt,
             __builtin_amdgcn_wave_barrier();
             if (lane + 64 < qn) queue[lane] = carry;      // (entries beyond 128 are shifted on later rounds)
             for (int j = 128 + lane; j < qn; j += 64) { const int c2 = queue[j]; queue[j - 64] = c2; }
+            n_active += qn > 64 ? 64 : qn;
             qn = qn > 64 ? qn - 64 : 0;
             __builtin_amdgcn_wave_barrier();
             if (n >= 0) eval_active<NP, PT>(recs[n], rot, x, k, cost, lg, lA, bad);
@@ -323,6 +325,7 @@ __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, int cnt,
 #pragma unroll
     for (int i = 0; i < Tri<NP>::N; ++i) { v = wave_sum(lA[i]); if (lane == 0) mine[1 + NP + i] = v; }
     if (lane == 0) mine[NV - 1] = (__any(bad) != 0) ? 1.0 : 0.0;
+    return n_active;
 }
 
 template <int NP>
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
                                                        const double* __restrict__ init_T, const double* __restrict__ yaw0,
                                                        double H, double W, Bounds bnd, int max_iter, int F, int R, int N,
                                                        double* __restrict__ params_out, double* __restrict__ cost_out,
-                                                       int* __restrict__ iters_out, int* __restrict__ sweeps_out) {
+                                                       int* __restrict__ iters_out, int* __restrict__ sweeps_out, long long* __restrict__ prof) {
     constexpr int TOFF = NP == 4 ? 1 : 3;
     constexpr int NT = Tri<NP>::N;
     constexpr int NV = NT + NP + 2;
@@ -547,12 +550,16 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
         st.phase = PH_INIT; st.done = 0; st.max_iter = max_iter; st.cost = 0.0; st.gmax = 0.0;
     }
     __syncthreads();
+    long long c_sweep = 0, c_wait = 0, c_lm = 0, n_act = 0;
     for (;;) {
         double xe[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) xe[i] = st.xe[i];
-        sweep<NP, PT, WPH, U>(recs, cnt, k, xe, sh);
+        const long long t0 = prof ? clock64() : 0;
+        n_act += sweep<NP, PT, WPH, U>(recs, cnt, k, xe, sh);
+        const long long t1 = prof ? clock64() : 0;
         __syncthreads();
+        const long long t2 = prof ? clock64() : 0;
         if (threadIdx.x == 0) {
             double v[NV];
             for (int i = 0; i < NV; ++i) {      // fixed-order combination of the wave partials
@@ -563,8 +570,13 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
             const bool ok = v[NV - 1] == 0.0 && isfinite(v[0]);
             lm_after_sweep<NP>(st, ok, v[0], v + 1, v + 1 + NP);
         }
+        const long long t3 = prof ? clock64() : 0;
         __syncthreads();
+        c_sweep += t1 - t0; c_wait += t2 - t1; c_lm += t3 - t2;
         if (st.done) break;
+    }
+    if (prof && threadIdx.x == 0) {   // diagnostics: shader-clock cycles of wave 0 per phase, phase-B evaluations of wave 0
+        prof[hr * 4 + 0] = c_sweep; prof[hr * 4 + 1] = c_wait; prof[hr * 4 + 2] = c_lm; prof[hr * 4 + 3] = n_act;
     }
     if (threadIdx.x == 0) {
         for (int i = 0; i < NP; ++i) params_out[hr * NP + i] = st.x[i];
@@ -743,6 +755,8 @@ __global__ __launch_bounds__(256) void residuals_kernel(const double* __restrict
     if (tid == 0) { counts[f] = s_base; cost_out[f] = s_cost[0]; }
 }
 
+static long long* g_prof = nullptr;   // diagnostics hook, see di2p_solver_set_profile_buffer
+
 template <typename PT>
 int launch_solve(const PT* points, const int* labels, const double* K, const double* init_y, const double* init_T,
                  const double* yaw0, double H, double W, const double* lb, const double* ub, int max_iter, int is_2d, int F,
@@ -756,7 +770,7 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
     static int cfg = -1;
     if (cfg < 0) { const char* e = getenv("DI2P_SOLVER_CFG"); cfg = e ? atoi(e) : 443; }
     const dim3 grid(R * F);
-#define DI2P_LAUNCH_SOLVE(NPV, MW, WP, UU) hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP, UU>), grid, dim3(WP * 64), 0, st, packed, counts, K, init_y, init_T, yaw0, H, W, b, max_iter, F, R, N, params, cost, iters, sweeps)
+#define DI2P_LAUNCH_SOLVE(NPV, MW, WP, UU) hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP, UU>), grid, dim3(WP * 64), 0, st, packed, counts, K, init_y, init_T, yaw0, H, W, b, max_iter, F, R, N, params, cost, iters, sweeps, g_prof)
     if (is_2d) {
         switch (cfg) {
             case 442: DI2P_LAUNCH_SOLVE(4, 2, 4, 4); break;
@@ -829,3 +843,7 @@ extern "C" int di2p_solver_residuals(const double* points, const int32_t* labels
 extern "C" long long di2p_solve_workspace_bytes(int F, int N) {
     return (((long long)F * 4 + 255) & ~255ll) + (long long)F * N * 32 + 256;
 }
+
+// Diagnostics: when set to a device buffer of F*R*4 int64, every solve launch records per hypothesis the shader-clock
+// cycles wave 0 spent in {sweep, waiting at the reduction barrier, LM update} and its number of phase-B evaluations.
+extern "C" void di2p_solver_set_profile_buffer(void* buf) { g_prof = (long long*)buf; }

@@ -110,10 +110,14 @@ class _PackedModule(nn.Module):
         return {k: v for k, v in self.state_dict().items()}
 
 
-def _fold(sd, conv_key, norm_key):
-    """(Wt [K,M], scale [M]|None, shift [M]) for conv(+bias) followed by optional BN(eval)."""
+def _fold(sd, conv_key, norm_key, tap_major=False):
+    """(Wt [K,M], scale [M]|None, shift [M]) for conv(+bias) followed by optional BN(eval).
+    tap_major: rows ordered (kh,kw,ci) instead of the weight's (ci,kh,kw) (see di2p_conv2d)."""
     w = sd[conv_key + ".weight"]
-    Wt = w.reshape(w.shape[0], -1).t().contiguous()
+    if tap_major:
+        Wt = w.permute(2, 3, 1, 0).reshape(-1, w.shape[0]).contiguous()
+    else:
+        Wt = w.reshape(w.shape[0], -1).t().contiguous()
     bias = sd.get(conv_key + ".bias")
     if norm_key is not None and (norm_key + ".weight") in sd:
         scale = sd[norm_key + ".weight"] / torch.sqrt(sd[norm_key + ".running_var"] + BN_EPS)
@@ -238,10 +242,10 @@ class ImageEncoder(_PackedModule):
             for li, nb in enumerate(self.LAYERS, start=1):
                 for bi in range(nb):
                     q = "%s.layer%d.%d" % (r, li, bi)
-                    blk = {"c1": _fold(sd, q + ".conv1", q + ".bn1"), "c2": _fold(sd, q + ".conv2", q + ".bn2"),
+                    blk = {"c1": _fold(sd, q + ".conv1", q + ".bn1", True), "c2": _fold(sd, q + ".conv2", q + ".bn2", True),
                            "stride": 2 if (bi == 0 and li > 1) else 1, "last_of_stage": bi == nb - 1, "stage": li}
                     if (q + ".downsample.0.weight") in sd:
-                        blk["ds"] = _fold(sd, q + ".downsample.0", q + ".downsample.1")
+                        blk["ds"] = _fold(sd, q + ".downsample.0", q + ".downsample.1", True)
                     p["blocks"].append(blk)
             self._packed = p
         return self._packed
@@ -256,12 +260,12 @@ class ImageEncoder(_PackedModule):
         for blk in p["blocks"]:
             identity = x
             Wt, sc, sh, _ = blk["c1"]
-            y = ops.conv2d(x, Wt, sc, sh, 3, 3, blk["stride"], 1, True)
+            y = ops.conv2d(x, Wt, sc, sh, 3, 3, blk["stride"], 1, True, tap_major=True)
             if "ds" in blk:
                 Wd, sd_, shd, _ = blk["ds"]
-                identity = ops.conv2d(x, Wd, sd_, shd, 1, 1, blk["stride"], 0, False)
+                identity = ops.conv2d(x, Wd, sd_, shd, 1, 1, blk["stride"], 0, False, tap_major=True)
             Wt, sc, sh, _ = blk["c2"]
-            x = ops.conv2d(y, Wt, sc, sh, 3, 3, 1, 1, True, residual=identity)
+            x = ops.conv2d(y, Wt, sc, sh, 3, 3, 1, 1, True, residual=identity, tap_major=True)
             if blk["last_of_stage"]:
                 stage_out[blk["stage"]] = x
         return stage_out[3], stage_out[4], ops.global_avgpool(stage_out[4])

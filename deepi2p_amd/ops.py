@@ -178,7 +178,7 @@ def attention_pool(feat, score):
     return out
 
 
-def conv2d(x, Wt, scale, shift, KH, KW, stride, pad, relu, residual=None):
+def conv2d(x, Wt, scale, shift, KH, KW, stride, pad, relu, residual=None, tap_major=False):
     require_cuda(x, Wt, scale, shift, residual)
     B, Cin, H, W = x.shape
     Cout = Wt.shape[1]
@@ -186,7 +186,7 @@ def conv2d(x, Wt, scale, shift, KH, KW, stride, pad, relu, residual=None):
     OW = (W + 2 * pad - KW) // stride + 1
     y = torch.empty((B, Cout, OH, OW), dtype=_f32, device=x.device)
     call("di2p_conv2d", ptr(x), ptr(Wt), ptr(scale), ptr(shift), ptr(residual), ptr(y), B, Cin, H, W, Cout, KH, KW,
-         stride, pad, int(bool(relu)), stream())
+         stride, pad, int(bool(relu)), int(bool(tap_major)), stream())
     return y
 
 

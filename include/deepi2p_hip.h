@@ -138,10 +138,12 @@ int di2p_attention_pool(const float* feat, const float* score, float* out, int B
  * add, 7x7/2 stem, 3x3/2 max-pool, global average pool) as implicit-GEMM convolutions on fp32
  * MFMA with the BN(eval)+residual+ReLU epilogue fused.
  *   x f32[B,Cin,H,W] (NCHW), Wt f32[Cin*KH*KW, Cout] (weight[co,ci,kh,kw] transposed), y
- *   f32[B,Cout,OH,OW];  y = relu?( scale*conv(x) + shift + residual ). */
+ *   f32[B,Cout,OH,OW];  y = relu?( scale*conv(x) + shift + residual ).
+ *   tap_major != 0: Wt rows are ordered (kh,kw,ci) instead of the weight's own (ci,kh,kw); needs Cin % 16 == 0 and
+ *   lets the loader decode the filter tap once per 16-row K-step. */
 int di2p_conv2d(const float* x, const float* Wt, const float* scale, const float* shift,
                 const float* residual, float* y, int B, int Cin, int H, int W, int Cout,
-                int KH, int KW, int stride, int pad, int relu, void* stream);
+                int KH, int KW, int stride, int pad, int relu, int tap_major, void* stream);
 int di2p_maxpool3x3s2(const float* x, float* y, int B, int C, int H, int W, void* stream);
 int di2p_global_avgpool(const float* x, float* y, int B, int C, int HW, void* stream);
 /* out[b,c] = max_n x[b,c,n]  (networks_pc.py:115) */
@@ -181,6 +183,8 @@ int di2p_solve_batched_f32(const float* points, const int32_t* labels, const dou
                            int max_iter, int is_2d, int F, int R, int N,
                            double* params, double* cost, int32_t* iters, int32_t* sweeps /* may be NULL: #passes over the points */, void* workspace, void* stream);
 long long di2p_solve_workspace_bytes(int F, int N);
+/* diagnostics only: device buffer of F*R*4 int64 (or NULL) receiving per-hypothesis phase cycle counts */
+void di2p_solver_set_profile_buffer(void* buf);
 int di2p_select_best(const double* params, const double* cost, const int32_t* has_inside, int is_2d,
                      int F, int R, int32_t* best, double* P, double* best_cost, void* stream);
 int di2p_solver_residuals(const double* points, const int32_t* labels, const double* K,

@@ -116,6 +116,10 @@ def test_conv2d(dev, B, Cin, H, W, Cout, k, s, p):
     assert (y - ref).abs().max() <= _tol(ref0, Cin * k * k)
     y2 = ops.conv2d(x.to(dev), Wt, scale.to(dev), shift.to(dev), k, k, s, p, False).cpu()
     assert (y2 - ref0).abs().max() <= _tol(ref0, Cin * k * k)
+    if Cin % 16 == 0:   # tap-major weight packing (kh,kw,ci): same result
+        Wtap = w.permute(2, 3, 1, 0).reshape(-1, Cout).contiguous().to(dev)
+        y3 = ops.conv2d(x.to(dev), Wtap, scale.to(dev), shift.to(dev), k, k, s, p, True, residual=res.to(dev), tap_major=True).cpu()
+        assert (y3 - ref).abs().max() <= _tol(ref0, Cin * k * k)
 
 
 def test_pools(dev):
