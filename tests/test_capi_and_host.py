@@ -39,7 +39,7 @@ def test_argument_errors_are_reported_not_crashed():
     with pytest.raises(_lib.DeepI2PHipError, match="k must be"):
         _lib.call("di2p_knn_nodes", None, None, None, None, 1, 10, 8, 99, None)
     with pytest.raises(_lib.DeepI2PHipError, match="null"):
-        _lib.call("di2p_conv2d", None, None, None, None, None, None, 1, 3, 8, 8, 4, 3, 3, 1, 1, 0, None)
+        _lib.call("di2p_conv2d", None, None, None, None, None, None, 1, 3, 8, 8, 4, 3, 3, 1, 1, 0, 0, None)
     # empty problems are valid no-ops (edge cases: B == 0)
     _lib.call("di2p_ball_query_forward", None, None, 0.5, 4, 0, 3, 10, None)
     _lib.call("di2p_index_max_forward", None, None, None, 0, 4, 10, 8, None, None)
