@@ -62,11 +62,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # DI2P_BENCH_BACKEND=gloo + DI2P_BENCH_ONE_DEVICE=1 let the multi-rank code path be exercised on a 1-GPU box
+    backend = os.environ.get("DI2P_BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
+    if os.environ.get("DI2P_BENCH_ONE_DEVICE"):
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl")
+        dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -83,7 +87,12 @@ def main():
     mm.detector.load_state_dict(sd)
     if world > 1:  # weights broadcast once over RCCL/xGMI (stands in for nn.DataParallel's per-step replicate)
         for t in mm.detector.state_dict().values():
-            dist.broadcast(t, 0)
+            if backend == "nccl":
+                dist.broadcast(t, 0)
+            else:                       # gloo (test mode): via host memory
+                h = t.cpu()
+                dist.broadcast(h, 0)
+                t.copy_(h)
         mm.detector._invalidate()
     batch = synthetic.make_batch(1000 + rank, B, N=N, H=H, W=W)
     t = {k: torch.from_numpy(batch[k]) for k in ("pc", "intensity", "sn", "node_a", "node_b", "img")}
@@ -149,7 +158,7 @@ def main():
     _lib.TIMED = None
     overlap = overlap_saved
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     frames = B * args.steps * world

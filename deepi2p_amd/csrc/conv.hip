@@ -8,12 +8,14 @@
 //   input row, i.e. coalesced 128-B segments straight from the reference's own layout.
 #include "mfma_tile.h"
 
+#include <stdlib.h>
+
 namespace {
 
 struct LoaderWtC {
     const float* Wt;  // [K][Cout]
     int K, M;
-    __device__ __forceinline__ float load(int k, int m) const { return (k < K && m < M) ? Wt[(long long)k * M + m] : 0.0f; }
+    __device__ __forceinline__ float load(int k, int m) const { return (k < K && m < M) ? Wt[k * M + m] : 0.0f; }   // K*M < 2^31 (host-checked)
 };
 
 struct LoaderIm2col {
@@ -67,17 +69,18 @@ struct LoaderIm2colTap {
         xb = x + (long long)b * Cin * HW;
         ih0 = oh * stride - pad;
         iw0 = ow * stride - pad;
-        ci0 = -16; kh = 0; kw = 0;
+        ci0 = -bk; kh = 0; kw = 0;
         tile_ptr = nullptr;
     }
+    int bk;                  // K-step (16 or 32); Cin % bk == 0
     __device__ __forceinline__ void begin_tile(int) {
-        ci0 += 16;
+        ci0 += bk;
         if (ci0 >= Cin) { ci0 = 0; if (++kw == KW) { kw = 0; ++kh; } }
         const int ih = ih0 + kh, iw = iw0 + kw;
         const bool ok = valid && kh < KH && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
         tile_ptr = ok ? xb + (ci0 * H + ih) * W + iw : nullptr;
     }
-    __device__ __forceinline__ float load(int k) const { return tile_ptr ? tile_ptr[(k & 15) * HW] : 0.0f; }
+    __device__ __forceinline__ float load(int k) const { return tile_ptr ? tile_ptr[(k & (bk - 1)) * HW] : 0.0f; }
 };
 
 struct EpiConv {
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv2d_kernel(const float* __res
     if (TAP) {
         LoaderIm2colTap lb;
         lb.x = x; lb.Cin = Cin; lb.H = H; lb.W = W; lb.OH = OH; lb.OW = OW; lb.KH = KH; lb.KW = KW; lb.stride = stride;
-        lb.pad = pad; lb.K = K; lb.Ntot = Ntot;
+        lb.pad = pad; lb.K = K; lb.Ntot = Ntot; lb.bk = Cfg::BK;
         mfma_gemm_block<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
     } else {
         LoaderIm2col lb{x, Cin, H, W, OH, OW, KH, KW, stride, pad, K, Ntot, nullptr, 0, 0, false};
@@ -179,6 +182,11 @@ __global__ __launch_bounds__(256) void global_avgpool_kernel(const float* __rest
 using CfgC128x128 = TileCfg<2, 2, 2, 2>;
 using CfgC64x128 = TileCfg<2, 2, 1, 2>;
 using CfgC64x64 = TileCfg<2, 2, 1, 1>;
+using CfgC128x64 = TileCfg<2, 2, 2, 1>;
+using CfgC128x128k32 = TileCfg<2, 2, 2, 2, 32>;
+using CfgC64x128k32 = TileCfg<2, 2, 1, 2, 32>;
+using CfgC64x64k32 = TileCfg<2, 2, 1, 1, 32>;
+using CfgC128x64k32 = TileCfg<2, 2, 2, 1, 32>;
 
 extern "C" int di2p_conv2d(const float* x, const float* Wt, const float* scale, const float* shift, const float* residual,
                            float* y, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int relu,
@@ -194,15 +202,30 @@ extern "C" int di2p_conv2d(const float* x, const float* Wt, const float* scale, 
     DI2P_CHECK_ARG(Ntot_ll < (1ll << 31), "too many output pixels");
     const int Ntot = (int)Ntot_ll;
     hipStream_t st = (hipStream_t)stream;
-    // biggest tile that still gives every CU a workgroup
-    const long long b128 = (long long)di2p_cdiv(Ntot, 128) * di2p_cdiv(Cout, 128);
-    const long long b64x128 = (long long)di2p_cdiv(Ntot, 128) * di2p_cdiv(Cout, 64);
-    if (Cout > 64 && b128 >= 512)
-        launch_conv<CfgC128x128>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, tap_major, st);
-    else if (b64x128 >= 384)
-        launch_conv<CfgC64x128>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, tap_major, st);
-    else
-        launch_conv<CfgC64x64>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, tap_major, st);
+#define DI2P_CONV(CFG) launch_conv<CFG>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, tap_major, st)
+    // tile choice: K-step 32 when a tap holds whole 32-channel groups (halves barriers, doubles the prefetch
+    // distance); the largest tile that still yields >= ~2 workgroups per CU.  DI2P_CONV_CFG overrides (experiments).
+    static int force = -2;
+    if (force == -2) { const char* e = getenv("DI2P_CONV_CFG"); force = e ? atoi(e) : -1; }
+    const bool k32 = tap_major && Cin % 32 == 0;
+    const long long nb64x128 = (long long)di2p_cdiv(Ntot, 128) * di2p_cdiv(Cout, 64);
+    const long long nb128x128 = (long long)di2p_cdiv(Ntot, 128) * di2p_cdiv(Cout, 128);
+    const long long nb128x64 = (long long)di2p_cdiv(Ntot, 64) * di2p_cdiv(Cout, 128);
+    int choice;   // 0: 64x64  1: 64x128  2: 128x64  3: 128x128
+    if (Cout >= 128 && nb128x128 >= 512) choice = 3;
+    else if (nb64x128 >= 512) choice = 1;
+    else if (Cout >= 128 && nb128x64 >= 512) choice = 2;
+    else choice = 0;
+    if (force >= 0) { choice = force % 10; if (choice >= 2 && Cout < 128) choice = 1; }
+    const bool use32 = k32 && (force < 0 || force >= 10);
+    if (use32) {
+        switch (choice) { case 3: DI2P_CONV(CfgC128x128k32); break; case 2: DI2P_CONV(CfgC128x64k32); break;
+                          case 1: DI2P_CONV(CfgC64x128k32); break; default: DI2P_CONV(CfgC64x64k32); }
+    } else {
+        switch (choice) { case 3: DI2P_CONV(CfgC128x128); break; case 2: DI2P_CONV(CfgC128x64); break;
+                          case 1: DI2P_CONV(CfgC64x128); break; default: DI2P_CONV(CfgC64x64); }
+    }
+#undef DI2P_CONV
     DI2P_RETURN_LAUNCH();
 }
 

@@ -12,7 +12,7 @@ namespace {
 struct LoaderWt {  // packed weight [K][M]
     const float* Wt;
     int K, M;
-    __device__ __forceinline__ float load(int k, int m) const { return (k < K && m < M) ? Wt[(long long)k * M + m] : 0.0f; }
+    __device__ __forceinline__ float load(int k, int m) const { return (k < K && m < M) ? Wt[k * M + m] : 0.0f; }   // K*M < 2^31 (host-checked)
 };
 
 struct SrcDev {
@@ -199,6 +199,7 @@ extern "C" int di2p_pointwise_gemm(const di2p_src_t* srcs, int n_src, const floa
                                    const di2p_epilogue_t* epi, void* stream) {
     DI2P_CHECK_ARG(srcs && n_src >= 1 && n_src <= DI2P_MAX_SRC, "1..3 sources");
     DI2P_CHECK_ARG(B >= 0 && M >= 1 && K >= 1 && N >= 0, "bad size");
+    DI2P_CHECK_ARG((long long)K * M < (1ll << 31), "weight too large");
     if (B == 0 || N == 0) return 0;
     SrcDev s{};
     int ctot = 0;

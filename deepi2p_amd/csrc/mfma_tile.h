@@ -15,10 +15,10 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int WM_, int WN_, int TM_, int TN_>
+template <int WM_, int WN_, int TM_, int TN_, int BK_ = 16>
 struct TileCfg {
     static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
-    static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 16;
+    static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = BK_;
     static constexpr int THREADS = WM * WN * 64;
     static constexpr int A_RPP = THREADS / BM, A_PASSES = BK / A_RPP;  // rows per pass / passes
     static constexpr int B_RPP = THREADS / BN, B_PASSES = BK / B_RPP;
@@ -78,19 +78,23 @@ __device__ __forceinline__ void mfma_gemm_block(float* lds, LoaderA& la, LoaderB
         if (t + 1 < T) gload(t + 1);
         const float* Ab = As + buf * BK * BM + wm * Cfg::TM * 32 + l31;
         const float* Bb = Bs + buf * BK * BN + wn * Cfg::TN * 32 + l31;
+        // all operand reads of the K-step first, then the MFMAs back to back: the LDS latency is paid once per
+        // K-step instead of once per k-pair (the compiler otherwise waits lgkmcnt(0) before every MFMA pair)
+        float a[BK / 2][Cfg::TM], b[BK / 2][Cfg::TN];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float a[Cfg::TM], b[Cfg::TN];
 #pragma unroll
-            for (int i = 0; i < Cfg::TM; ++i) a[i] = Ab[(kk + half) * BM + i * 32];
+            for (int i = 0; i < Cfg::TM; ++i) a[kk / 2][i] = Ab[(kk + half) * BM + i * 32];
 #pragma unroll
-            for (int j = 0; j < Cfg::TN; ++j) b[j] = Bb[(kk + half) * BN + j * 32];
+            for (int j = 0; j < Cfg::TN; ++j) b[kk / 2][j] = Bb[(kk + half) * BN + j * 32];
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk)
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
                 for (int j = 0; j < Cfg::TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
         if (t + 1 < T) lstore(buf ^ 1);
         __syncthreads();
     }
