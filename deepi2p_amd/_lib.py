@@ -59,6 +59,11 @@ _SIGS = {
     "di2p_select_best": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "di2p_solver_residuals": [c_void_p] * 4 + [c_double, c_double, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "di2p_f32_to_f64": [c_void_p, c_void_p, c_ll, c_void_p],
+    "di2p_farthest_point_sampling": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "di2p_gather_points": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "di2p_project_labels": [c_void_p, c_void_p, c_int, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "di2p_label_accuracy": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "di2p_pack_pc_label": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
 }
 EXPORTS = sorted(list(_SIGS) + ["di2p_last_error", "di2p_version", "di2p_solve_workspace_bytes", "di2p_solver_set_profile_buffer"])
 

@@ -191,6 +191,30 @@ int di2p_solver_residuals(const double* points, const int32_t* labels, const dou
                           const double* params, double H, double W, int is_2d, int F, int N,
                           double* residuals, int32_t* counts, double* cost, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * "Next" rows: the steps directly before and after the classifier.
+ * di2p_farthest_point_sampling: FarthestSampler.sample of data/kitti_helper.py:224-243 (called at
+ *   data/kitti_pc_img_pose_loader.py:416-423).  pts f32[B,3,M] (M <= 4096 candidate points), init_idx i32[B] or
+ *   NULL (= 0; the reference draws randint(len(pts)) = randint(3)) -> idx i32[B,k], nodes f32[B,3,k] (may be NULL).
+ *   numpy semantics: fp64 squared distances, np.minimum update, first-occurrence argmax.
+ * di2p_gather_points: out[b,c,n] = src[b,c,idx[b,n]] -- the down-sampling of kitti_pc_img_pose_loader.py:158-171
+ *   with the host-drawn index list as an explicit input.
+ * di2p_project_labels: evaluation/visualize_and_save_data.py:100-115,138-139 (same arithmetic as
+ *   models/multimodal_classifier.py:135-156): P f32[B,p_rows(3|4),4], K f32[B,3,3] -> coarse i32[B,N] (inside-frustum,
+ *   <= W-1, z > 0.1), fine i32[B,N] = floor(px/scale) + floor(py/scale)*W_fine (may be NULL), pxpy f32[B,2,N] (may be NULL).
+ * di2p_label_accuracy: :142-145 -> out f32[B,2] = {coarse accuracy, fine accuracy over gt-inside points (NaN if none)}.
+ * di2p_pack_pc_label: the 7 x N hand-off record of :174-181 (xyz, coarse_pred, coarse_gt, fine_pred, fine_gt) as
+ *   f64[B,7,N], i.e. what np.load(..._pc_label.npy) gives evaluation/registration_lsq.py:291-296. */
+int di2p_farthest_point_sampling(const float* pts, const int32_t* init_idx, int32_t* idx_out, float* nodes_out,
+                                 int B, int M, int k, void* stream);
+int di2p_gather_points(const float* src, const int32_t* idx, float* out, int B, int C, int Nsrc, int Nout, void* stream);
+int di2p_project_labels(const float* pc, const float* P, int p_rows, const float* K, float H, float W, float fine_scale,
+                        int32_t* coarse, int32_t* fine, float* pxpy, int B, int N, void* stream);
+int di2p_label_accuracy(const int32_t* coarse_pred, const int32_t* coarse_gt, const int32_t* fine_pred,
+                        const int32_t* fine_gt, float* out, int B, int N, void* stream);
+int di2p_pack_pc_label(const float* pc, const int32_t* coarse_pred, const int32_t* coarse_gt, const int32_t* fine_pred,
+                       const int32_t* fine_gt, double* out, int B, int N, void* stream);
+
 /* f32 -> f64 widening copy of the point cloud for the solver ([B,3,N]) and i32 label passthrough
  * are done by the caller; helper for the fused pipeline: */
 int di2p_f32_to_f64(const float* in, double* out, long long n, void* stream);

@@ -7,6 +7,7 @@ where /root/reference exists):   python tests/golden/make_golden.py
                          closed-form weights of oracle/network_torch.synthetic_state_dict on seeded inputs:
                          PCEncoder 8-tuple, ImageEncoder maps, coarse+fine logits (B=2, N=1024, 64x128)
   network_coarse_golden.npz   same, coarse-only head
+  prep_golden.npz        data/kitti_helper.py FarthestSampler.sample (class extracted with ast), incl. duplicate points
   lsq_driver_golden.npz  evaluation/registration_lsq.py get_initial_guess / wrap_in_pi / get_P_diff /
                          get_inside_img_mask and data/augmentation.py angles2rotation_matrix: the function
                          DEFINITIONS are extracted from the reference files with ``ast`` and exec'd here
@@ -141,6 +142,32 @@ def make_lsq_driver():
     print("lsq_driver_golden.npz written")
 
 
+def make_prep():
+    """FarthestSampler.sample of data/kitti_helper.py, class extracted with ast (the module imports open3d)."""
+    src = open(os.path.join(REF, "data", "kitti_helper.py")).read()
+    tree = ast.parse(src)
+    ns = {"np": np}
+    np.int = int   # the reference predates numpy 1.24 (np.int removed); alias for exec only
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == "FarthestSampler":
+            exec(compile(ast.Module(body=[node], type_ignores=[]), "kitti_helper.py", "exec"), ns)
+    fs = ns["FarthestSampler"]()
+    rng = np.random.default_rng(5)
+    out = {}
+    for i, (M, k) in enumerate([(1024, 128), (300, 17), (64, 64)]):
+        pts = (rng.standard_normal((3, M)) * 20).astype(np.float32)
+        if i == 1:
+            pts[:, 100:110] = pts[:, 50:60]          # duplicated points -> exact distance ties
+        np.random.seed(100 + i)
+        init = np.random.randint(len(pts))           # what the reference would draw
+        np.random.seed(100 + i)
+        far, idx = fs.sample(pts, k)
+        out["fps%d_pts" % i], out["fps%d_k" % i], out["fps%d_init" % i] = pts, np.int32(k), np.int32(init)
+        out["fps%d_nodes" % i], out["fps%d_idx" % i] = far, idx.astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, "prep_golden.npz"), **out)
+    print("prep_golden.npz written")
+
+
 if __name__ == "__main__":
     assert rn.available(), "needs /root/reference and oracle/_ref (make -C oracle ref)"
     torch.set_num_threads(8)
@@ -148,3 +175,4 @@ if __name__ == "__main__":
     make_network(True, "network_golden.npz")
     make_network(False, "network_coarse_golden.npz")
     make_lsq_driver()
+    make_prep()
