@@ -77,12 +77,11 @@ def main():
     from deepi2p_amd import _lib, ops, synthetic
     from deepi2p_amd.networks import MMClassiferCoarse
     from deepi2p_amd.registration import RegistrationPipeline
-    from oracle import network_torch as nt   # cpu_baseline leg + closed-form weight generator only
 
     B, N, H, W, R = args.batch, args.points, 160, 512, args.restarts
-    opt = nt.OptLike(N, H, W, False)
+    opt = synthetic.OptLike(N, H, W, False)
     opt.device = dev
-    sd = nt.synthetic_state_dict(opt)
+    sd = synthetic.synthetic_state_dict(opt)
     mm = MMClassiferCoarse(opt)
     mm.detector.load_state_dict(sd)
     if world > 1:  # weights broadcast once over RCCL/xGMI (stands in for nn.DataParallel's per-step replicate)
@@ -220,9 +219,9 @@ def main():
 def pose_check(out, batch):
     """Sanity (not parity): the network has random weights, so its labels are meaningless; report only that the
     solver ran to completion on them."""
-    from oracle import frustum_lm as flm
+    from deepi2p_amd.registration import get_P_diff
     P = out["P"].cpu().numpy()
-    errs = [flm.get_P_diff(P[i], batch["P_gt"][i]) for i in range(P.shape[0])]
+    errs = [get_P_diff(P[i], batch["P_gt"][i]) for i in range(P.shape[0])]
     ok = sum(1 for t, r in errs if t < 2.0 and r < 5.0)
     return {"mean_iters": float(out["iters"].float().mean()), "frames_with_inside_points": int((out["best"] >= 0).sum()),
             "frames_within_2m_5deg_of_gt": ok, "frames": int(P.shape[0]),

@@ -68,6 +68,15 @@ def solvePGivenK(points, labels, K, init_y_angle, init_T, H, W, t_xyz_lower_boun
     return P[0].cpu().numpy(), float(fcost.item()), res[0, :n].cpu().numpy()
 
 
+def get_P_diff(P_pred_np, P_gt_np):
+    """evaluation/registration_lsq.py:87-95: RTE = |t| of P_pred^-1 P_gt, RRE = sum |euler_xzy| in degrees."""
+    from scipy.spatial.transform import Rotation
+    P_diff = np.dot(np.linalg.inv(P_pred_np), P_gt_np)
+    t_diff = np.linalg.norm(P_diff[0:3, 3])
+    angles = Rotation.from_matrix(P_diff[0:3, 0:3]).as_euler("xzy", degrees=True)
+    return t_diff, float(np.sum(np.abs(angles)))
+
+
 def wrap_in_pi(x):
     x = math.fmod(x + math.pi, math.pi * 2)
     if x < 0:

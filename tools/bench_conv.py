@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from deepi2p_amd.networks import ImageEncoder
-from oracle import network_torch as nt   # closed-form weights only
+from deepi2p_amd import synthetic as nt
 
 B = int(os.environ.get("B", 32))
 dev = torch.device("cuda", 0)
