@@ -63,9 +63,10 @@ _SIGS = {
     "di2p_gather_points": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "di2p_project_labels": [c_void_p, c_void_p, c_int, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "di2p_label_accuracy": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "di2p_pnp_ransac": [c_void_p] * 5 + [c_int, c_void_p, c_int, c_double, c_int, c_int, c_int, c_int] + [c_void_p] * 7,
     "di2p_pack_pc_label": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
 }
-EXPORTS = sorted(list(_SIGS) + ["di2p_last_error", "di2p_version", "di2p_solve_workspace_bytes", "di2p_solver_set_profile_buffer"])
+EXPORTS = sorted(list(_SIGS) + ["di2p_last_error", "di2p_version", "di2p_solve_workspace_bytes", "di2p_solver_set_profile_buffer", "di2p_pnp_workspace_bytes"])
 
 
 def load():
@@ -85,6 +86,8 @@ def load():
         lib.di2p_version.restype = c_int
         lib.di2p_solve_workspace_bytes.restype = c_ll
         lib.di2p_solve_workspace_bytes.argtypes = [c_int, c_int]
+        lib.di2p_pnp_workspace_bytes.restype = c_ll
+        lib.di2p_pnp_workspace_bytes.argtypes = [c_int, c_int, c_int]
         lib.di2p_solver_set_profile_buffer.restype = None
         lib.di2p_solver_set_profile_buffer.argtypes = [c_void_p]
         _lib = lib

@@ -215,6 +215,22 @@ int di2p_label_accuracy(const int32_t* coarse_pred, const int32_t* coarse_gt, co
 int di2p_pack_pc_label(const float* pc, const int32_t* coarse_pred, const int32_t* coarse_gt, const int32_t* fine_pred,
                        const int32_t* fine_gt, double* out, int B, int N, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * PnP back end of config 3 -- replaces cv2.solvePnPRansac as called by evaluation/registration_pnp.py:95-148
+ * (solve_PnP).  OpenCV is absent (parity unpinned): the algorithm is stated in csrc/pnp.hip and DESIGN.md.
+ *   pc f32[F,3,N], coarse i32[F,N] (1 = use the point), fine i32[F,N] (cell id: pixel = (fine % W_fine, fine / W_fine))
+ *   or explicit pixels f32[F,2,N] (then fine may be NULL), K_scaled f64[F,3,3] (already multiplied by the 1/32 scale,
+ *   camera_matrix_scaling :58-61), samples i32[F,iters,6] (RANSAC draws, taken modulo the frame's correspondence count),
+ *   reproj_err in scaled pixels (reference: 0.6); local optimisation of the best model: refine_rounds rounds of
+ *   {re-estimate inliers, refine_iters Gauss-Newton steps}, a round kept only if it loses no inliers.
+ *   -> P f64[F,4,4] (identity when rejected), outlier_ratio f64[F] (1 when rejected), n_inliers, n_corr, best i32[F].
+ *   workspace: di2p_pnp_workspace_bytes(F, N, iters). */
+long long di2p_pnp_workspace_bytes(int F, int N, int iters);
+int di2p_pnp_ransac(const float* pc, const int32_t* coarse, const int32_t* fine, const float* pixels,
+                    const double* K_scaled, int W_fine, const int32_t* samples, int iters, double reproj_err,
+                    int refine_rounds, int refine_iters, int F, int N, double* P_out, double* outlier_ratio, int32_t* n_inliers,
+                    int32_t* n_corr, int32_t* best, void* workspace, void* stream);
+
 /* f32 -> f64 widening copy of the point cloud for the solver ([B,3,N]) and i32 label passthrough
  * are done by the caller; helper for the fused pipeline: */
 int di2p_f32_to_f64(const float* in, double* out, long long n, void* stream);
