@@ -50,8 +50,8 @@ def conv_flops_per_frame(H, W):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--points", type=int, default=20480)
     ap.add_argument("--restarts", type=int, default=60)
@@ -188,8 +188,21 @@ def main():
         if "achieved" in r:
             r["frac"] = r["achieved"] / r["peak"]
     dom = roofs["conv2d_kernel(implicit-GEMM fp32 MFMA)"]
+    # HBM traffic per launch from the committed PMC passes of the same kernels on the same shapes (separate
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, profiles/r01_pmc_traffic.json); None if the file is absent
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+        if B == 32 and (H, W) == (160, 512):
+            traffic = pmc["conv2d_resnet34_B32_160x512"]["hbm_bytes_per_launch_raw"]
+            roofs["index_max_kernel"]["traffic_C64"] = pmc["index_max_C64_B32_N20480_K128"]["hbm_bytes_corrected"]
+            roofs["index_max_kernel"]["algorithmic_C64"] = pmc["index_max_C64_B32_N20480_K128"]["algorithmic_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {"kernel": "conv2d_kernel", "bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"],
-                "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None,
+                "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
+                "algorithmic_flop_per_launch": conv_flops / 36.0,
                 "note": "algorithmic 2*MAC of the 36 ResNet-34 conv launches of one step / their summed HIP-event time "
                         "(events on the launch stream, serial pass of %d steps directly after the timed region)" % prof_steps}
 
