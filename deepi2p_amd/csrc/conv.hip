@@ -83,6 +83,65 @@ struct LoaderIm2colTap {
     __device__ __forceinline__ float load(int k) const { return tile_ptr ? tile_ptr[(k & (bk - 1)) * HW] : 0.0f; }
 };
 
+// Vector stagers (16-byte loads).  Weights: 4 consecutive output channels of one k row (needs Cout % 4 == 0).
+struct LoaderWtC4 {
+    const float* Wt;
+    int K, M;
+    __device__ __forceinline__ float4 load4(int k, int m) const {
+        if (k < K && m + 3 < M) return *reinterpret_cast<const float4*>(Wt + k * M + m);
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < K) { if (m < M) v.x = Wt[k * M + m]; if (m + 1 < M) v.y = Wt[k * M + m + 1]; if (m + 2 < M) v.z = Wt[k * M + m + 2]; }
+        return v;
+    }
+};
+
+// im2col, tap-major, 4 consecutive output pixels of one output row per lane (needs OW % 4 == 0): for stride 1 they are 4
+// consecutive input floats (one dword-aligned 16-byte load; scalar only at the left/right image border), for
+// stride 2 four strided scalars.
+struct LoaderIm2colTap4 {
+    const float* x;
+    int Cin, H, W, OH, OW, KH, KW, stride, pad, K, Ntot;
+    const float* xb;
+    const float* tile_ptr;
+    int ih0, iw0, HW, iw_first;
+    int ci0, kh, kw, bk;
+    bool valid, full;
+    __device__ __forceinline__ void column4(int j) {
+        valid = j < Ntot;                      // Ntot % 4 == 0: a group is entirely valid or entirely out
+        const int jj = valid ? j : 0;
+        const int opix = OH * OW;
+        const int b = jj / opix, pix = jj - b * opix;
+        const int oh = pix / OW, ow = pix - oh * OW;
+        HW = H * W;
+        xb = x + (long long)b * Cin * HW;
+        ih0 = oh * stride - pad;
+        iw0 = ow * stride - pad;
+        ci0 = -bk; kh = 0; kw = 0;
+        tile_ptr = nullptr; full = false; iw_first = 0;
+    }
+    __device__ __forceinline__ void begin_tile(int) {
+        ci0 += bk;
+        if (ci0 >= Cin) { ci0 = 0; if (++kw == KW) { kw = 0; ++kh; } }
+        const int ih = ih0 + kh;
+        iw_first = iw0 + kw;
+        const bool row_ok = valid && kh < KH && (unsigned)ih < (unsigned)H;
+        tile_ptr = row_ok ? xb + (ci0 * H + ih) * W : nullptr;            // start of the input row of channel ci0
+        full = row_ok && stride == 1 && iw_first >= 0 && iw_first + 3 < W;
+    }
+    __device__ __forceinline__ float4 load4(int k) const {
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!tile_ptr) return v;
+        const float* r = tile_ptr + (k & (bk - 1)) * HW;
+        if (full) { const F4u t = *reinterpret_cast<const F4u*>(r + iw_first); v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w; return v; }
+        const int i0 = iw_first, i1 = iw_first + stride, i2 = iw_first + 2 * stride, i3 = iw_first + 3 * stride;
+        if ((unsigned)i0 < (unsigned)W) v.x = r[i0];
+        if ((unsigned)i1 < (unsigned)W) v.y = r[i1];
+        if ((unsigned)i2 < (unsigned)W) v.z = r[i2];
+        if ((unsigned)i3 < (unsigned)W) v.w = r[i3];
+        return v;
+    }
+};
+
 struct EpiConv {
     const float* scale;
     const float* shift;
@@ -125,6 +184,147 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv2d_kernel(const float* __res
         LoaderIm2col lb{x, Cin, H, W, OH, OW, KH, KW, stride, pad, K, Ntot, nullptr, 0, 0, false};
         mfma_gemm_block<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
     }
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::THREADS) void conv2d_vec_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
+                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                   const float* __restrict__ residual, float* __restrict__ y, int Cin,
+                                                                   int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride,
+                                                                   int pad, int Ntot, int relu) {
+    extern __shared__ float lds[];
+    const int K = Cin * KH * KW;
+    LoaderWtC4 la{Wt, K, Cout};
+    EpiConv ep{scale, shift, residual, y, Cout, OH * OW, Ntot, relu};
+    LoaderIm2colTap4 lb;
+    lb.x = x; lb.Cin = Cin; lb.H = H; lb.W = W; lb.OH = OH; lb.OW = OW; lb.KH = KH; lb.KW = KW; lb.stride = stride;
+    lb.pad = pad; lb.K = K; lb.Ntot = Ntot; lb.bk = Cfg::BK;
+    mfma_gemm_block_vec<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
+}
+
+template <class Cfg>
+void launch_conv_vec(const float* x, const float* Wt, const float* scale, const float* shift, const float* residual, float* y,
+                     int Cin, int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride, int pad, int Ntot, int relu,
+                     hipStream_t st) {
+    const dim3 grid(di2p_cdiv(Ntot, Cfg::BN), di2p_cdiv(Cout, Cfg::BM)), block(Cfg::THREADS);
+    hipLaunchKernelGGL(conv2d_vec_kernel<Cfg>, grid, block, Cfg::LDS_FLOATS * sizeof(float), st, x, Wt, scale, shift, residual, y,
+                       Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Barrier-free variant: every WAVE owns a (TM*32) x (TN*32) output tile and loads its MFMA operands straight from
+// global memory in fragment layout -- v_mfma_f32_32x32x2_f32 takes ONE dword per lane per operand (lane l: A[m0+(l&31)]
+// of row k+(l>>5), B[n0+(l&31)] of row k+(l>>5)), i.e. each operand load is two perfectly coalesced 128-byte rows, and
+// the instruction runs 64 cycles, so there is ample time to stream them through L1/L2 with a register prefetch.
+// No LDS staging and no workgroup barrier: the LDS-staged kernels above lose ~45 % of the matrix pipe to barrier
+// convoys (4 waves of a workgroup sit on 4 SIMDs, each queued behind other workgroups' waves, once per K-step).
+// The 4 waves of a workgroup cover a 2x2 (or 1x4) arrangement of neighbouring tiles so they share operand rows in L1.
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv2d_direct_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ residual, float* __restrict__ y, int Cin,
+                                                            int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride,
+                                                            int pad, int Ntot, int relu) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = (blockIdx.y * WM + wm) * TM * 32;
+    const int n0 = (blockIdx.x * WN + wn) * TN * 32;
+    if (m0 >= Cout || n0 >= Ntot) return;          // whole wave out of range (no barriers in this kernel)
+    const int HW = H * W, opix = OH * OW;
+    // per-lane output columns
+    const float* xb[TN];
+    int ih0[TN], iw0[TN];
+    bool colok[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + j * 32 + l31;
+        colok[j] = n < Ntot;
+        const int nn = colok[j] ? n : 0;
+        const int b = nn / opix, pix = nn - b * opix;
+        const int oh = pix / OW, ow = pix - oh * OW;
+        xb[j] = x + (long long)b * Cin * HW + half * HW;     // this lane's k-row parity is folded into the base
+        ih0[j] = oh * stride - pad;
+        iw0[j] = ow * stride - pad;
+    }
+    bool rowok[TM];
+    const float* wa[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + i * 32 + l31;
+        rowok[i] = m < Cout;
+        wa[i] = Wt + half * Cout + (rowok[i] ? m : 0);
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // Software pipeline over the flattened (tap, channel-batch) sequence: the operands of batch s+1 are requested
+    // before the MFMAs of batch s are issued, so their L2 latency hides under 4*TM*TN matrix instructions.
+    constexpr int U = 4;                       // k-pairs per batch (Cin % 8 == 0 is checked on the host)
+    const int cstep = 2 * U;
+    const int batches_per_tap = Cin / cstep;
+    const int nsteps = KH * KW * batches_per_tap;
+    float a0[U][TM], b0[U][TN], a1[U][TM], b1[U][TN];
+    int s_kh = 0, s_kw = 0, s_cb = 0;          // loader position (wave-uniform)
+    const float* bp[TN];
+    auto set_tap = [&]() {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ih = ih0[j] + s_kh, iw = iw0[j] + s_kw;
+            const bool ok = colok[j] && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+            bp[j] = ok ? xb[j] + ih * W + iw : nullptr;
+        }
+    };
+    auto fetch = [&](float (&a)[U][TM], float (&b)[U][TN]) {
+        const int ci = s_cb * cstep;
+        const int wrow = (s_kh * KW + s_kw) * Cin + ci;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[u][i] = rowok[i] ? wa[i][(wrow + 2 * u) * Cout] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[u][j] = bp[j] ? bp[j][(ci + 2 * u) * HW] : 0.0f;
+        }
+        if (++s_cb == batches_per_tap) { s_cb = 0; if (++s_kw == KW) { s_kw = 0; ++s_kh; } set_tap(); }
+    };
+    auto compute = [&](float (&a)[U][TM], float (&b)[U][TN]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+    };
+    set_tap();
+    fetch(a0, b0);
+    int st = 0;
+    for (; st + 2 <= nsteps; st += 2) {
+        if (st + 1 < nsteps) fetch(a1, b1);
+        compute(a0, b0);
+        if (st + 2 < nsteps) fetch(a0, b0);
+        compute(a1, b1);
+    }
+    if (st < nsteps) compute(a0, b0);
+    EpiConv ep{scale, shift, residual, y, Cout, opix, Ntot, relu};
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) ep.tile(m0 + i * 32 + 4 * half, n0 + j * 32 + l31, acc[i][j]);
+}
+
+template <int TM, int TN, int WM, int WN>
+void launch_conv_direct(const float* x, const float* Wt, const float* scale, const float* shift, const float* residual, float* y,
+                        int Cin, int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride, int pad, int Ntot, int relu,
+                        hipStream_t st) {
+    const dim3 grid(di2p_cdiv(Ntot, WN * TN * 32), di2p_cdiv(Cout, WM * TM * 32));
+    hipLaunchKernelGGL((conv2d_direct_kernel<TM, TN, WM, WN>), grid, dim3(256), 0, st, x, Wt, scale, shift, residual, y, Cin, H, W,
+                       Cout, OH, OW, KH, KW, stride, pad, Ntot, relu);
 }
 
 template <class Cfg>
@@ -218,7 +418,33 @@ extern "C" int di2p_conv2d(const float* x, const float* Wt, const float* scale, 
     else choice = 0;
     if (force >= 0) { choice = force % 10; if (choice >= 2 && Cout < 128) choice = 1; }
     const bool use32 = k32 && (force < 0 || force >= 10);
-    if (use32) {
+    // EXPERIMENT, off by default (measured slower): barrier-free direct-to-register kernels
+    // (DI2P_CONV_DIRECT=1: 64x64 per wave, 2: 32x64, 3: 32x32, 4: auto)
+    static int direct = -1;
+    if (direct < 0) { const char* e = getenv("DI2P_CONV_DIRECT"); direct = e ? atoi(e) : 0; }
+    if (direct && tap_major && Cin % 8 == 0) {
+#define DI2P_CONVD(TM, TN, WM, WN) launch_conv_direct<TM, TN, WM, WN>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, st)
+        int mode = direct;
+        if (mode == 4) {   // enough waves to fill 1024 SIMDs a few times over, biggest tile first
+            const long long w64 = (long long)di2p_cdiv(Ntot, 64) * di2p_cdiv(Cout, 64);
+            const long long w32x64 = (long long)di2p_cdiv(Ntot, 64) * di2p_cdiv(Cout, 32);
+            mode = w64 >= 3072 ? 1 : (w32x64 >= 3072 ? 2 : 3);
+        }
+        if (mode == 1) { if (Cout >= 128) DI2P_CONVD(2, 2, 2, 2); else DI2P_CONVD(2, 2, 1, 4); }
+        else if (mode == 2) DI2P_CONVD(1, 2, 2, 2);
+        else DI2P_CONVD(1, 1, 2, 2);
+#undef DI2P_CONVD
+        DI2P_RETURN_LAUNCH();
+    }
+    // vector stager: tap-major weights, 32-channel taps, whole 4-pixel groups per output row, 16-byte aligned weights
+    static int novec = -1;
+    if (novec < 0) { const char* e = getenv("DI2P_CONV_NOVEC"); novec = e ? atoi(e) : 0; }
+    const bool vec = !novec && use32 && OW % 4 == 0 && Cout % 4 == 0 && ((uintptr_t)Wt & 15) == 0;
+#define DI2P_CONVV(CFG) launch_conv_vec<CFG>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, st)
+    if (vec) {
+        switch (choice) { case 3: DI2P_CONVV(CfgC128x128k32); break; case 2: DI2P_CONVV(CfgC128x64k32); break;
+                          case 1: DI2P_CONVV(CfgC64x128k32); break; default: DI2P_CONVV(CfgC64x64k32); }
+    } else if (use32) {
         switch (choice) { case 3: DI2P_CONV(CfgC128x128k32); break; case 2: DI2P_CONV(CfgC128x64k32); break;
                           case 1: DI2P_CONV(CfgC64x128k32); break; default: DI2P_CONV(CfgC64x64k32); }
     } else {
@@ -226,6 +452,7 @@ extern "C" int di2p_conv2d(const float* x, const float* Wt, const float* scale, 
                           case 1: DI2P_CONV(CfgC64x128); break; default: DI2P_CONV(CfgC64x64); }
     }
 #undef DI2P_CONV
+#undef DI2P_CONVV
     DI2P_RETURN_LAUNCH();
 }
 

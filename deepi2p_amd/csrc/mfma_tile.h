@@ -108,3 +108,86 @@ __device__ __forceinline__ void mfma_gemm_block(float* lds, LoaderA& la, LoaderB
             epi.tile(mrow0, jcol, acc[i][j]);
         }
 }
+
+
+// ----------------------------------------------------------------------------------------------------------------
+// Vectorised variant: operands are staged with 16-byte global loads and ds_write_b128 (4 consecutive m / n per lane),
+// 4x fewer VMEM and LDS-write instructions per MFMA than the scalar stager above.  Loaders provide
+//   LoaderA: float4 load4(int k, int m)      (m % 4 == 0; out-of-range rows/cols -> 0)
+//   LoaderB: void column4(int j) (j % 4 == 0); void begin_tile(int k0); float4 load4(int k)
+struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };   // 16-byte load that only needs dword alignment
+
+template <class Cfg, class LoaderA, class LoaderB, class Epi>
+__device__ __forceinline__ void mfma_gemm_block_vec(float* lds, LoaderA& la, LoaderB& lb, Epi& epi, int K, int m_blk, int j_blk) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
+    constexpr int A_TPR = BM / 4, B_TPR = BN / 4;                       // threads per panel row
+    constexpr int A_RPP = Cfg::THREADS / A_TPR, B_RPP = Cfg::THREADS / B_TPR;
+    constexpr int A_PASSES = BK / A_RPP, B_PASSES = BK / B_RPP;
+    static_assert(BK % A_RPP == 0 && BK % B_RPP == 0 && A_PASSES >= 1 && B_PASSES >= 1, "tile too small for the vector stager");
+    float* As = lds;
+    float* Bs = lds + 2 * BK * BM;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int a_col = (tid % A_TPR) * 4, a_row0 = tid / A_TPR;
+    const int b_col = (tid % B_TPR) * 4, b_row0 = tid / B_TPR;
+    lb.column4(j_blk + b_col);
+
+    f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 ra[A_PASSES], rb[B_PASSES];
+    const int T = (K + BK - 1) / BK;
+    auto gload = [&](int t) {
+        const int k0 = t * BK;
+        lb.begin_tile(k0);
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) ra[p] = la.load4(k0 + a_row0 + p * A_RPP, m_blk + a_col);
+#pragma unroll
+        for (int p = 0; p < B_PASSES; ++p) rb[p] = lb.load4(k0 + b_row0 + p * B_RPP);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<float4*>(&As[(buf * BK + a_row0 + p * A_RPP) * BM + a_col]) = ra[p];
+#pragma unroll
+        for (int p = 0; p < B_PASSES; ++p) *reinterpret_cast<float4*>(&Bs[(buf * BK + b_row0 + p * B_RPP) * BN + b_col]) = rb[p];
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < T) gload(t + 1);
+        const float* Ab = As + buf * BK * BM + wm * Cfg::TM * 32 + l31;
+        const float* Bb = Bs + buf * BK * BN + wn * Cfg::TN * 32 + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[Cfg::TM], b[Cfg::TN];
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i) a[i] = Ab[(kk + half) * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) b[j] = Bb[(kk + half) * BN + j * 32];
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < T) lstore(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) {
+            const int jcol = j_blk + (wn * Cfg::TN + j) * 32 + l31;
+            const int mrow0 = m_blk + (wm * Cfg::TM + i) * 32 + 4 * half;
+            epi.tile(mrow0, jcol, acc[i][j]);
+        }
+}
