@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--restarts", type=int, default=60)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams = batches in flight (1 = fully serial)")
+    ap.add_argument("--priority", type=int, default=0, help="1: classifier on a high-priority stream, solves on --streams low-priority streams")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,8 +114,16 @@ def main():
     # the chip idles) is filled by the next batches' kernels.  Each step is still one full batch through the whole
     # path on its own stream, and all K steps complete inside the timed region.
     n_streams = max(1, args.streams)
-    streams = [torch.cuda.Stream() for _ in range(n_streams)]
     overlap = n_streams > 1
+    prio = args.priority and overlap
+    if prio:
+        # one HIGH-priority stream for the classifier (short MFMA kernels) running ahead, S low-priority streams for
+        # the pose solves: network workgroups are dispatched first whenever a CU frees up, the long fp64 solver
+        # workgroups fill the rest and overlap each other's tails
+        s_net = torch.cuda.Stream(priority=-1)
+        streams = [torch.cuda.Stream(priority=0) for _ in range(n_streams)]
+    else:
+        streams = [torch.cuda.Stream() for _ in range(n_streams)]
     step_no = [0]
 
     def step():
@@ -125,9 +134,19 @@ def main():
             return o
         st = streams[step_no[0] % n_streams]
         step_no[0] += 1
-        with torch.cuda.stream(st):
-            pred = mm.inference_labels()
-            o = pipe(mm.pc, solver_labels, K64, restarts)   # same stream: the pose solve of a batch follows its classification
+        if prio:
+            with torch.cuda.stream(s_net):
+                pred = mm.inference_labels()
+                ev = torch.cuda.Event()
+                ev.record()
+            with torch.cuda.stream(st):
+                st.wait_event(ev)                          # the pose solve of a batch follows its classification
+                o = pipe(mm.pc, solver_labels, K64, restarts)
+                pred.record_stream(st)
+        else:
+            with torch.cuda.stream(st):
+                pred = mm.inference_labels()
+                o = pipe(mm.pc, solver_labels, K64, restarts)   # same stream: the pose solve of a batch follows its classification
         o["pred"] = pred
         return o
 
@@ -220,7 +239,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: KITTI 20480-pt / 160x512, batch %d per GPU, coarse classification "
                                    "+ %d-restart 2D GN/LM solver, max_iter 500" % (B, R),
                        "frames_per_gpu_per_step": B, "points": N, "image": [H, W], "restarts": R, "parallelism": "dp%d" % world,
-                       "streams": n_streams},
+                       "streams": n_streams, "priority_streams": bool(prio)},
             "roofline": roofline, "kernels": roofs, "cpu_baseline": cpu_baseline,
             "pose_check": pose_check(out, batch),
         }

@@ -98,36 +98,43 @@ template <> struct __attribute__((aligned(16))) Rec<double> { double x, y, z; lo
 template <typename PT>
 __global__ __launch_bounds__(256) void pack_kernel(const PT* __restrict__ points, const int* __restrict__ labels, int N,
                                                    Rec<PT>* __restrict__ packed, int* __restrict__ counts) {
-    __shared__ int s_scan[256];
-    __shared__ int s_base;
+    __shared__ int s_scan1[256], s_scan0[256];
+    __shared__ int s_base1, s_base0, s_n1;
     const int f = blockIdx.x, tid = threadIdx.x;
     const PT* px = points + (long long)f * 3 * N;
     const int* lab = labels + (long long)f * N;
     Rec<PT>* out = packed + (long long)f * N;
-    if (tid == 0) s_base = 0;
+    // pass 1: number of label-1 records (they are stored first so that every 64-record step of a sweep and every
+    // phase-B batch holds ONE label: no label divergence in the hot loops)
+    int c1 = 0;
+    for (int n = tid; n < N; n += 256) c1 += lab[n] == 1;
+    s_scan1[tid] = c1;
     __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_scan1[tid] += s_scan1[tid + o]; __syncthreads(); }
+    if (tid == 0) { s_n1 = s_scan1[0]; s_base1 = 0; s_base0 = 0; }
+    __syncthreads();
+    const int n1 = s_n1;
     for (int n0 = 0; n0 < N; n0 += 256) {
         const int n = n0 + tid;
         const int l = n < N ? lab[n] : -1;
-        const int keep = (l == 0 || l == 1) ? 1 : 0;
-        s_scan[tid] = keep;
+        s_scan1[tid] = l == 1; s_scan0[tid] = l == 0;
         __syncthreads();
         for (int o = 1; o < 256; o <<= 1) {
-            const int v = tid >= o ? s_scan[tid - o] : 0;
+            const int v1 = tid >= o ? s_scan1[tid - o] : 0, v0 = tid >= o ? s_scan0[tid - o] : 0;
             __syncthreads();
-            s_scan[tid] += v;
+            s_scan1[tid] += v1; s_scan0[tid] += v0;
             __syncthreads();
         }
-        if (keep) {
+        if (l == 0 || l == 1) {
             Rec<PT> r;
             r.x = px[n]; r.y = px[N + n]; r.z = px[2 * (long long)N + n]; r.lab = l;
-            out[s_base + s_scan[tid] - 1] = r;
+            out[l == 1 ? s_base1 + s_scan1[tid] - 1 : n1 + s_base0 + s_scan0[tid] - 1] = r;
         }
         __syncthreads();
-        if (tid == 255) s_base += s_scan[255];
+        if (tid == 255) { s_base1 += s_scan1[255]; s_base0 += s_scan0[255]; }
         __syncthreads();
     }
-    if (tid == 0) counts[f] = s_base;
+    if (tid == 0) { counts[2 * f] = n1; counts[2 * f + 1] = s_base0; }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -169,7 +176,7 @@ __device__ __forceinline__ void project(const Rec<PT>& rc, const Rot<NP>& rot, d
     pix_y = p1 * k.fy * iz + k.cy;
 }
 
-template <int NP, typename PT>
+template <int NP, typename PT, int LAB>
 __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& rot, const double* x, const Cam& k, double& cost,
                                             double* lg, double* lA, bool& bad) {
     constexpr int TOFF = NP == 4 ? 1 : 3;
@@ -179,7 +186,7 @@ __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& ro
     // residual rows as (value, d/dpix_x, d/dpix_y, d/dp2 direct) -- at most 3 rows
     double rv[3], sx[3], sy[3], sz[3];
     int nr;
-    if ((int)rc.lab == 1) {
+    if (LAB == 1) {
         nr = 3;
         const double a0 = -pix_x, b0 = pix_x - k.W1;
         rv[0] = (a0 < 0.0 ? 0.0 : a0) + (b0 < 0.0 ? 0.0 : b0);
@@ -198,10 +205,10 @@ __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& ro
         sx[0] = ex < 0.0 ? 1.0 : -1.0;
         sy[0] = ey < 0.0 ? 1.0 : -1.0;
         sz[0] = 0.0;
-        rv[1] = rv[2] = 0.0; sx[1] = sx[2] = sy[1] = sy[2] = sz[1] = sz[2] = 0.0;
     }
     double s = 0.0;
-    for (int i = 0; i < nr; ++i) s += rv[i] * rv[i];
+#pragma unroll
+    for (int i = 0; i < (LAB == 1 ? 3 : 1); ++i) s += rv[i] * rv[i];
     if (!isfinite(s)) bad = true;
     if (s > 0.0) cost += 0.5 * log1p(s);
     const double rho1 = 1.0 / (1.0 + s);
@@ -221,8 +228,9 @@ __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& ro
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) { dp0[TOFF + i] = i == 0 ? 1.0 : 0.0; dp1[TOFF + i] = i == 1 ? 1.0 : 0.0; dp2[TOFF + i] = i == 2 ? 1.0 : 0.0; }
-    for (int i = 0; i < nr; ++i) {
-        if (sx[i] == 0.0 && sy[i] == 0.0 && sz[i] == 0.0) continue;
+#pragma unroll
+    for (int i = 0; i < (LAB == 1 ? 3 : 1); ++i) {
+        if (LAB == 1 && sx[i] == 0.0 && sy[i] == 0.0 && sz[i] == 0.0) continue;
         double J[NP];
 #pragma unroll
         for (int a = 0; a < NP; ++a) {
@@ -242,31 +250,19 @@ __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& ro
     }
 }
 
-// Leaves the 4 wave partials {cost, g[NP], A[tri], bad} in sh.red[wave][*]; the caller combines them after a
-// barrier.  Records are prefetched one batch (U per lane) ahead so a batch's arithmetic covers the next
-// batch's L2/HBM latency.
-template <int NP, typename PT, int WPH, int U>   // U = records per lane per batch
-__device__ __forceinline__ int sweep(const Rec<PT>* __restrict__ recs, int cnt, const Cam& k, const double* x,
-                                     SweepShared<NP, WPH>& sh) {
+// One label-uniform range of records [recs, recs+cnt): phase A (exact fp64 classification), wave-level compaction of
+// the active ids, dense phase B.  LAB is a compile-time constant: no label test and no label divergence anywhere.
+template <int NP, typename PT, int WPH, int U, int LAB>
+__device__ __forceinline__ void sweep_range(const Rec<PT>* __restrict__ recs, int cnt, const Cam& k, const double* x,
+                                            const Rot<NP>& rot, int* queue, double& cost, double* lg, double* lA, bool& bad,
+                                            int& n_active) {
     constexpr int TOFF = NP == 4 ? 1 : 3;
-    constexpr int NV = Tri<NP>::N + NP + 2;
-    Rot<NP> rot;
-    make_rot<NP>(x, rot);
     const double tx = x[TOFF], ty = x[TOFF + 1], tz = x[TOFF + 2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    int* queue = sh.queue[wave];
-    int qn = 0;  // wave-uniform
-    int n_active = 0;
-    double cost = 0.0;
-    double lg[NP], lA[Tri<NP>::N];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) lg[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < Tri<NP>::N; ++i) lA[i] = 0.0;
-    bool bad = false;
     const double hw = k.W1 * 0.5, hh = k.H1 * 0.5;
     constexpr int span = WPH * 64 * U;
+    int qn = 0;  // wave-uniform
     Rec<PT> nxt[U];
     auto fetch = [&](int base) {
 #pragma unroll
@@ -275,7 +271,7 @@ __device__ __forceinline__ int sweep(const Rec<PT>* __restrict__ recs, int cnt, 
             if (n < cnt) nxt[u] = recs[n]; else { nxt[u].x = 0; nxt[u].y = 0; nxt[u].z = 1; nxt[u].lab = -1; }
         }
     };
-    fetch(0);
+    if (cnt > 0) fetch(0);
     for (int base = 0; base < cnt; base += span) {
         Rec<PT> rec[U];
 #pragma unroll
@@ -283,19 +279,19 @@ __device__ __forceinline__ int sweep(const Rec<PT>* __restrict__ recs, int cnt, 
         if (base + span < cnt) fetch(base + span);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int lab = (int)rec[u].lab;
             double X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y;
             project<NP, PT>(rec[u], rot, tx, ty, tz, k, X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y);
-            bool act = false;
-            if (lab == 1) {
+            bool act;
+            if (LAB == 1) {
                 act = !(-pix_x < 0.0) || !(pix_x - k.W1 < 0.0) || !(-pix_y < 0.0) || !(pix_y - k.H1 < 0.0) || !(-p2 < 0.0);
-            } else if (lab == 0) {
+            } else {
                 const double dx = hw - fabs(pix_x - hw), dy = hh - fabs(pix_y - hh);
                 // fmax(v,0)/v is NaN at v == 0 (registration_2d.hpp:53,56,58): evaluation failure
                 if (dx == 0.0 || dy == 0.0 || p2 == 0.0) bad = true;
                 if (!isfinite(pix_x) || !isfinite(pix_y)) bad = true;
                 act = dx > 0.0 && dy > 0.0 && p2 > 0.0;
             }
+            act = act && (int)rec[u].lab >= 0;          // padding lanes of the last batch
             const unsigned long long bal = __ballot(act);
             if (act) queue[qn + __popcll(bal & lt)] = base + u * (WPH * 64) + tid;
             qn += __popcll(bal);
@@ -313,9 +309,32 @@ __device__ __forceinline__ int sweep(const Rec<PT>* __restrict__ recs, int cnt, 
             n_active += qn > 64 ? 64 : qn;
             qn = qn > 64 ? qn - 64 : 0;
             __builtin_amdgcn_wave_barrier();
-            if (n >= 0) eval_active<NP, PT>(recs[n], rot, x, k, cost, lg, lA, bad);
+            if (n >= 0) eval_active<NP, PT, LAB>(recs[n], rot, x, k, cost, lg, lA, bad);
         }
     }
+}
+
+// Leaves the WPH wave partials {cost, g[NP], A[tri], bad} in sh.red[wave][*]; the caller combines them after a
+// barrier.  Records are sorted by label (pack_kernel): the label-1 block and the label-0 block are swept by two
+// specialised loops; records are prefetched one batch (U per lane) ahead.
+template <int NP, typename PT, int WPH, int U>
+__device__ __forceinline__ int sweep(const Rec<PT>* __restrict__ recs, int cnt1, int cnt0, const Cam& k, const double* x,
+                                     SweepShared<NP, WPH>& sh) {
+    constexpr int NV = Tri<NP>::N + NP + 2;
+    Rot<NP> rot;
+    make_rot<NP>(x, rot);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int* queue = sh.queue[wave];
+    int n_active = 0;
+    double cost = 0.0;
+    double lg[NP], lA[Tri<NP>::N];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) lg[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < Tri<NP>::N; ++i) lA[i] = 0.0;
+    bool bad = false;
+    sweep_range<NP, PT, WPH, U, 1>(recs, cnt1, k, x, rot, queue, cost, lg, lA, bad, n_active);
+    sweep_range<NP, PT, WPH, U, 0>(recs + cnt1, cnt0, k, x, rot, queue, cost, lg, lA, bad, n_active);
 
     double* mine = sh.red[wave];
     double v = wave_sum(cost);
@@ -534,7 +553,7 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
     __shared__ SweepShared<NP, WPH> sh;
     __shared__ LMState<NP> st;
     const Rec<PT>* recs = packed + (long long)f * N;
-    const int cnt = counts[f];
+    const int cnt1 = counts[2 * f], cnt0 = counts[2 * f + 1];
     const double* Kf = Kmat + (long long)f * 9;
     const Cam k{Kf[0], Kf[4], Kf[2], Kf[5], H - 1.0, W - 1.0};
     const long long hr = (long long)f * R + r;
@@ -556,7 +575,7 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
 #pragma unroll
         for (int i = 0; i < NP; ++i) xe[i] = st.xe[i];
         const long long t0 = prof ? clock64() : 0;
-        n_act += sweep<NP, PT, WPH, U>(recs, cnt, k, xe, sh);
+        n_act += sweep<NP, PT, WPH, U>(recs, cnt1, cnt0, k, xe, sh);
         const long long t1 = prof ? clock64() : 0;
         __syncthreads();
         const long long t2 = prof ? clock64() : 0;
@@ -764,7 +783,7 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
     Bounds b;
     for (int i = 0; i < 3; ++i) { b.lb[i] = lb[i]; b.ub[i] = ub[i]; }
     int* counts = (int*)workspace;
-    Rec<PT>* packed = (Rec<PT>*)((char*)workspace + (((size_t)F * sizeof(int) + 255) & ~(size_t)255));
+    Rec<PT>* packed = (Rec<PT>*)((char*)workspace + (((size_t)F * 2 * sizeof(int) + 255) & ~(size_t)255));
     hipLaunchKernelGGL(pack_kernel<PT>, dim3(F), dim3(256), 0, st, points, labels, N, packed, counts);
     // DI2P_SOLVER_CFG=<waves per hypothesis><records per lane per batch><min waves/SIMD>, e.g. 443 (default)
     static int cfg = -1;
@@ -841,7 +860,7 @@ extern "C" int di2p_solver_residuals(const double* points, const int32_t* labels
 }
 
 extern "C" long long di2p_solve_workspace_bytes(int F, int N) {
-    return (((long long)F * 4 + 255) & ~255ll) + (long long)F * N * 32 + 256;
+    return (((long long)F * 8 + 255) & ~255ll) + (long long)F * N * 32 + 256;
 }
 
 // Diagnostics: when set to a device buffer of F*R*4 int64, every solve launch records per hypothesis the shader-clock
