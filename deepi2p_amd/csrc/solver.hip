@@ -157,7 +157,16 @@ struct SweepShared {
     int queue[WPH][QCAP];
 };
 
-template <int NP, typename PT>
+// v_rcp_f64 + two Newton steps: <= 1 ulp for finite non-zero inputs; 0 / inf / NaN give inf / 0 / NaN-like values that the
+// callers' finiteness tests catch.  ~5 instructions instead of the ~15 of the IEEE division sequence.
+__device__ __forceinline__ double fast_rcp(double v) {
+    double r = __builtin_amdgcn_rcp(v);
+    r = fma(fma(-v, r, 1.0), r, r);
+    r = fma(fma(-v, r, 1.0), r, r);
+    return r;
+}
+
+template <int NP, typename PT, bool FAST_RCP = false>
 __device__ __forceinline__ void project(const Rec<PT>& rc, const Rot<NP>& rot, double tx, double ty, double tz, const Cam& k,
                                         double& X, double& Y, double& Z, double& qx, double& qz, double& p0, double& p1,
                                         double& p2, double& iz, double& pix_x, double& pix_y) {
@@ -171,7 +180,7 @@ __device__ __forceinline__ void project(const Rec<PT>& rc, const Rot<NP>& rot, d
         qz = rot.R[6] * X + rot.R[7] * Y + rot.R[8] * Z;
     }
     p0 = qx + tx; p1 = qy + ty; p2 = qz + tz;
-    iz = 1.0 / p2;                                   // the one fp64 division per record
+    iz = FAST_RCP ? fast_rcp(p2) : 1.0 / p2;          // the one reciprocal per record
     pix_x = p0 * k.fx * iz + k.cx;
     pix_y = p1 * k.fy * iz + k.cy;
 }
@@ -181,7 +190,7 @@ __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& ro
                                             double* lg, double* lA, bool& bad) {
     constexpr int TOFF = NP == 4 ? 1 : 3;
     double X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y;
-    project<NP, PT>(rc, rot, x[TOFF], x[TOFF + 1], x[TOFF + 2], k, X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y);
+    project<NP, PT, true>(rc, rot, x[TOFF], x[TOFF + 1], x[TOFF + 2], k, X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y);
     const double hw = k.W1 * 0.5, hh = k.H1 * 0.5;
     // residual rows as (value, d/dpix_x, d/dpix_y, d/dp2 direct) -- at most 3 rows
     double rv[3], sx[3], sy[3], sz[3];
@@ -210,8 +219,9 @@ __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& ro
 #pragma unroll
     for (int i = 0; i < (LAB == 1 ? 3 : 1); ++i) s += rv[i] * rv[i];
     if (!isfinite(s)) bad = true;
-    if (s > 0.0) cost += 0.5 * log1p(s);
-    const double rho1 = 1.0 / (1.0 + s);
+    const double s1 = 1.0 + s;
+    if (s > 0.0) cost += 0.5 * log(s1);          // rho(s) = log(1+s); absolute error <= 1 ulp(1) per block
+    const double rho1 = fast_rcp(s1);
     const double ax = k.fx * iz, bx = -k.fx * p0 * iz * iz;   // dpix_x = ax*dp0 + bx*dp2
     const double ay = k.fy * iz, by = -k.fy * p1 * iz * iz;   // dpix_y = ay*dp1 + by*dp2
     double dp0[NP], dp1[NP], dp2[NP];
@@ -234,9 +244,11 @@ __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& ro
         double J[NP];
 #pragma unroll
         for (int a = 0; a < NP; ++a) {
-            const double dpx = ax * dp0[a] + bx * dp2[a];
-            const double dpy = ay * dp1[a] + by * dp2[a];
-            J[a] = sx[i] * dpx + sy[i] * dpy + sz[i] * dp2[a];
+            if (LAB == 1) {          // row 0 depends on pix_x only, row 1 on pix_y, row 2 on p2
+                J[a] = i == 0 ? sx[0] * (ax * dp0[a] + bx * dp2[a]) : (i == 1 ? sy[1] * (ay * dp1[a] + by * dp2[a]) : sz[2] * dp2[a]);
+            } else {
+                J[a] = sx[0] * (ax * dp0[a] + bx * dp2[a]) + sy[0] * (ay * dp1[a] + by * dp2[a]);
+            }
             if (!isfinite(J[a])) bad = true;
         }
         const double wr = rho1 * rv[i];
@@ -280,15 +292,16 @@ __device__ __forceinline__ void sweep_range(const Rec<PT>* __restrict__ recs, in
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             double X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y;
-            project<NP, PT>(rec[u], rot, tx, ty, tz, k, X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y);
+            project<NP, PT, true>(rec[u], rot, tx, ty, tz, k, X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y);
             bool act;
             if (LAB == 1) {
                 act = !(-pix_x < 0.0) || !(pix_x - k.W1 < 0.0) || !(-pix_y < 0.0) || !(pix_y - k.H1 < 0.0) || !(-p2 < 0.0);
             } else {
                 const double dx = hw - fabs(pix_x - hw), dy = hh - fabs(pix_y - hh);
-                // fmax(v,0)/v is NaN at v == 0 (registration_2d.hpp:53,56,58): evaluation failure
-                if (dx == 0.0 || dy == 0.0 || p2 == 0.0) bad = true;
-                if (!isfinite(pix_x) || !isfinite(pix_y)) bad = true;
+                // fmax(v,0)/v is NaN at v == 0 (registration_2d.hpp:53,56,58), and a non-finite pixel poisons the
+                // residual: evaluation failure.  One test: dx*dy*p2 is 0 or non-finite exactly in those cases.
+                const double chk = dx * dy * p2;
+                if (!(fabs(chk) > 0.0) || !(fabs(chk) < __builtin_inf())) bad = true;
                 act = dx > 0.0 && dy > 0.0 && p2 > 0.0;
             }
             act = act && (int)rec[u].lab >= 0;          // padding lanes of the last batch
