@@ -83,65 +83,78 @@ struct LoaderIm2colTap {
     __device__ __forceinline__ float load(int k) const { return tile_ptr ? tile_ptr[(k & (bk - 1)) * HW] : 0.0f; }
 };
 
-// Vector stagers (16-byte loads).  Weights: 4 consecutive output channels of one k row (needs Cout % 4 == 0).
-struct LoaderWtC4 {
-    const float* Wt;
-    int K, M;
-    __device__ __forceinline__ float4 load4(int k, int m) const {
-        if (k < K && m + 3 < M) return *reinterpret_cast<const float4*>(Wt + k * M + m);
-        float4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k < K) { if (m < M) v.x = Wt[k * M + m]; if (m + 1 < M) v.y = Wt[k * M + m + 1]; if (m + 2 < M) v.z = Wt[k * M + m + 2]; }
-        return v;
-    }
-};
-
-// im2col, tap-major, 4 consecutive output pixels of one output row per lane (needs OW % 4 == 0): for stride 1 they are 4
-// consecutive input floats (one dword-aligned 16-byte load; scalar only at the left/right image border), for
-// stride 2 four strided scalars.
+// Vector stager (16-byte loads), tap-major weights.  Four consecutive output pixels of one output row per lane
+// (OW % 4 == 0).  All loads are UNCONDITIONAL from clamped addresses -- no control flow in the K-loop, so the loads of
+// K-step t+1 stay in flight under the MFMAs of step t -- and padding is applied by fix() at LDS-store time:
+//   stride 1 (pad <= 1): ONE dword-aligned 16-byte load from the 4-float window clamped into the input row; at the
+//             left/right image border the window is off by one, fix() shifts the components and zeroes the pad;
+//   stride 2: four scalar loads at clamped columns, fix() zeroes the out-of-range ones.
+// A row outside the image is read from the clamped row and zeroed as a whole.
+template <int STRIDE>
 struct LoaderIm2colTap4 {
     const float* x;
-    int Cin, H, W, OH, OW, KH, KW, stride, pad, K, Ntot;
+    int Cin, H, W, OH, OW, KH, KW, pad, Ntot;
     const float* xb;
-    const float* tile_ptr;
-    int ih0, iw0, HW, iw_first;
+    const float* tile_ptr;   // channel ci0 of the (clamped) input row, at the clamped first column (stride 1) / column 0 (stride 2)
+    int ih0, iw0, HW;
     int ci0, kh, kw, bk;
-    bool valid, full;
+    int c0, c1, c2, c3;      // stride 2: clamped columns
+    int shift;               // stride 1: wanted first column - clamped first column, in {-1, 0, +1}
+    unsigned okmask;         // bit i: element i is inside the image
     __device__ __forceinline__ void column4(int j) {
-        valid = j < Ntot;                      // Ntot % 4 == 0: a group is entirely valid or entirely out
-        const int jj = valid ? j : 0;
+        const int jj = j < Ntot ? j : 0;       // out-of-range groups compute garbage that the epilogue drops
         const int opix = OH * OW;
         const int b = jj / opix, pix = jj - b * opix;
         const int oh = pix / OW, ow = pix - oh * OW;
         HW = H * W;
         xb = x + (long long)b * Cin * HW;
-        ih0 = oh * stride - pad;
-        iw0 = ow * stride - pad;
+        ih0 = oh * STRIDE - pad;
+        iw0 = ow * STRIDE - pad;
         ci0 = -bk; kh = 0; kw = 0;
-        tile_ptr = nullptr; full = false; iw_first = 0;
+        tile_ptr = xb; shift = 0; okmask = 0; c0 = c1 = c2 = c3 = 0;
     }
     __device__ __forceinline__ void begin_tile(int) {
         ci0 += bk;
         if (ci0 >= Cin) { ci0 = 0; if (++kw == KW) { kw = 0; ++kh; } }
-        const int ih = ih0 + kh;
-        iw_first = iw0 + kw;
-        const bool row_ok = valid && kh < KH && (unsigned)ih < (unsigned)H;
-        tile_ptr = row_ok ? xb + (ci0 * H + ih) * W : nullptr;            // start of the input row of channel ci0
-        full = row_ok && stride == 1 && iw_first >= 0 && iw_first + 3 < W;
+        const int ih = ih0 + kh, iw = iw0 + kw;
+        const bool row_ok = (unsigned)ih < (unsigned)H;
+        const int ihc = min(max(ih, 0), H - 1);
+        const float* row = xb + (ci0 * H + ihc) * W;
+        if (STRIDE == 1) {
+            const int cs = min(max(iw, 0), W - 4);
+            shift = iw - cs;
+            tile_ptr = row + cs;
+            okmask = row_ok ? 0xfu : 0u;
+        } else {
+            c0 = min(max(iw, 0), W - 1); c1 = min(max(iw + STRIDE, 0), W - 1);
+            c2 = min(max(iw + 2 * STRIDE, 0), W - 1); c3 = min(max(iw + 3 * STRIDE, 0), W - 1);
+            tile_ptr = row;
+            okmask = !row_ok ? 0u : ((unsigned)iw < (unsigned)W ? 1u : 0u) | ((unsigned)(iw + STRIDE) < (unsigned)W ? 2u : 0u) |
+                                    ((unsigned)(iw + 2 * STRIDE) < (unsigned)W ? 4u : 0u) | ((unsigned)(iw + 3 * STRIDE) < (unsigned)W ? 8u : 0u);
+        }
     }
     __device__ __forceinline__ float4 load4(int k) const {
-        float4 v = {0.f, 0.f, 0.f, 0.f};
-        if (!tile_ptr) return v;
         const float* r = tile_ptr + (k & (bk - 1)) * HW;
-        if (full) { const F4u t = *reinterpret_cast<const F4u*>(r + iw_first); v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w; return v; }
-        const int i0 = iw_first, i1 = iw_first + stride, i2 = iw_first + 2 * stride, i3 = iw_first + 3 * stride;
-        if ((unsigned)i0 < (unsigned)W) v.x = r[i0];
-        if ((unsigned)i1 < (unsigned)W) v.y = r[i1];
-        if ((unsigned)i2 < (unsigned)W) v.z = r[i2];
-        if ((unsigned)i3 < (unsigned)W) v.w = r[i3];
-        return v;
+        if (STRIDE == 1) { const F4u t = *reinterpret_cast<const F4u*>(r); return make_float4(t.x, t.y, t.z, t.w); }
+        return make_float4(r[c0], r[c1], r[c2], r[c3]);
+    }
+    __device__ __forceinline__ void fix(float4& v, int) const {
+        if (STRIDE == 1) {
+            const float4 t = v;
+            const bool l = shift < 0, r = shift > 0, ok = okmask != 0;
+            v.x = !ok || l ? 0.0f : (r ? t.y : t.x);
+            v.y = !ok ? 0.0f : (l ? t.x : (r ? t.z : t.y));
+            v.z = !ok ? 0.0f : (l ? t.y : (r ? t.w : t.z));
+            v.w = !ok || r ? 0.0f : (l ? t.z : t.w);
+        } else {
+            v.x = (okmask & 1u) ? v.x : 0.0f; v.y = (okmask & 2u) ? v.y : 0.0f;
+            v.z = (okmask & 4u) ? v.z : 0.0f; v.w = (okmask & 8u) ? v.w : 0.0f;
+        }
     }
 };
 
+// BN(eval) + residual + ReLU.  Per-row operands and the residual are fetched first (clamped addresses, independent
+// loads), arithmetic and stores follow: no load -> wait -> store chain per accumulator register.
 struct EpiConv {
     const float* scale;
     const float* shift;
@@ -149,18 +162,34 @@ struct EpiConv {
     float* y;
     int Cout, opix, Ntot, relu;
     __device__ __forceinline__ void tile(int mrow0, int j, const f32x16& acc) {
-        if (j >= Ntot) return;
-        const int b = j / opix, pix = j - b * opix;
+        const bool col_ok = j < Ntot;
+        const int jj = col_ok ? j : 0;
+        const int b = jj / opix, pix = jj - b * opix;
+        const long long o0 = (long long)b * Cout * opix + pix;
+        float sc[16], sh[16], v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mc = min(mrow0 + (r & 3) + 8 * (r >> 2), Cout - 1);
+            sc[r] = scale[mc];
+            sh[r] = shift[mc];
+        }
+        if (residual) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = residual[o0 + (long long)min(mrow0 + (r & 3) + 8 * (r >> 2), Cout - 1) * opix];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += acc[r] * sc[r] + sh[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[r] * sc[r] + sh[r];
+        }
+        if (relu) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = mrow0 + (r & 3) + 8 * (r >> 2);
-            if (m < Cout) {
-                const long long o = ((long long)b * Cout + m) * opix + pix;
-                float v = acc[r] * scale[m] + shift[m];
-                if (residual) v += residual[o];
-                if (relu) v = fmaxf(v, 0.0f);
-                y[o] = v;
-            }
+            if (col_ok && m < Cout) y[o0 + (long long)m * opix] = v[r];
         }
     }
 };
@@ -186,19 +215,19 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv2d_kernel(const float* __res
     }
 }
 
-template <class Cfg>
+template <class Cfg, int STRIDE>
 __global__ __launch_bounds__(Cfg::THREADS) void conv2d_vec_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    const float* __restrict__ residual, float* __restrict__ y, int Cin,
-                                                                   int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride,
-                                                                   int pad, int Ntot, int relu) {
-    extern __shared__ float lds[];
+                                                                   int H, int W, int Cout, int OH, int OW, int KH, int KW, int pad,
+                                                                   int Ntot, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int K = Cin * KH * KW;
-    LoaderWtC4 la{Wt, K, Cout};
+    LoaderWt4 la{Wt, K, Cout};
     EpiConv ep{scale, shift, residual, y, Cout, OH * OW, Ntot, relu};
-    LoaderIm2colTap4 lb;
-    lb.x = x; lb.Cin = Cin; lb.H = H; lb.W = W; lb.OH = OH; lb.OW = OW; lb.KH = KH; lb.KW = KW; lb.stride = stride;
-    lb.pad = pad; lb.K = K; lb.Ntot = Ntot; lb.bk = Cfg::BK;
+    LoaderIm2colTap4<STRIDE> lb;
+    lb.x = x; lb.Cin = Cin; lb.H = H; lb.W = W; lb.OH = OH; lb.OW = OW; lb.KH = KH; lb.KW = KW;
+    lb.pad = pad; lb.Ntot = Ntot; lb.bk = Cfg::BK;
     mfma_gemm_block_vec<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
 }
 
@@ -207,124 +236,13 @@ void launch_conv_vec(const float* x, const float* Wt, const float* scale, const 
                      int Cin, int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride, int pad, int Ntot, int relu,
                      hipStream_t st) {
     const dim3 grid(di2p_cdiv(Ntot, Cfg::BN), di2p_cdiv(Cout, Cfg::BM)), block(Cfg::THREADS);
-    hipLaunchKernelGGL(conv2d_vec_kernel<Cfg>, grid, block, Cfg::LDS_FLOATS * sizeof(float), st, x, Wt, scale, shift, residual, y,
-                       Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu);
-}
-
-// ----------------------------------------------------------------------------------------------------------------
-// Barrier-free variant: every WAVE owns a (TM*32) x (TN*32) output tile and loads its MFMA operands straight from
-// global memory in fragment layout -- v_mfma_f32_32x32x2_f32 takes ONE dword per lane per operand (lane l: A[m0+(l&31)]
-// of row k+(l>>5), B[n0+(l&31)] of row k+(l>>5)), i.e. each operand load is two perfectly coalesced 128-byte rows, and
-// the instruction runs 64 cycles, so there is ample time to stream them through L1/L2 with a register prefetch.
-// No LDS staging and no workgroup barrier: the LDS-staged kernels above lose ~45 % of the matrix pipe to barrier
-// convoys (4 waves of a workgroup sit on 4 SIMDs, each queued behind other workgroups' waves, once per K-step).
-// The 4 waves of a workgroup cover a 2x2 (or 1x4) arrangement of neighbouring tiles so they share operand rows in L1.
-template <int TM, int TN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv2d_direct_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
-                                                            const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            const float* __restrict__ residual, float* __restrict__ y, int Cin,
-                                                            int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride,
-                                                            int pad, int Ntot, int relu) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
-    const int m0 = (blockIdx.y * WM + wm) * TM * 32;
-    const int n0 = (blockIdx.x * WN + wn) * TN * 32;
-    if (m0 >= Cout || n0 >= Ntot) return;          // whole wave out of range (no barriers in this kernel)
-    const int HW = H * W, opix = OH * OW;
-    // per-lane output columns
-    const float* xb[TN];
-    int ih0[TN], iw0[TN];
-    bool colok[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + j * 32 + l31;
-        colok[j] = n < Ntot;
-        const int nn = colok[j] ? n : 0;
-        const int b = nn / opix, pix = nn - b * opix;
-        const int oh = pix / OW, ow = pix - oh * OW;
-        xb[j] = x + (long long)b * Cin * HW + half * HW;     // this lane's k-row parity is folded into the base
-        ih0[j] = oh * stride - pad;
-        iw0[j] = ow * stride - pad;
-    }
-    bool rowok[TM];
-    const float* wa[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + i * 32 + l31;
-        rowok[i] = m < Cout;
-        wa[i] = Wt + half * Cout + (rowok[i] ? m : 0);
-    }
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    // Software pipeline over the flattened (tap, channel-batch) sequence: the operands of batch s+1 are requested
-    // before the MFMAs of batch s are issued, so their L2 latency hides under 4*TM*TN matrix instructions.
-    constexpr int U = 4;                       // k-pairs per batch (Cin % 8 == 0 is checked on the host)
-    const int cstep = 2 * U;
-    const int batches_per_tap = Cin / cstep;
-    const int nsteps = KH * KW * batches_per_tap;
-    float a0[U][TM], b0[U][TN], a1[U][TM], b1[U][TN];
-    int s_kh = 0, s_kw = 0, s_cb = 0;          // loader position (wave-uniform)
-    const float* bp[TN];
-    auto set_tap = [&]() {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int ih = ih0[j] + s_kh, iw = iw0[j] + s_kw;
-            const bool ok = colok[j] && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-            bp[j] = ok ? xb[j] + ih * W + iw : nullptr;
-        }
-    };
-    auto fetch = [&](float (&a)[U][TM], float (&b)[U][TN]) {
-        const int ci = s_cb * cstep;
-        const int wrow = (s_kh * KW + s_kw) * Cin + ci;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[u][i] = rowok[i] ? wa[i][(wrow + 2 * u) * Cout] : 0.0f;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[u][j] = bp[j] ? bp[j][(ci + 2 * u) * HW] : 0.0f;
-        }
-        if (++s_cb == batches_per_tap) { s_cb = 0; if (++s_kw == KW) { s_kw = 0; ++s_kh; } set_tap(); }
-    };
-    auto compute = [&](float (&a)[U][TM], float (&b)[U][TN]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
-    };
-    set_tap();
-    fetch(a0, b0);
-    int st = 0;
-    for (; st + 2 <= nsteps; st += 2) {
-        if (st + 1 < nsteps) fetch(a1, b1);
-        compute(a0, b0);
-        if (st + 2 < nsteps) fetch(a0, b0);
-        compute(a1, b1);
-    }
-    if (st < nsteps) compute(a0, b0);
-    EpiConv ep{scale, shift, residual, y, Cout, opix, Ntot, relu};
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) ep.tile(m0 + i * 32 + 4 * half, n0 + j * 32 + l31, acc[i][j]);
-}
-
-template <int TM, int TN, int WM, int WN>
-void launch_conv_direct(const float* x, const float* Wt, const float* scale, const float* shift, const float* residual, float* y,
-                        int Cin, int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride, int pad, int Ntot, int relu,
-                        hipStream_t st) {
-    const dim3 grid(di2p_cdiv(Ntot, WN * TN * 32), di2p_cdiv(Cout, WM * TM * 32));
-    hipLaunchKernelGGL((conv2d_direct_kernel<TM, TN, WM, WN>), grid, dim3(256), 0, st, x, Wt, scale, shift, residual, y, Cin, H, W,
-                       Cout, OH, OW, KH, KW, stride, pad, Ntot, relu);
+    const size_t lds = Cfg::LDS_FLOATS * sizeof(float);
+    if (stride == 1)
+        hipLaunchKernelGGL((conv2d_vec_kernel<Cfg, 1>), grid, block, lds, st, x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW,
+                           KH, KW, pad, Ntot, relu);
+    else
+        hipLaunchKernelGGL((conv2d_vec_kernel<Cfg, 2>), grid, block, lds, st, x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW,
+                           KH, KW, pad, Ntot, relu);
 }
 
 template <class Cfg>
@@ -418,28 +336,11 @@ extern "C" int di2p_conv2d(const float* x, const float* Wt, const float* scale, 
     else choice = 0;
     if (force >= 0) { choice = force % 10; if (choice >= 2 && Cout < 128) choice = 1; }
     const bool use32 = k32 && (force < 0 || force >= 10);
-    // EXPERIMENT, off by default (measured slower): barrier-free direct-to-register kernels
-    // (DI2P_CONV_DIRECT=1: 64x64 per wave, 2: 32x64, 3: 32x32, 4: auto)
-    static int direct = -1;
-    if (direct < 0) { const char* e = getenv("DI2P_CONV_DIRECT"); direct = e ? atoi(e) : 0; }
-    if (direct && tap_major && Cin % 8 == 0) {
-#define DI2P_CONVD(TM, TN, WM, WN) launch_conv_direct<TM, TN, WM, WN>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, st)
-        int mode = direct;
-        if (mode == 4) {   // enough waves to fill 1024 SIMDs a few times over, biggest tile first
-            const long long w64 = (long long)di2p_cdiv(Ntot, 64) * di2p_cdiv(Cout, 64);
-            const long long w32x64 = (long long)di2p_cdiv(Ntot, 64) * di2p_cdiv(Cout, 32);
-            mode = w64 >= 3072 ? 1 : (w32x64 >= 3072 ? 2 : 3);
-        }
-        if (mode == 1) { if (Cout >= 128) DI2P_CONVD(2, 2, 2, 2); else DI2P_CONVD(2, 2, 1, 4); }
-        else if (mode == 2) DI2P_CONVD(1, 2, 2, 2);
-        else DI2P_CONVD(1, 1, 2, 2);
-#undef DI2P_CONVD
-        DI2P_RETURN_LAUNCH();
-    }
     // vector stager: tap-major weights, 32-channel taps, whole 4-pixel groups per output row, 16-byte aligned weights
     static int novec = -1;
     if (novec < 0) { const char* e = getenv("DI2P_CONV_NOVEC"); novec = e ? atoi(e) : 0; }
-    const bool vec = !novec && use32 && OW % 4 == 0 && Cout % 4 == 0 && ((uintptr_t)Wt & 15) == 0;
+    const bool vec = !novec && use32 && OW % 4 == 0 && Cout % 4 == 0 && ((uintptr_t)Wt & 15) == 0 &&
+                     ((stride == 1 && pad <= 1 && KW <= 2 * pad + 1 && W >= 4) || stride == 2);
 #define DI2P_CONVV(CFG) launch_conv_vec<CFG>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, st)
     if (vec) {
         switch (choice) { case 3: DI2P_CONVV(CfgC128x128k32); break; case 2: DI2P_CONVV(CfgC128x64k32); break;

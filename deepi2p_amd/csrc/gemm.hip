@@ -7,6 +7,9 @@
 // the epilogue, so none of those intermediates ever exists in HBM.
 #include "mfma_tile.h"
 
+#include <stdint.h>
+#include <stdlib.h>
+
 namespace {
 
 struct LoaderWt {  // packed weight [K][M]
@@ -55,6 +58,38 @@ struct LoaderConcat {
     }
 };
 
+// 16-byte stager for the common case: every source DENSE, 4 consecutive columns per lane.  Loads are UNCONDITIONAL
+// from clamped addresses (no control flow in the K-loop): rows k >= K meet zero weights (clamping k re-reads real,
+// column-local data), columns n >= N are dropped by the epilogue.  The source of a row is picked with selects.
+struct LoaderConcat4 {
+    const float* base[DI2P_MAX_SRC];
+    int rs[DI2P_MAX_SRC];
+    int c0, c1, K;          // channel range ends of source 0 / 1 (== K when absent)
+    SrcDev s;
+    int b, N;
+    __device__ __forceinline__ void column4(int n) {
+        const int nc = min(n, N - 4);
+#pragma unroll
+        for (int i = 0; i < DI2P_MAX_SRC; ++i) {
+            const int j = i < s.n_src ? i : 0;
+            base[i] = s.ptr[j] + (long long)b * s.batch_stride[j] + nc;
+            rs[i] = s.row_stride[j];
+        }
+        c0 = s.c_end[0];
+        c1 = s.n_src > 1 ? s.c_end[1] : K;
+    }
+    __device__ __forceinline__ void begin_tile(int) {}
+    __device__ __forceinline__ float4 load4(int k) const {
+        const int kc = min(k, K - 1);
+        const bool s1 = kc >= c0, s2 = kc >= c1;
+        const float* p = s2 ? base[2] : (s1 ? base[1] : base[0]);
+        const int kk = kc - (s2 ? c1 : (s1 ? c0 : 0));
+        const int r = s2 ? rs[2] : (s1 ? rs[1] : rs[0]);
+        return *reinterpret_cast<const float4*>(p + kk * r);      // kk*r < 2^31 (host-checked)
+    }
+    __device__ __forceinline__ void fix(float4&, int) const {}
+};
+
 struct EpiDev {
     const float* scale;
     const float* shift;
@@ -66,54 +101,77 @@ struct EpiDev {
     int g_k;
     int relu;
     int group_max;
+    int transpose_out;
 };
 
+// The accumulator tile of a lane is 16 rows of ONE column: rows mrow0 + 8g + {0..3}, g = 0..3.  All per-row operands
+// (scale/shift/bias, the gathered tables stored [B][nodes][M]) are fetched as one float4 per group g from clamped
+// addresses, before any arithmetic, so the epilogue is a handful of independent loads instead of 16 serial
+// load -> wait -> store rounds.  Needs M % 4 == 0 whenever float4 operands are used (host-checked).
 struct EpiPointwise {
     EpiDev e;
     float* Y;
     int b, M, N;
     __device__ __forceinline__ void tile(int mrow0, int n, const f32x16& acc) {
         const bool col_ok = n < N;
-        // gathered-add operands of this column (per_point_pn layer 0)
-        int gi[2][4];
-        float gw[2][4];
+        const int nc = col_ok ? n : N - 1;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[r];
+        if (e.batch_bias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += e.batch_bias[(long long)b * M + min(mrow0 + (r & 3) + 8 * (r >> 2), M - 1)];
+        }
+        // gathered add (per_point_pn layer 0): v[m] += sum_j w_j * G[b][idx_j][m]
 #pragma unroll
         for (int t = 0; t < 2; ++t)
+            if (e.g_table[t]) {
+                const float* gt = e.g_table[t] + (long long)b * e.g_nodes[t] * M;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                gi[t][j] = 0;
-                gw[t][j] = 0.0f;
-                if (e.g_table[t] && col_ok && j < e.g_k) {
-                    gi[t][j] = e.g_idx[t][((long long)b * N + n) * e.g_k + j];
-                    gw[t][j] = e.g_w[t][((long long)b * N + n) * e.g_k + j];
-                }
-            }
+                for (int j = 0; j < 4; ++j)
+                    if (j < e.g_k) {
+                        const int gi = e.g_idx[t][((long long)b * N + nc) * e.g_k + j];
+                        const float gw = e.g_w[t][((long long)b * N + nc) * e.g_k + j];
+                        const float* gp = gt + (long long)gi * M;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mrow0 + (r & 3) + 8 * (r >> 2);
-            const bool ok = col_ok && m < M;
-            float v = acc[r];
-            if (ok) {
-                if (e.batch_bias) v += e.batch_bias[(long long)b * M + m];
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    if (e.g_table[t]) {
-                        const float* g = e.g_table[t] + ((long long)b * M + m) * e.g_nodes[t];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (j < e.g_k) v += gw[t][j] * g[gi[t][j]];
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 q = *reinterpret_cast<const float4*>(gp + min(mrow0 + 8 * g, M - 4));
+                            v[4 * g + 0] += gw * q.x; v[4 * g + 1] += gw * q.y; v[4 * g + 2] += gw * q.z; v[4 * g + 3] += gw * q.w;
+                        }
                     }
-                const float sc = e.scale ? e.scale[m] : 1.0f;
-                const float sh = e.shift ? e.shift[m] : 0.0f;
-                v = v * sc + sh;
-                if (e.relu) v = fmaxf(v, 0.0f);
             }
-            if (e.group_max > 1) {
-                float mx = ok ? v : -__builtin_inff();
+        if (e.scale) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] *= e.scale[min(mrow0 + (r & 3) + 8 * (r >> 2), M - 1)];
+        }
+        if (e.shift) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += e.shift[min(mrow0 + (r & 3) + 8 * (r >> 2), M - 1)];
+        }
+        if (e.relu) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
+        }
+        if (e.group_max > 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+                const bool ok = col_ok && m < M;
+                float mx = ok ? v[r] : -__builtin_inff();
                 for (int o = 1; o < e.group_max; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
                 if (ok && (n % e.group_max) == 0) Y[((long long)b * M + m) * (N / e.group_max) + n / e.group_max] = mx;
-            } else if (ok) {
-                Y[((long long)b * M + m) * N + n] = v;
+            }
+        } else if (e.transpose_out) {        // Y[b][n][m]: one float4 per row group (M % 4 == 0)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int m = mrow0 + 8 * g;
+                if (col_ok && m < M) *reinterpret_cast<float4*>(Y + ((long long)b * N + n) * M + m) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+                if (col_ok && m < M) Y[((long long)b * M + m) * N + n] = v[r];
             }
         }
     }
@@ -131,6 +189,20 @@ __global__ __launch_bounds__(Cfg::THREADS) void pointwise_gemm_kernel(SrcDev src
     lb.K = K;
     EpiPointwise ep{epi, Y, (int)blockIdx.z, M, N};
     mfma_gemm_block<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::THREADS) void pointwise_gemm_vec_kernel(SrcDev srcs, const float* __restrict__ Wt, float* __restrict__ Y,
+                                                                           int M, int K, int N, EpiDev epi) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    LoaderWt4 la{Wt, K, M};
+    LoaderConcat4 lb;
+    lb.s = srcs;
+    lb.b = blockIdx.z;
+    lb.N = N;
+    lb.K = K;
+    EpiPointwise ep{epi, Y, (int)blockIdx.z, M, N};
+    mfma_gemm_block_vec<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
 }
 
 // ---- attention pooling: out[b,c,m] = (1/HW) sum_hw feat[b,c,hw] * score[b,hw,m]
@@ -171,15 +243,31 @@ __global__ __launch_bounds__(Cfg::THREADS) void attention_pool_kernel(const floa
     mfma_gemm_block<Cfg>(lds, la, lb, ep, HW, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
 }
 
+// out[b][m] = sum_k Wt[k0+k][m] * v[b][k].  One block = 64 output channels x 4 k-slices (one wave per slice: its v[b][k]
+// reads are wave-uniform, its Wt reads 256 contiguous bytes); 4 independent accumulators per lane keep the dependent
+// FMA chain at Kv/16, the slices are combined through LDS.
 __global__ __launch_bounds__(256) void batch_gemv_kernel(const float* __restrict__ Wt, int M, int k0, const float* __restrict__ v,
                                                          int Kv, float* __restrict__ out) {
+    __shared__ float part[4][64];
     const int b = blockIdx.y;
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int m = blockIdx.x * 64 + lane;
+    const int mc = min(m, M - 1);
     const float* vb = v + (long long)b * Kv;
-    float acc = 0.0f;
-    for (int k = 0; k < Kv; ++k) acc += Wt[(long long)(k0 + k) * M + m] * vb[k];
-    out[(long long)b * M + m] = acc;
+    const int per = (Kv + 3) / 4;
+    const int kb = slice * per, ke = min(kb + per, Kv);
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int k = kb;
+    for (; k + 3 < ke; k += 4) {
+        a0 += Wt[(long long)(k0 + k) * M + mc] * vb[k];
+        a1 += Wt[(long long)(k0 + k + 1) * M + mc] * vb[k + 1];
+        a2 += Wt[(long long)(k0 + k + 2) * M + mc] * vb[k + 2];
+        a3 += Wt[(long long)(k0 + k + 3) * M + mc] * vb[k + 3];
+    }
+    for (; k < ke; ++k) a0 += Wt[(long long)(k0 + k) * M + mc] * vb[k];
+    part[slice][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (slice == 0 && m < M) out[(long long)b * M + m] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 template <class Cfg>
@@ -187,6 +275,14 @@ void launch_pw(const SrcDev& s, const float* Wt, float* Y, int B, int M, int K, 
     const dim3 grid(di2p_cdiv(N, Cfg::BN), di2p_cdiv(M, Cfg::BM), B);
     hipLaunchKernelGGL(pointwise_gemm_kernel<Cfg>, grid, dim3(Cfg::THREADS), Cfg::LDS_FLOATS * sizeof(float), st, s, Wt, Y, M, K, N, e);
 }
+
+template <class Cfg>
+void launch_pw_vec(const SrcDev& s, const float* Wt, float* Y, int B, int M, int K, int N, const EpiDev& e, hipStream_t st) {
+    const dim3 grid(di2p_cdiv(N, Cfg::BN), di2p_cdiv(M, Cfg::BM), B);
+    hipLaunchKernelGGL(pointwise_gemm_vec_kernel<Cfg>, grid, dim3(Cfg::THREADS), Cfg::LDS_FLOATS * sizeof(float), st, s, Wt, Y, M, K, N, e);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
@@ -224,13 +320,26 @@ extern "C" int di2p_pointwise_gemm(const di2p_src_t* srcs, int n_src, const floa
         e.group_max = epi->group_max > 1 ? epi->group_max : 1;
         for (int t = 0; t < 2; ++t) { e.g_table[t] = epi->g_table[t]; e.g_idx[t] = epi->g_idx[t]; e.g_w[t] = epi->g_w[t]; e.g_nodes[t] = epi->g_nodes[t]; }
         e.g_k = epi->g_k;
+        e.transpose_out = epi->transpose_out;
         DI2P_CHECK_ARG(e.g_k >= 0 && e.g_k <= 4, "g_k must be <= 4");
+        DI2P_CHECK_ARG(!(e.g_table[0] || e.g_table[1]) || (M % 4 == 0 && M >= 4), "gathered tables need M % 4 == 0");
+        DI2P_CHECK_ARG(!e.transpose_out || (M % 4 == 0 && e.group_max == 1), "transpose_out needs M % 4 == 0 and no group_max");
     }
     if (e.group_max > 1) {
         const int g = e.group_max;
         DI2P_CHECK_ARG((g & (g - 1)) == 0 && g <= 32 && N % g == 0, "group_max must be a power of two <= 32 dividing N");
     }
     hipStream_t st = (hipStream_t)stream;
+    // 16-byte staged path: all sources dense and 16-byte addressable in 4-column groups
+    bool vec = N % 4 == 0 && N >= 4 && M % 4 == 0 && aligned16(Wt) && getenv("DI2P_PW_NOVEC") == nullptr;
+    for (int i = 0; i < n_src && vec; ++i)
+        vec = srcs[i].mode == DI2P_SRC_DENSE && srcs[i].row_stride % 4 == 0 && srcs[i].batch_stride % 4 == 0 && aligned16(srcs[i].ptr);
+    if (vec) {
+        if (M <= 32) launch_pw_vec<TileCfg<1, 4, 1, 1, 32>>(s, Wt, Y, B, M, K, N, e, st);
+        else if (M <= 64 || (long long)B * di2p_cdiv(N, 128) * di2p_cdiv(M, 128) < 256) launch_pw_vec<TileCfg<2, 2, 1, 2, 32>>(s, Wt, Y, B, M, K, N, e, st);
+        else launch_pw_vec<TileCfg<2, 2, 2, 2, 32>>(s, Wt, Y, B, M, K, N, e, st);
+        DI2P_RETURN_LAUNCH();
+    }
     if (M <= 32) launch_pw<Cfg32x128>(s, Wt, Y, B, M, K, N, e, st);
     else if (M <= 64 || (long long)B * di2p_cdiv(N, 128) * di2p_cdiv(M, 128) < 256) launch_pw<Cfg64x128>(s, Wt, Y, B, M, K, N, e, st);
     else launch_pw<Cfg128x128>(s, Wt, Y, B, M, K, N, e, st);
@@ -240,7 +349,7 @@ extern "C" int di2p_pointwise_gemm(const di2p_src_t* srcs, int n_src, const floa
 extern "C" int di2p_batch_gemv(const float* Wt, int M, int k0, const float* v, int Kv, float* out, int B, void* stream) {
     DI2P_CHECK_ARG(Wt && v && out && M >= 1 && Kv >= 1 && k0 >= 0 && B >= 0, "bad args");
     if (B == 0) return 0;
-    hipLaunchKernelGGL(batch_gemv_kernel, dim3(di2p_cdiv(M, 256), B), dim3(256), 0, (hipStream_t)stream, Wt, M, k0, v, Kv, out);
+    hipLaunchKernelGGL(batch_gemv_kernel, dim3(di2p_cdiv(M, 64), B), dim3(256), 0, (hipStream_t)stream, Wt, M, k0, v, Kv, out);
     DI2P_RETURN_LAUNCH();
 }
 

@@ -113,9 +113,25 @@ __device__ __forceinline__ void mfma_gemm_block(float* lds, LoaderA& la, LoaderB
 // ----------------------------------------------------------------------------------------------------------------
 // Vectorised variant: operands are staged with 16-byte global loads and ds_write_b128 (4 consecutive m / n per lane),
 // 4x fewer VMEM and LDS-write instructions per MFMA than the scalar stager above.  Loaders provide
-//   LoaderA: float4 load4(int k, int m)      (m % 4 == 0; out-of-range rows/cols -> 0)
-//   LoaderB: void column4(int j) (j % 4 == 0); void begin_tile(int k0); float4 load4(int k)
+//   LoaderA: float4 load4(int k, int m)      (m % 4 == 0); void fix(float4&, int k) zeroes rows k >= K at store time
+//   LoaderB: void column4(int j) (j % 4 == 0); void begin_tile(int k0); float4 load4(int k);
+//            void fix(float4&, int pass)  -- applied at LDS-store time to the values of the tile loaded after the last
+//            begin_tile: loaders keep their loads UNCONDITIONAL (clamped addresses, no control flow in the K-loop)
+//            and zero here what must read as zero (convolution padding)
 struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };   // 16-byte load that only needs dword alignment
+
+// Weights [K][M] with M % 4 == 0: 4 consecutive output channels of one k row, loaded unconditionally from the
+// clamped (k, m) and zeroed for k >= K at LDS-store time (rows m >= M are dropped by the epilogue).
+struct LoaderWt4 {
+    const float* Wt;
+    int K, M;
+    __device__ __forceinline__ float4 load4(int k, int m) const {
+        return *reinterpret_cast<const float4*>(Wt + min(k, K - 1) * M + min(m, M - 4));
+    }
+    __device__ __forceinline__ void fix(float4& v, int k) const {
+        if (k >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+};
 
 template <class Cfg, class LoaderA, class LoaderB, class Epi>
 __device__ __forceinline__ void mfma_gemm_block_vec(float* lds, LoaderA& la, LoaderB& lb, Epi& epi, int K, int m_blk, int j_blk) {
@@ -144,8 +160,10 @@ __device__ __forceinline__ void mfma_gemm_block_vec(float* lds, LoaderA& la, Loa
 
     float4 ra[A_PASSES], rb[B_PASSES];
     const int T = (K + BK - 1) / BK;
+    int k_loaded = 0;
     auto gload = [&](int t) {
         const int k0 = t * BK;
+        k_loaded = k0;
         lb.begin_tile(k0);
 #pragma unroll
         for (int p = 0; p < A_PASSES; ++p) ra[p] = la.load4(k0 + a_row0 + p * A_RPP, m_blk + a_col);
@@ -154,32 +172,49 @@ __device__ __forceinline__ void mfma_gemm_block_vec(float* lds, LoaderA& la, Loa
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<float4*>(&As[(buf * BK + a_row0 + p * A_RPP) * BM + a_col]) = ra[p];
+        for (int p = 0; p < A_PASSES; ++p) {
+            la.fix(ra[p], k_loaded + a_row0 + p * A_RPP);
+            *reinterpret_cast<float4*>(&As[(buf * BK + a_row0 + p * A_RPP) * BM + a_col]) = ra[p];
+        }
 #pragma unroll
-        for (int p = 0; p < B_PASSES; ++p) *reinterpret_cast<float4*>(&Bs[(buf * BK + b_row0 + p * B_RPP) * BN + b_col]) = rb[p];
+        for (int p = 0; p < B_PASSES; ++p) {
+            lb.fix(rb[p], p);
+            *reinterpret_cast<float4*>(&Bs[(buf * BK + b_row0 + p * B_RPP) * BN + b_col]) = rb[p];
+        }
     };
     gload(0);
     lstore(0);
     __syncthreads();
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
-        if (t + 1 < T) gload(t + 1);
+        // Branch-free loop body (the last step loads one tile too many from clamped addresses; it is stored to the idle
+        // buffer and never read).  The scheduling fences pin the global loads AHEAD of the MFMA phase and their first
+        // use (fix + ds_write) BEHIND it, so the L2/HBM latency of step t+1 hides under the MFMAs of step t.
+        gload(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
         const float* Ab = As + buf * BK * BM + wm * Cfg::TM * 32 + l31;
         const float* Bb = Bs + buf * BK * BN + wn * Cfg::TN * 32 + l31;
+        // operand fragments double-buffered in registers: the ds_reads of k-pair kk+1 are in flight under the MFMAs of kk
+        float a[2][Cfg::TM], b[2][Cfg::TN];
+        auto fread = [&](int kk, int s) {
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i) a[s][i] = Ab[(kk + half) * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) b[s][j] = Bb[(kk + half) * BN + j * 32];
+        };
+        fread(0, 0);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float a[Cfg::TM], b[Cfg::TN];
-#pragma unroll
-            for (int i = 0; i < Cfg::TM; ++i) a[i] = Ab[(kk + half) * BM + i * 32];
-#pragma unroll
-            for (int j = 0; j < Cfg::TN; ++j) b[j] = Bb[(kk + half) * BN + j * 32];
+            const int s = (kk >> 1) & 1;
+            if (kk + 2 < BK) fread(kk + 2, s ^ 1);
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
                 for (int j = 0; j < Cfg::TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
         }
-        if (t + 1 < T) lstore(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(buf ^ 1);
         __syncthreads();
     }
 #pragma unroll

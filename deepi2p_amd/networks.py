@@ -341,8 +341,8 @@ class KeypointDetector(_PackedModule):
         # per-point head (:188-197): layer 0 contracts the interpolated inputs per node
         Wt, sc, sh, act = p["per_point_pn"][0]
         M0 = Wt.shape[1]
-        G_a = ops.pointwise_gemm([Src(up_a)], Wt[0:128], M0, Ma)
-        G_b = ops.pointwise_gemm([Src(up_b)], Wt[128:640], M0, Mb)
+        G_a = ops.pointwise_gemm([Src(up_a)], Wt[0:128], M0, Ma, transpose_out=True)     # [B,Ma,M0] node-major
+        G_b = ops.pointwise_gemm([Src(up_b)], Wt[128:640], M0, Mb, transpose_out=True)
         h = ops.pointwise_gemm([Src(first), Src(second)], Wt[640:736], M0, N, scale=sc, shift=sh, relu=act,
                                gathered=[(G_a, idx_a, ex["w_a"]), (G_b, idx_pb, w_pb)])
         scores = _run_pn(h, p["per_point_pn"][1:])

@@ -126,9 +126,10 @@ class Src:
         self.t, self.mode, self.gidx, self.group = t, mode, gidx, group
 
 
-def pointwise_gemm(srcs, Wt, M, N, scale=None, shift=None, batch_bias=None, relu=False, group_max=1, gathered=None):
+def pointwise_gemm(srcs, Wt, M, N, scale=None, shift=None, batch_bias=None, relu=False, group_max=1, gathered=None,
+                   transpose_out=False):
     """Y[b] = epi(Wt^T @ concat(srcs)[b]).  srcs: list of Src; Wt f32[K,M].  gathered: optional list of up
-    to two (table f32[B,M,nodes], idx i32[B,N,k], w f32[B,N,k])."""
+    to two (table f32[B,nodes,M] node-major, idx i32[B,N,k], w f32[B,N,k]).  transpose_out: Y is f32[B,N,M]."""
     B = srcs[0].t.shape[0]
     K = Wt.shape[0]
     arr = (SrcT * len(srcs))()
@@ -150,10 +151,12 @@ def pointwise_gemm(srcs, Wt, M, N, scale=None, shift=None, batch_bias=None, relu
         for t, (tab, gi, gw) in enumerate(gathered):
             require_cuda(tab, gi, gw)
             e.g_table[t], e.g_idx[t], e.g_w[t] = ptr(tab), ptr(gi), ptr(gw)
-            e.g_nodes[t] = tab.shape[2]
+            assert tab.shape[2] == M
+            e.g_nodes[t] = tab.shape[1]
             e.g_k = gi.shape[2]
+    e.transpose_out = int(bool(transpose_out))
     Nout = N // group_max if group_max > 1 else N
-    Y = torch.empty((B, M, Nout), dtype=_f32, device=Wt.device)
+    Y = torch.empty((B, Nout, M) if transpose_out else (B, M, Nout), dtype=_f32, device=Wt.device)
     call("di2p_pointwise_gemm", arr, len(srcs), ptr(Wt), ptr(Y), B, M, K, N, ctypes.byref(e), stream())
     return Y
 

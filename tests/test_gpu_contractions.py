@@ -25,6 +25,35 @@ def test_pointwise_gemm_dense(dev, B, M, K, N):
     assert (y - ref).abs().max() <= _tol(ref, K)
 
 
+@pytest.mark.parametrize("B,chans,M,N", [(3, (24, 40, 5), 100, 1500), (2, (96,), 128, 20480), (1, (7,), 32, 260),
+                                        (2, (64, 64), 512, 2048), (2, (33,), 4, 8)])
+def test_pointwise_gemm_dense_vector_path(dev, B, chans, M, N):
+    """16-byte staged path (all sources dense, N % 4 == 0, M % 4 == 0): ragged K, M and N against torch and against the
+    scalar stager."""
+    import os
+    from deepi2p_amd import ops
+    g = torch.Generator().manual_seed(11 + N)
+    xs = [torch.randn(B, c, N, generator=g) for c in chans]
+    K = sum(chans)
+    W = torch.randn(M, K, generator=g) / K ** 0.5
+    scale, shift = torch.rand(M, generator=g) + 0.5, torch.randn(M, generator=g)
+    bias = torch.randn(B, M, generator=g)
+    Wt = W.t().contiguous().to(dev)
+    args = dict(scale=scale.to(dev), shift=shift.to(dev), relu=True, batch_bias=bias.to(dev))
+    srcs = [ops.Src(x.to(dev)) for x in xs]
+    y = ops.pointwise_gemm(srcs, Wt, M, N, **args).cpu()
+    ref = torch.relu((torch.einsum("mk,bkn->bmn", W, torch.cat(xs, 1)) + bias.unsqueeze(2)) * scale.view(1, M, 1) + shift.view(1, M, 1))
+    assert (y - ref).abs().max() <= _tol(ref, K)
+    os.environ["DI2P_PW_NOVEC"] = "1"
+    try:
+        y0 = ops.pointwise_gemm(srcs, Wt, M, N, **args).cpu()
+    finally:
+        del os.environ["DI2P_PW_NOVEC"]
+    assert (y - y0).abs().max() <= _tol(ref, K)
+    yt = ops.pointwise_gemm(srcs, Wt, M, N, transpose_out=True, **args).cpu()
+    assert torch.equal(yt.transpose(1, 2), y)
+
+
 def test_pointwise_gemm_transpose_detecting(dev):
     """A = identity-like weights with an ASYMMETRIC input: catches row/col swaps in the MFMA C layout."""
     from deepi2p_amd import ops
@@ -74,8 +103,10 @@ def test_pointwise_gemm_gathered_add(dev):
     W = torch.randn(M, 736, generator=g) / 736 ** 0.5
     scale, shift = torch.rand(M, generator=g) + 0.5, torch.randn(M, generator=g)
     Wt = W.t().contiguous().to(dev)
-    Ga = ops.pointwise_gemm([ops.Src(fa.to(dev))], Wt[0:128], M, Ma)
-    Gb = ops.pointwise_gemm([ops.Src(fb.to(dev))], Wt[128:640], M, Mb)
+    Ga = ops.pointwise_gemm([ops.Src(fa.to(dev))], Wt[0:128], M, Ma, transpose_out=True)      # node-major [B,Ma,M]
+    Gb = ops.pointwise_gemm([ops.Src(fb.to(dev))], Wt[128:640], M, Mb, transpose_out=True)
+    Ga_plain = ops.pointwise_gemm([ops.Src(fa.to(dev))], Wt[0:128], M, Ma)
+    assert torch.equal(Ga.transpose(1, 2), Ga_plain)                                            # same values, transposed store
     y = ops.pointwise_gemm([ops.Src(x.to(dev))], Wt[640:736], M, N, scale=scale.to(dev), shift=shift.to(dev), relu=True,
                            gathered=[(Ga, ia.to(dev), wa.to(dev)), (Gb, ib.to(dev), wb.to(dev))]).cpu()
 
@@ -100,7 +131,9 @@ def test_attention_pool(dev):
 @pytest.mark.parametrize("B,Cin,H,W,Cout,k,s,p", [(2, 3, 64, 128, 64, 7, 2, 3), (2, 64, 16, 32, 64, 3, 1, 1),
                                                   (1, 64, 16, 32, 128, 3, 2, 1), (2, 64, 16, 32, 128, 1, 2, 0),
                                                   (3, 256, 5, 16, 512, 3, 2, 1), (1, 512, 5, 16, 512, 3, 1, 1),
-                                                  (1, 5, 9, 11, 7, 3, 1, 1)])
+                                                  (1, 5, 9, 11, 7, 3, 1, 1), (2, 32, 3, 4, 32, 3, 1, 1),
+                                                  (1, 64, 1, 8, 64, 3, 1, 1), (3, 32, 7, 12, 36, 1, 1, 0),
+                                                  (2, 32, 6, 8, 64, 3, 2, 1)])
 def test_conv2d(dev, B, Cin, H, W, Cout, k, s, p):
     from deepi2p_amd import ops
     g = torch.Generator().manual_seed(Cin + Cout)
