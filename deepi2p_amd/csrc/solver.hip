@@ -95,46 +95,165 @@ template <typename PT> struct Rec;
 template <> struct __attribute__((aligned(16))) Rec<float> { float x, y, z; int lab; };
 template <> struct __attribute__((aligned(16))) Rec<double> { double x, y, z; long long lab; };
 
+// Frame preparation (once per solve call, one 1024-thread workgroup per frame):
+//   1. records with label 0/1 are sorted by (label: 1 first, Morton code of the (x,z) ground-plane cell) with an
+//      in-workgroup bitonic sort on unique 64-bit keys (key << 32 | point index): deterministic, data-independent
+//      network, 64 KB LDS chunks with the wide strides done in the (L2-resident) global scratch;
+//   2. consecutive groups of CL = 64 sorted records of one label form a CLUSTER with a bounding sphere.
+// The solver's sweeps test each sphere against the five planes of the camera frustum of the current iterate and
+// classify the points of a cluster individually only when the sphere touches a plane (see sweep_clusters).
+constexpr int CL = 64;
+struct __attribute__((aligned(16))) Sphere { double cx, cy, cz, r; };
+
+__device__ __forceinline__ unsigned spread10(unsigned v) {
+    v &= 0x3ffu;
+    v = (v | (v << 8)) & 0x00ff00ffu; v = (v | (v << 4)) & 0x0f0f0f0fu; v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
 template <typename PT>
-__global__ __launch_bounds__(256) void pack_kernel(const PT* __restrict__ points, const int* __restrict__ labels, int N,
-                                                   Rec<PT>* __restrict__ packed, int* __restrict__ counts) {
-    __shared__ int s_scan1[256], s_scan0[256];
-    __shared__ int s_base1, s_base0, s_n1;
-    const int f = blockIdx.x, tid = threadIdx.x;
+__global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ points, const int* __restrict__ labels, int N, int P,
+                                                       int NCMAX, unsigned long long* __restrict__ keys_all,
+                                                       Rec<PT>* __restrict__ packed, Sphere* __restrict__ spheres_all,
+                                                       int* __restrict__ counts) {
+    constexpr int CH = 8192;                       // LDS chunk (64 KB)
+    __shared__ unsigned long long chunk[CH];
+    __shared__ float s_f[4][16];
+    __shared__ int s_i[2][16];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const PT* px = points + (long long)f * 3 * N;
+    const PT* py = px + N;
+    const PT* pz = px + 2 * (long long)N;
     const int* lab = labels + (long long)f * N;
+    unsigned long long* keys = keys_all + (long long)f * P;
     Rec<PT>* out = packed + (long long)f * N;
-    // pass 1: number of label-1 records (they are stored first so that every 64-record step of a sweep and every
-    // phase-B batch holds ONE label: no label divergence in the hot loops)
-    int c1 = 0;
-    for (int n = tid; n < N; n += 256) c1 += lab[n] == 1;
-    s_scan1[tid] = c1;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_scan1[tid] += s_scan1[tid + o]; __syncthreads(); }
-    if (tid == 0) { s_n1 = s_scan1[0]; s_base1 = 0; s_base0 = 0; }
-    __syncthreads();
-    const int n1 = s_n1;
-    for (int n0 = 0; n0 < N; n0 += 256) {
-        const int n = n0 + tid;
-        const int l = n < N ? lab[n] : -1;
-        s_scan1[tid] = l == 1; s_scan0[tid] = l == 0;
-        __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {
-            const int v1 = tid >= o ? s_scan1[tid - o] : 0, v0 = tid >= o ? s_scan0[tid - o] : 0;
-            __syncthreads();
-            s_scan1[tid] += v1; s_scan0[tid] += v0;
-            __syncthreads();
-        }
+    Sphere* spheres = spheres_all + (long long)f * NCMAX;
+
+    // 1. ground-plane bounding box of the valid points, label counts (fixed-order reductions)
+    float mnx = __builtin_inff(), mxx = -__builtin_inff(), mnz = __builtin_inff(), mxz = -__builtin_inff();
+    int c1 = 0, c0 = 0;
+    for (int n = tid; n < N; n += 1024) {
+        const int l = lab[n];
         if (l == 0 || l == 1) {
-            Rec<PT> r;
-            r.x = px[n]; r.y = px[N + n]; r.z = px[2 * (long long)N + n]; r.lab = l;
-            out[l == 1 ? s_base1 + s_scan1[tid] - 1 : n1 + s_base0 + s_scan0[tid] - 1] = r;
+            const float x = (float)px[n], z = (float)pz[n];
+            mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mnz = fminf(mnz, z); mxz = fmaxf(mxz, z);
+            c1 += l == 1; c0 += l == 0;
         }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mnx = fminf(mnx, __shfl_xor(mnx, o)); mxx = fmaxf(mxx, __shfl_xor(mxx, o));
+        mnz = fminf(mnz, __shfl_xor(mnz, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o));
+        c1 += __shfl_xor(c1, o); c0 += __shfl_xor(c0, o);
+    }
+    if (lane == 0) { s_f[0][wave] = mnx; s_f[1][wave] = mxx; s_f[2][wave] = mnz; s_f[3][wave] = mxz; s_i[0][wave] = c1; s_i[1][wave] = c0; }
+    __syncthreads();
+    mnx = s_f[0][0]; mxx = s_f[1][0]; mnz = s_f[2][0]; mxz = s_f[3][0];
+    int n1 = s_i[0][0], n0 = s_i[1][0];
+    for (int w = 1; w < 16; ++w) {
+        mnx = fminf(mnx, s_f[0][w]); mxx = fmaxf(mxx, s_f[1][w]); mnz = fminf(mnz, s_f[2][w]); mxz = fmaxf(mxz, s_f[3][w]);
+        n1 += s_i[0][w]; n0 += s_i[1][w];
+    }
+    const float ext = fmaxf(mxx - mnx, mxz - mnz);
+    const float scale = (ext > 0.0f && ext < __builtin_inff()) ? 1023.0f / ext : 0.0f;
+
+    // 2. sort keys: [label != 1][20-bit Morton of the cell] << 32 | index; everything else sorts to the end
+    for (int n = tid; n < P; n += 1024) {
+        unsigned long long k = ~0ull;
+        if (n < N) {
+            const int l = lab[n];
+            if (l == 0 || l == 1) {
+                const float qx = fminf(fmaxf(((float)px[n] - mnx) * scale, 0.0f), 1023.0f);
+                const float qz = fminf(fmaxf(((float)pz[n] - mnz) * scale, 0.0f), 1023.0f);
+                const unsigned m = spread10((unsigned)qx) | (spread10((unsigned)qz) << 1);
+                k = ((unsigned long long)((l == 1 ? 0u : 1u << 20) | m) << 32) | (unsigned)n;
+            }
+        }
+        keys[n] = k;
+    }
+    __syncthreads();
+
+    // 3. bitonic sort, ascending
+    const int CHe = P < CH ? P : CH;
+    const int nchunks = P / CHe;
+    auto chunk_stages = [&](int base, int k, int j_first) {     // stages j_first, j_first/2, ..., 1 of merge size k on the LDS chunk
+        for (int j = j_first; j > 0; j >>= 1) {
+            for (int t = tid; t < CHe / 2; t += 1024) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const bool up = ((base + i) & k) == 0;
+                const unsigned long long a = chunk[i], b = chunk[i + j];
+                if ((a > b) == up) { chunk[i] = b; chunk[i + j] = a; }
+            }
+            __syncthreads();
+        }
+    };
+    for (int c = 0; c < nchunks; ++c) {
+        const int base = c * CHe;
+        for (int i = tid; i < CHe; i += 1024) chunk[i] = keys[base + i];
         __syncthreads();
-        if (tid == 255) { s_base1 += s_scan1[255]; s_base0 += s_scan0[255]; }
+        for (int k = 2; k <= CHe; k <<= 1) chunk_stages(base, k, k >> 1);
+        for (int i = tid; i < CHe; i += 1024) keys[base + i] = chunk[i];
         __syncthreads();
     }
-    if (tid == 0) { counts[2 * f] = n1; counts[2 * f + 1] = s_base0; }
+    for (int k = CHe << 1; k <= P; k <<= 1) {
+        for (int j = k >> 1; j >= CHe; j >>= 1) {
+            for (int t = tid; t < P / 2; t += 1024) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const bool up = (i & k) == 0;
+                const unsigned long long a = keys[i], b = keys[i + j];
+                if ((a > b) == up) { keys[i] = b; keys[i + j] = a; }
+            }
+            __syncthreads();
+        }
+        for (int c = 0; c < nchunks; ++c) {
+            const int base = c * CHe;
+            for (int i = tid; i < CHe; i += 1024) chunk[i] = keys[base + i];
+            __syncthreads();
+            chunk_stages(base, k, CHe >> 1);
+            for (int i = tid; i < CHe; i += 1024) keys[base + i] = chunk[i];
+            __syncthreads();
+        }
+    }
+
+    // 4. records in sorted order: label-1 block [0, n1), label-0 block [n1, n1+n0)
+    const int nv = n1 + n0;
+    for (int i = tid; i < nv; i += 1024) {
+        const int n = (int)(unsigned)(keys[i] & 0xffffffffull);
+        Rec<PT> r;
+        r.x = px[n]; r.y = py[n]; r.z = pz[n]; r.lab = lab[n];
+        out[i] = r;
+    }
+    __syncthreads();
+
+    // 5. bounding spheres: one wavefront per cluster
+    const int nc1 = (n1 + CL - 1) / CL, nc0 = (n0 + CL - 1) / CL;
+    for (int c = wave; c < nc1 + nc0; c += 16) {
+        const int start = c < nc1 ? c * CL : n1 + (c - nc1) * CL;
+        const int end = c < nc1 ? min(start + CL, n1) : min(start + CL, nv);
+        const bool valid = start + lane < end;
+        double x = 0, y = 0, z = 0;
+        if (valid) { const Rec<PT> r = out[start + lane]; x = (double)r.x; y = (double)r.y; z = (double)r.z; }
+        double lo[3] = {valid ? x : __builtin_inf(), valid ? y : __builtin_inf(), valid ? z : __builtin_inf()};
+        double hi[3] = {valid ? x : -__builtin_inf(), valid ? y : -__builtin_inf(), valid ? z : -__builtin_inf()};
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { lo[a] = fmin(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmax(hi[a], __shfl_xor(hi[a], o)); }
+        const double cx = 0.5 * (lo[0] + hi[0]), cy = 0.5 * (lo[1] + hi[1]), cz = 0.5 * (lo[2] + hi[2]);
+        double d2 = valid ? (x - cx) * (x - cx) + (y - cy) * (y - cy) + (z - cz) * (z - cz) : 0.0;
+        // a NaN coordinate must poison the radius (fmax would drop it): such clusters are always classified per point
+        bool nan_any = valid && !(d2 == d2);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d2 = fmax(d2, __shfl_xor(d2, o));
+        nan_any = __any(nan_any) != 0;
+        if (lane == 0) {
+            Sphere sp;
+            sp.cx = cx; sp.cy = cy; sp.cz = cz;
+            sp.r = nan_any ? __builtin_nan("") : sqrt(d2) * (1.0 + 1e-12);
+            spheres[c] = sp;
+        }
+    }
+    if (tid == 0) { counts[4 * f] = n1; counts[4 * f + 1] = n0; counts[4 * f + 2] = nc1; counts[4 * f + 3] = nc0; }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -149,7 +268,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const PT* __restrict__ points
 //   reduction: xor-butterfly inside each wave, then the 4 wave partials are combined through LDS in a FIXED
 //     order by every thread, so all 256 threads hold bit-identical sums and the LM control flow that
 //     follows is workgroup-uniform.
-constexpr int QCAP = 320;        // per-wave queue capacity (>= 63 carried + 4*64 pushed per batch)
+constexpr int QCAP = 128;        // per-wave queue capacity (<= 63 carried + 64 pushed per cluster)
 
 template <int NP, int WPH>   // WPH = waves per hypothesis (workgroup = WPH*64 threads)
 struct SweepShared {
@@ -262,83 +381,131 @@ __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& ro
     }
 }
 
-// One label-uniform range of records [recs, recs+cnt): phase A (exact fp64 classification), wave-level compaction of
-// the active ids, dense phase B.  LAB is a compile-time constant: no label test and no label divergence anywhere.
-template <int NP, typename PT, int WPH, int U, int LAB>
-__device__ __forceinline__ void sweep_range(const Rec<PT>* __restrict__ recs, int cnt, const Cam& k, const double* x,
-                                            const Rot<NP>& rot, int* queue, double& cost, double* lg, double* lA, bool& bad,
-                                            int& n_active) {
+// The five planes of the camera frustum in camera coordinates, f_i(p) = n_i . p (un-normalised) with |n_i|:
+//   pix_x > 0  <=> f_L = fx*p0 + cx*p2 > 0,  pix_x < W1 <=> f_R = -fx*p0 + (W1-cx)*p2 > 0   (for p2 > 0; for p2 < 0 the
+//   pix_y > 0  <=> f_T = fy*p1 + cy*p2 > 0,  pix_y < H1 <=> f_B = -fy*p1 + (H1-cy)*p2 > 0    signs flip together),
+//   p2 > 0     <=> f_Z = p2 > 0.
+struct Planes { double nL, nR, nT, nB; };
+
+// Cluster test.  A sphere (centre c, radius r) lies strictly on one side of plane i iff |f_i(c)| > (r + delta)*|n_i|.
+// If that holds for ALL five planes, every point of the cluster has the same sign pattern as the centre, none of
+// dx, dy, p2 is zero or non-finite, and the per-point classification of phase A is known without evaluating it:
+//   label 1: inactive iff all five are positive, else every point is active;
+//   label 0: active   iff all five are positive, else every point is inactive (and cannot raise `bad`).
+// delta = 1e-9*(1+|p|) exceeds the rounding error of the per-point pixel test (~1e-13 of the same scale) by four
+// orders of magnitude, so the shortcut never disagrees with the exact test; NaN/inf anywhere fails every
+// comparison and falls back to the per-point path.  Returns 0: skip, 1: classify per point, 2: all active.
+template <int NP, int LAB>
+__device__ __forceinline__ int cluster_status(const Sphere& sp, const Rot<NP>& rot, double tx, double ty, double tz, const Cam& k,
+                                              const Planes& pl) {
+    double qx, qy, qz;
+    if (NP == 4) {
+        qx = rot.R[0] * sp.cx + rot.R[2] * sp.cz; qy = sp.cy; qz = rot.R[6] * sp.cx + rot.R[8] * sp.cz;
+    } else {
+        qx = rot.R[0] * sp.cx + rot.R[1] * sp.cy + rot.R[2] * sp.cz;
+        qy = rot.R[3] * sp.cx + rot.R[4] * sp.cy + rot.R[5] * sp.cz;
+        qz = rot.R[6] * sp.cx + rot.R[7] * sp.cy + rot.R[8] * sp.cz;
+    }
+    const double p0 = qx + tx, p1 = qy + ty, p2 = qz + tz;
+    const double thr = sp.r + 1e-9 * (1.0 + fabs(p0) + fabs(p1) + fabs(p2));
+    const double fL = k.fx * p0 + k.cx * p2, fR = -k.fx * p0 + (k.W1 - k.cx) * p2;
+    const double fT = k.fy * p1 + k.cy * p2, fB = -k.fy * p1 + (k.H1 - k.cy) * p2;
+    const double tL = thr * pl.nL, tR = thr * pl.nR, tT = thr * pl.nT, tB = thr * pl.nB;
+    const bool pL = fL > tL, pR = fR > tR, pT = fT > tT, pB = fB > tB, pZ = p2 > thr;
+    const bool certified = (pL || fL < -tL) && (pR || fR < -tR) && (pT || fT < -tT) && (pB || fB < -tB) && (pZ || p2 < -thr);
+    if (!certified) return 1;
+    const bool inside = pL && pR && pT && pB && pZ;
+    return (LAB == 1) ? (inside ? 0 : 2) : (inside ? 2 : 0);
+}
+
+// One label-uniform block of records [recs, recs+cnt) = nc clusters of CL records.  Cluster c belongs to wave
+// c % WPH (neighbouring clusters -- which tend to share their status -- spread over the waves).  Per round a lane
+// tests one cluster; the wave then walks the flagged ones: status 1 -> phase A (exact fp64 classification) on its 64
+// records, status 2 -> all 64 are active; active ids go to the per-wave LDS queue and are evaluated densely (phase B)
+// 64 at a time.  The queue sequence is the same as if every cluster had been classified per point, so the sums are
+// bit-identical to the unculled sweep (nocull != 0 forces status 1 everywhere: tests compare the two).
+template <int NP, typename PT, int WPH, int LAB>
+__device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs, int cnt, const Sphere* __restrict__ spheres, int nc,
+                                               const Cam& k, const Planes& pl, const double* x, const Rot<NP>& rot, int nocull,
+                                               int* queue, double& cost, double* lg, double* lA, bool& bad, int* n_active) {
     constexpr int TOFF = NP == 4 ? 1 : 3;
     const double tx = x[TOFF], ty = x[TOFF + 1], tz = x[TOFF + 2];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const double hw = k.W1 * 0.5, hh = k.H1 * 0.5;
-    constexpr int span = WPH * 64 * U;
     int qn = 0;  // wave-uniform
-    Rec<PT> nxt[U];
-    auto fetch = [&](int base) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int n = base + u * (WPH * 64) + tid;
-            if (n < cnt) nxt[u] = recs[n]; else { nxt[u].x = 0; nxt[u].y = 0; nxt[u].z = 1; nxt[u].lab = -1; }
-        }
+    auto load_rec = [&](int c) {
+        const int n = c * CL + lane;
+        Rec<PT> r;
+        if (n < cnt) r = recs[n]; else { r.x = 0; r.y = 0; r.z = 1; r.lab = -1; }
+        return r;
     };
-    if (cnt > 0) fetch(0);
-    for (int base = 0; base < cnt; base += span) {
-        Rec<PT> rec[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) rec[u] = nxt[u];
-        if (base + span < cnt) fetch(base + span);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            double X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y;
-            project<NP, PT, true>(rec[u], rot, tx, ty, tz, k, X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y);
-            bool act;
-            if (LAB == 1) {
-                act = !(-pix_x < 0.0) || !(pix_x - k.W1 < 0.0) || !(-pix_y < 0.0) || !(pix_y - k.H1 < 0.0) || !(-p2 < 0.0);
-            } else {
-                const double dx = hw - fabs(pix_x - hw), dy = hh - fabs(pix_y - hh);
-                // fmax(v,0)/v is NaN at v == 0 (registration_2d.hpp:53,56,58), and a non-finite pixel poisons the
-                // residual: evaluation failure.  One test: dx*dy*p2 is 0 or non-finite exactly in those cases.
-                const double chk = dx * dy * p2;
-                if (!(fabs(chk) > 0.0) || !(fabs(chk) < __builtin_inf())) bad = true;
-                act = dx > 0.0 && dy > 0.0 && p2 > 0.0;
-            }
-            act = act && (int)rec[u].lab >= 0;          // padding lanes of the last batch
-            const unsigned long long bal = __ballot(act);
-            if (act) queue[qn + __popcll(bal & lt)] = base + u * (WPH * 64) + tid;
-            qn += __popcll(bal);
-        }
-        // drain: dense evaluation of queued active records, 64 at a time (the remainder on the last batch)
-        const bool last = base + span >= cnt;
-        while (qn >= 64 || (last && qn > 0)) {
+    auto drain = [&](bool flush) {
+        while (qn >= 64 || (flush && qn > 0)) {
             // LDS ops of one wave retire in order; only the compiler must not reorder them
             __builtin_amdgcn_wave_barrier();
             const int n = lane < qn ? queue[lane] : -1;
             const int carry = (lane + 64 < qn) ? queue[lane + 64] : 0;
             __builtin_amdgcn_wave_barrier();
-            if (lane + 64 < qn) queue[lane] = carry;      // (entries beyond 128 are shifted on later rounds)
-            for (int j = 128 + lane; j < qn; j += 64) { const int c2 = queue[j]; queue[j - 64] = c2; }
-            n_active += qn > 64 ? 64 : qn;
+            if (lane + 64 < qn) queue[lane] = carry;
+            n_active[0] += qn > 64 ? 64 : qn;
             qn = qn > 64 ? qn - 64 : 0;
             __builtin_amdgcn_wave_barrier();
             if (n >= 0) eval_active<NP, PT, LAB>(recs[n], rot, x, k, cost, lg, lA, bad);
         }
+    };
+    const int mine = (nc - wave + WPH - 1) / WPH;        // clusters wave, wave+WPH, ... < nc
+    for (int j0 = 0; j0 < mine; j0 += 64) {
+        const int j = j0 + lane;
+        int status = 0;
+        if (j < mine) status = nocull ? 1 : cluster_status<NP, LAB>(spheres[j * WPH + wave], rot, tx, ty, tz, k, pl);
+        unsigned long long mA = __ballot(status == 1), mB = __ballot(status == 2);
+        unsigned long long m = mA | mB;
+        n_active[1] += __popcll(mA); n_active[2] += __popcll(mB); n_active[3] += min(mine - j0, 64);
+        Rec<PT> nxt;
+        if (m) nxt = load_rec((j0 + (int)__builtin_ctzll(m)) * WPH + wave);
+        while (m) {
+            const int bit = (int)__builtin_ctzll(m);
+            const int c = (j0 + bit) * WPH + wave;
+            const bool isA = (mA >> bit) & 1ull;
+            m &= m - 1;
+            const Rec<PT> rec = nxt;
+            if (m) nxt = load_rec((j0 + (int)__builtin_ctzll(m)) * WPH + wave);     // next flagged cluster in flight
+            bool act = (int)rec.lab >= 0;                                           // padding lanes of a partial cluster
+            if (isA) {
+                double X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y;
+                project<NP, PT, true>(rec, rot, tx, ty, tz, k, X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y);
+                if (LAB == 1) {
+                    act = act && (!(-pix_x < 0.0) || !(pix_x - k.W1 < 0.0) || !(-pix_y < 0.0) || !(pix_y - k.H1 < 0.0) || !(-p2 < 0.0));
+                } else {
+                    const double dx = hw - fabs(pix_x - hw), dy = hh - fabs(pix_y - hh);
+                    // fmax(v,0)/v is NaN at v == 0 (registration_2d.hpp:53,56,58), and a non-finite pixel poisons the
+                    // residual: evaluation failure.  One test: dx*dy*p2 is 0 or non-finite exactly in those cases.
+                    const double chk = dx * dy * p2;
+                    if (act && (!(fabs(chk) > 0.0) || !(fabs(chk) < __builtin_inf()))) bad = true;
+                    act = act && dx > 0.0 && dy > 0.0 && p2 > 0.0;
+                }
+            }
+            const unsigned long long bal = __ballot(act);
+            if (act) queue[qn + __popcll(bal & lt)] = c * CL + lane;
+            qn += __popcll(bal);
+            drain(false);
+        }
     }
+    drain(true);
 }
 
 // Leaves the WPH wave partials {cost, g[NP], A[tri], bad} in sh.red[wave][*]; the caller combines them after a
-// barrier.  Records are sorted by label (pack_kernel): the label-1 block and the label-0 block are swept by two
-// specialised loops; records are prefetched one batch (U per lane) ahead.
-template <int NP, typename PT, int WPH, int U>
-__device__ __forceinline__ int sweep(const Rec<PT>* __restrict__ recs, int cnt1, int cnt0, const Cam& k, const double* x,
-                                     SweepShared<NP, WPH>& sh) {
+// barrier.  Records are sorted by label (prepare_kernel): the label-1 block and the label-0 block are swept by two
+// specialised loops.
+template <int NP, typename PT, int WPH>
+__device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Sphere* __restrict__ spheres, int cnt1, int cnt0, int nc1,
+                                     int nc0, const Cam& k, const Planes& pl, const double* x, int nocull, SweepShared<NP, WPH>& sh, int* n_active) {
     constexpr int NV = Tri<NP>::N + NP + 2;
     Rot<NP> rot;
     make_rot<NP>(x, rot);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int* queue = sh.queue[wave];
-    int n_active = 0;
     double cost = 0.0;
     double lg[NP], lA[Tri<NP>::N];
 #pragma unroll
@@ -346,8 +513,8 @@ __device__ __forceinline__ int sweep(const Rec<PT>* __restrict__ recs, int cnt1,
 #pragma unroll
     for (int i = 0; i < Tri<NP>::N; ++i) lA[i] = 0.0;
     bool bad = false;
-    sweep_range<NP, PT, WPH, U, 1>(recs, cnt1, k, x, rot, queue, cost, lg, lA, bad, n_active);
-    sweep_range<NP, PT, WPH, U, 0>(recs + cnt1, cnt0, k, x, rot, queue, cost, lg, lA, bad, n_active);
+    sweep_clusters<NP, PT, WPH, 1>(recs, cnt1, spheres, nc1, k, pl, x, rot, nocull, queue, cost, lg, lA, bad, n_active);
+    sweep_clusters<NP, PT, WPH, 0>(recs + cnt1, cnt0, spheres + nc1, nc0, k, pl, x, rot, nocull, queue, cost, lg, lA, bad, n_active);
 
     double* mine = sh.red[wave];
     double v = wave_sum(cost);
@@ -357,7 +524,6 @@ __device__ __forceinline__ int sweep(const Rec<PT>* __restrict__ recs, int cnt1,
 #pragma unroll
     for (int i = 0; i < Tri<NP>::N; ++i) { v = wave_sum(lA[i]); if (lane == 0) mine[1 + NP + i] = v; }
     if (lane == 0) mine[NV - 1] = (__any(bad) != 0) ? 1.0 : 0.0;
-    return n_active;
 }
 
 template <int NP>
@@ -549,8 +715,9 @@ __device__ void lm_after_sweep(LMState<NP>& st, bool ok, double fe, const double
     plus_proj<NP>(st.x, st.delta, tn, st.lb, st.ub, st.xe);
 }
 
-template <int NP, typename PT, int MINW, int WPH, int U>
-__global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __restrict__ packed, const int* __restrict__ counts,
+template <int NP, typename PT, int MINW, int WPH>
+__global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __restrict__ packed, const Sphere* __restrict__ spheres_all,
+                                                       int NCMAX, int nocull, const int* __restrict__ counts,
                                                        const double* __restrict__ Kmat, const double* __restrict__ init_y,
                                                        const double* __restrict__ init_T, const double* __restrict__ yaw0,
                                                        double H, double W, Bounds bnd, int max_iter, int F, int R, int N,
@@ -566,9 +733,12 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
     __shared__ SweepShared<NP, WPH> sh;
     __shared__ LMState<NP> st;
     const Rec<PT>* recs = packed + (long long)f * N;
-    const int cnt1 = counts[2 * f], cnt0 = counts[2 * f + 1];
+    const Sphere* spheres = spheres_all + (long long)f * NCMAX;
+    const int cnt1 = counts[4 * f], cnt0 = counts[4 * f + 1], nc1 = counts[4 * f + 2], nc0 = counts[4 * f + 3];
     const double* Kf = Kmat + (long long)f * 9;
     const Cam k{Kf[0], Kf[4], Kf[2], Kf[5], H - 1.0, W - 1.0};
+    const Planes pl{sqrt(k.fx * k.fx + k.cx * k.cx), sqrt(k.fx * k.fx + (k.W1 - k.cx) * (k.W1 - k.cx)),
+                    sqrt(k.fy * k.fy + k.cy * k.cy), sqrt(k.fy * k.fy + (k.H1 - k.cy) * (k.H1 - k.cy))};
     const long long hr = (long long)f * R + r;
 
     if (threadIdx.x == 0) {
@@ -582,13 +752,14 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
         st.phase = PH_INIT; st.done = 0; st.max_iter = max_iter; st.cost = 0.0; st.gmax = 0.0;
     }
     __syncthreads();
-    long long c_sweep = 0, c_wait = 0, c_lm = 0, n_act = 0;
+    long long c_sweep = 0, c_wait = 0, c_lm = 0;
+    int n_act[4] = {0, 0, 0, 0};   // wave 0: phase-B evaluations, clusters classified per point / all active / tested
     for (;;) {
         double xe[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) xe[i] = st.xe[i];
         const long long t0 = prof ? clock64() : 0;
-        n_act += sweep<NP, PT, WPH, U>(recs, cnt1, cnt0, k, xe, sh);
+        sweep<NP, PT, WPH>(recs, spheres, cnt1, cnt0, nc1, nc0, k, pl, xe, nocull, sh, n_act);
         const long long t1 = prof ? clock64() : 0;
         __syncthreads();
         const long long t2 = prof ? clock64() : 0;
@@ -608,7 +779,8 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
         if (st.done) break;
     }
     if (prof && threadIdx.x == 0) {   // diagnostics: shader-clock cycles of wave 0 per phase, phase-B evaluations of wave 0
-        prof[hr * 4 + 0] = c_sweep; prof[hr * 4 + 1] = c_wait; prof[hr * 4 + 2] = c_lm; prof[hr * 4 + 3] = n_act;
+        prof[hr * 8 + 0] = c_sweep; prof[hr * 8 + 1] = c_wait; prof[hr * 8 + 2] = c_lm; prof[hr * 8 + 3] = n_act[0];
+        prof[hr * 8 + 4] = n_act[1]; prof[hr * 8 + 5] = n_act[2]; prof[hr * 8 + 6] = n_act[3]; prof[hr * 8 + 7] = 0;
     }
     if (threadIdx.x == 0) {
         for (int i = 0; i < NP; ++i) params_out[hr * NP + i] = st.x[i];
@@ -789,32 +961,52 @@ __global__ __launch_bounds__(256) void residuals_kernel(const double* __restrict
 
 static long long* g_prof = nullptr;   // diagnostics hook, see di2p_solver_set_profile_buffer
 
+struct SolveWs { int P, NCMAX; size_t off_recs, off_spheres, off_keys, bytes; };
+static SolveWs solve_ws_layout(int F, int N) {
+    SolveWs w;
+    w.P = 64;
+    while (w.P < N) w.P <<= 1;
+    w.NCMAX = (N + CL - 1) / CL + 2;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    w.off_recs = up((size_t)F * 4 * sizeof(int));
+    w.off_spheres = up(w.off_recs + (size_t)F * N * 32);
+    w.off_keys = up(w.off_spheres + (size_t)F * w.NCMAX * sizeof(Sphere));
+    w.bytes = up(w.off_keys + (size_t)F * w.P * 8) + 256;
+    return w;
+}
+
 template <typename PT>
 int launch_solve(const PT* points, const int* labels, const double* K, const double* init_y, const double* init_T,
                  const double* yaw0, double H, double W, const double* lb, const double* ub, int max_iter, int is_2d, int F,
                  int R, int N, double* params, double* cost, int* iters, int* sweeps, void* workspace, hipStream_t st) {
     Bounds b;
     for (int i = 0; i < 3; ++i) { b.lb[i] = lb[i]; b.ub[i] = ub[i]; }
-    int* counts = (int*)workspace;
-    Rec<PT>* packed = (Rec<PT>*)((char*)workspace + (((size_t)F * 2 * sizeof(int) + 255) & ~(size_t)255));
-    hipLaunchKernelGGL(pack_kernel<PT>, dim3(F), dim3(256), 0, st, points, labels, N, packed, counts);
-    // DI2P_SOLVER_CFG=<waves per hypothesis><records per lane per batch><min waves/SIMD>, e.g. 443 (default)
-    static int cfg = -1;
-    if (cfg < 0) { const char* e = getenv("DI2P_SOLVER_CFG"); cfg = e ? atoi(e) : 443; }
+    // workspace: counts i32[F][4] | records Rec[F][N] | spheres [F][NCMAX] | sort keys u64[F][P]
+    const SolveWs ws = solve_ws_layout(F, N);
+    char* base = (char*)workspace;
+    int* counts = (int*)base;
+    Rec<PT>* packed = (Rec<PT>*)(base + ws.off_recs);
+    Sphere* spheres = (Sphere*)(base + ws.off_spheres);
+    unsigned long long* keys = (unsigned long long*)(base + ws.off_keys);
+    hipLaunchKernelGGL(prepare_kernel<PT>, dim3(F), dim3(1024), 0, st, points, labels, N, ws.P, ws.NCMAX, keys, packed, spheres, counts);
+    // DI2P_SOLVER_CFG=<waves per hypothesis><min waves/SIMD>, e.g. 43 (default); DI2P_SOLVER_NOCULL=1 classifies every
+    // cluster per point (the sums are bit-identical by construction: tests compare the two)
+    static int cfg = -1, nocull = -1;
+    if (cfg < 0) { const char* e = getenv("DI2P_SOLVER_CFG"); cfg = e ? atoi(e) : 43; }
+    { const char* e = getenv("DI2P_SOLVER_NOCULL"); nocull = e ? atoi(e) : 0; }
     const dim3 grid(R * F);
-#define DI2P_LAUNCH_SOLVE(NPV, MW, WP, UU) hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP, UU>), grid, dim3(WP * 64), 0, st, packed, counts, K, init_y, init_T, yaw0, H, W, b, max_iter, F, R, N, params, cost, iters, sweeps, g_prof)
+#define DI2P_LAUNCH_SOLVE(NPV, MW, WP) hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP>), grid, dim3(WP * 64), 0, st, packed, spheres, ws.NCMAX, nocull, counts, K, init_y, init_T, yaw0, H, W, b, max_iter, F, R, N, params, cost, iters, sweeps, g_prof)
     if (is_2d) {
         switch (cfg) {
-            case 442: DI2P_LAUNCH_SOLVE(4, 2, 4, 4); break;
-            case 423: DI2P_LAUNCH_SOLVE(4, 3, 4, 2); break;
-            case 822: DI2P_LAUNCH_SOLVE(4, 2, 8, 2); break;
-            case 842: DI2P_LAUNCH_SOLVE(4, 2, 8, 4); break;
-            case 824: DI2P_LAUNCH_SOLVE(4, 4, 8, 2); break;
-            case 1624: DI2P_LAUNCH_SOLVE(4, 4, 16, 2); break;
-            default: DI2P_LAUNCH_SOLVE(4, 3, 4, 4); break;
+            case 42: DI2P_LAUNCH_SOLVE(4, 2, 4); break;
+            case 44: DI2P_LAUNCH_SOLVE(4, 4, 4); break;
+            case 23: DI2P_LAUNCH_SOLVE(4, 3, 2); break;
+            case 24: DI2P_LAUNCH_SOLVE(4, 4, 2); break;
+            case 82: DI2P_LAUNCH_SOLVE(4, 2, 8); break;
+            default: DI2P_LAUNCH_SOLVE(4, 3, 4); break;
         }
     } else {
-        DI2P_LAUNCH_SOLVE(6, 2, 4, 2);
+        DI2P_LAUNCH_SOLVE(6, 2, 4);
     }
 #undef DI2P_LAUNCH_SOLVE
     return 0;
@@ -873,9 +1065,11 @@ extern "C" int di2p_solver_residuals(const double* points, const int32_t* labels
 }
 
 extern "C" long long di2p_solve_workspace_bytes(int F, int N) {
-    return (((long long)F * 8 + 255) & ~255ll) + (long long)F * N * 32 + 256;
+    if (F < 0 || N < 0) return 0;
+    return (long long)solve_ws_layout(F, N).bytes;
 }
 
-// Diagnostics: when set to a device buffer of F*R*4 int64, every solve launch records per hypothesis the shader-clock
-// cycles wave 0 spent in {sweep, waiting at the reduction barrier, LM update} and its number of phase-B evaluations.
+// Diagnostics: when set to a device buffer of F*R*8 int64, every solve launch records per hypothesis the shader-clock
+// cycles wave 0 spent in {sweep, waiting at the reduction barrier, LM update}, its number of phase-B evaluations, and
+// its clusters {classified per point, taken as all-active, tested}.
 extern "C" void di2p_solver_set_profile_buffer(void* buf) { g_prof = (long long*)buf; }

@@ -184,7 +184,7 @@ int di2p_solve_batched_f32(const float* points, const int32_t* labels, const dou
                            int max_iter, int is_2d, int F, int R, int N,
                            double* params, double* cost, int32_t* iters, int32_t* sweeps /* may be NULL: #passes over the points */, void* workspace, void* stream);
 long long di2p_solve_workspace_bytes(int F, int N);
-/* diagnostics only: device buffer of F*R*4 int64 (or NULL) receiving per-hypothesis phase cycle counts */
+/* diagnostics only: device buffer of F*R*8 int64 (or NULL) receiving per-hypothesis phase cycle counts and cluster statistics */
 void di2p_solver_set_profile_buffer(void* buf);
 int di2p_select_best(const double* params, const double* cost, const int32_t* has_inside, int is_2d,
                      int F, int R, int32_t* best, double* P, double* best_cost, void* stream);

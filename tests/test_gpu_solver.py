@@ -83,6 +83,53 @@ def test_solver_matches_oracle_per_hypothesis(dev, is_2d, N, R):
     assert np.all(par_g[:, toff:] >= np.array(LB) - 1e-12) and np.all(par_g[:, toff:] <= np.array(UB) + 1e-12)
 
 
+@pytest.mark.parametrize("is_2d,use_f32", [(True, True), (True, False), (False, False)])
+def test_cluster_culling_is_exact(dev, is_2d, use_f32):
+    """The frustum-plane test of whole 64-point clusters must never change a result: with DI2P_SOLVER_NOCULL=1 every
+    cluster is classified point by point, and params / cost / iteration and sweep counts have to be BIT-identical.
+    The frame mixes a synthetic scan with adversarial points: exactly on the frustum planes of the initial poses,
+    on the camera plane, duplicated, far away, and labels outside {0,1}."""
+    import os
+    from deepi2p_amd import ops
+    f, rng = _frame(21, 6000)
+    pts, lab = f["pc"].astype(np.float64).copy(), f["labels"].astype(np.int32).copy()
+    K = f["K"]
+    n_adv = 600
+    z = rng.uniform(0.5, 60, n_adv)
+    side = rng.integers(0, 5, n_adv)
+    x = np.where(side == 0, (0 - K[0, 2]) * z / K[0, 0], np.where(side == 1, (W - 1 - K[0, 2]) * z / K[0, 0], rng.uniform(-40, 40, n_adv)))
+    y = np.where(side == 2, (0 - K[1, 2]) * z / K[1, 1], np.where(side == 3, (H - 1 - K[1, 2]) * z / K[1, 1], rng.uniform(-2, 2, n_adv)))
+    z = np.where(side == 4, 0.0, z)
+    pts[:, :n_adv] = np.stack((x, y, z))
+    pts[:, n_adv:n_adv + 50] = pts[:, n_adv + 50:n_adv + 100]           # duplicates
+    pts[:, n_adv + 100:n_adv + 110] *= 1e3                              # far outliers (huge cluster radii)
+    lab[:n_adv] = rng.integers(0, 2, n_adv)
+    lab[::37] = 2
+    if use_f32:
+        pts = pts.astype(np.float32).astype(np.float64)
+    R = 16
+    ys = np.concatenate(([0.0, 0.0], rng.normal(0, 0.3, R - 2)))
+    Ts = np.concatenate((np.zeros((2, 3)), rng.uniform(-3, 3, (R - 2, 3))))      # hypotheses 0/1: points sit ON the planes
+    Ts[:, 1] = np.clip(Ts[:, 1], -0.1, 0.1)
+    tp = torch.from_numpy(pts.astype(np.float32) if use_f32 else pts).to(dev).unsqueeze(0)
+    args = (tp, torch.from_numpy(lab).to(dev).unsqueeze(0), torch.from_numpy(K).to(dev).view(1, 3, 3),
+            torch.from_numpy(ys).to(dev).view(1, R), torch.from_numpy(Ts).to(dev).view(1, R, 3), H, W, LB, UB, 60, is_2d)
+
+    def run():
+        sweeps = torch.zeros((1, R), dtype=torch.int32, device=dev)
+        params, cost, iters = ops.solve_batched(*args, sweeps=sweeps)
+        return params.cpu().numpy(), cost.cpu().numpy(), iters.cpu().numpy(), sweeps.cpu().numpy()
+    a = run()
+    os.environ["DI2P_SOLVER_NOCULL"] = "1"
+    try:
+        b = run()
+    finally:
+        del os.environ["DI2P_SOLVER_NOCULL"]
+    for u, v in zip(a, b):
+        assert u.tobytes() == v.tobytes()        # bit-identical, NaN-safe
+    assert np.isfinite(a[1]).sum() >= R - 4      # the planted on-plane points may fail hypotheses 0/1 only
+
+
 def test_solvePGivenK_drop_in(dev):
     """Reference call signature and return triple (registration.cpp:190-206)."""
     from deepi2p_amd import FrustumRegistration

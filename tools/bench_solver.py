@@ -25,18 +25,19 @@ for name, lab_np in (("noisy-gt", np.stack([f["labels"] for f in frames])),):
     kept = (lab_front >= 0).sum(1).float().mean().item()
     if os.environ.get("PROF"):
         from deepi2p_amd import _lib
-        prof = torch.zeros((F, R, 4), dtype=torch.int64, device=dev)
+        prof = torch.zeros((F, R, 8), dtype=torch.int64, device=dev)
         _lib.load().di2p_solver_set_profile_buffer(prof.data_ptr())
         ops.solve_batched(pc, lab_front, K, restarts[0], restarts[1], H, W, pipe.lb, pipe.ub, 500, True, yaw0=yaw0, sweeps=sweeps)
         torch.cuda.synchronize()
         _lib.load().di2p_solver_set_profile_buffer(None)
-        p = prof.double().cpu().numpy().reshape(-1, 4); sw = sweeps.cpu().numpy().reshape(-1)
+        p = prof.double().cpu().numpy().reshape(-1, 8); sw = sweeps.cpu().numpy().reshape(-1)
         tot = p[:, :3].sum(1)
         print("  per-sweep cycles (mean over hyps): sweep %.0f  barrier-wait %.0f  LM %.0f ; active evals/sweep (wave0) %.1f of %d records/wave"
               % ((p[:, 0] / sw).mean(), (p[:, 1] / sw).mean(), (p[:, 2] / sw).mean(), (p[:, 3] / sw).mean(), kept / 4))
+        print("  clusters per sweep (wave 0): tested %.1f  per-point %.1f  all-active %.1f" % ((p[:, 6] / sw).mean(), (p[:, 4] / sw).mean(), (p[:, 5] / sw).mean()))
         i = int(np.argmax(sw))
         print("  slowest hyp: sweeps %d cycles total %.3g (sweep %.3g wait %.3g lm %.3g) active/sweep %.1f" % (sw[i], tot[i], p[i, 0], p[i, 1], p[i, 2], p[i, 3] / sw[i]))
         print("  sum over hyps of block cycles %.3g ; max %.3g" % (tot.sum(), tot.max()))
     print("%s CFG=%s: %.2f ms  iters mean %.1f max %d  sweeps mean %.1f max %d  kept pts %.0f  -> %.1f us/sweep/hyp-wave" % (
-        name, os.environ.get("DI2P_SOLVER_CFG", "443"), dt * 1e3, iters.float().mean().item(), iters.max().item(),
+        name, os.environ.get("DI2P_SOLVER_CFG", "43"), dt * 1e3, iters.float().mean().item(), iters.max().item(),
         sweeps.float().mean().item(), sweeps.max().item(), kept, dt * 1e6 / max(sweeps.float().mean().item(), 1)))
