@@ -38,9 +38,15 @@ struct LoaderIm2col {
     __device__ __forceinline__ float load(int k) const {
         k = __builtin_amdgcn_readfirstlane(k);
         if (!valid || k >= K) return 0.0f;
-        const int khw = KH * KW;
-        const int ci = k / khw, rem = k - ci * khw;
-        const int kh = rem / KW, kw = rem - kh * KW;
+        int ci, kh, kw;
+        if (KH == 7 && KW == 7) {            // the ResNet stem: divisions by constants
+            ci = k / 49; const int rem = k - ci * 49; kh = rem / 7; kw = rem - kh * 7;
+        } else if (KH == 3 && KW == 3) {
+            ci = k / 9; const int rem = k - ci * 9; kh = rem / 3; kw = rem - kh * 3;
+        } else {
+            const int khw = KH * KW;
+            ci = k / khw; const int rem = k - ci * khw; kh = rem / KW; kw = rem - kh * KW;
+        }
         const int ih = ih0 + kh, iw = iw0 + kw;
         if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) return 0.0f;
         return xb[((long long)ci * H + ih) * W + iw];
@@ -341,6 +347,7 @@ extern "C" int di2p_conv2d(const float* x, const float* Wt, const float* scale, 
     if (novec < 0) { const char* e = getenv("DI2P_CONV_NOVEC"); novec = e ? atoi(e) : 0; }
     const bool vec = !novec && use32 && OW % 4 == 0 && Cout % 4 == 0 && ((uintptr_t)Wt & 15) == 0 &&
                      ((stride == 1 && pad <= 1 && KW <= 2 * pad + 1 && W >= 4) || stride == 2);
+    if (vec && force < 0) choice = Cout <= 64 ? 1 : 0;   // measured: 64x64 tiles (more, smaller workgroups) win for Cout >= 128
 #define DI2P_CONVV(CFG) launch_conv_vec<CFG>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, st)
     if (vec) {
         switch (choice) { case 3: DI2P_CONVV(CfgC128x128k32); break; case 2: DI2P_CONVV(CfgC128x64k32); break;

@@ -58,12 +58,15 @@ struct LoaderConcat {
     }
 };
 
-// 16-byte stager for the common case: every source DENSE, 4 consecutive columns per lane.  Loads are UNCONDITIONAL
-// from clamped addresses (no control flow in the K-loop): rows k >= K meet zero weights (clamping k re-reads real,
-// column-local data), columns n >= N are dropped by the epilogue.  The source of a row is picked with selects.
+// 4-column stager.  Loads are UNCONDITIONAL from clamped addresses (no control flow in the K-loop): rows k >= K meet
+// zero weights (clamping k re-reads real, column-local data), columns n >= N are dropped by the epilogue.  The source
+// of a row is picked with selects.  DENSE: every source is DENSE and 16-byte addressable -> one 16-byte load per row;
+// otherwise four dword loads at per-source column offsets (dense n, gathered gidx[n], group n/group).
+template <bool DENSE>
 struct LoaderConcat4 {
     const float* base[DI2P_MAX_SRC];
     int rs[DI2P_MAX_SRC];
+    int off[DENSE ? 1 : DI2P_MAX_SRC][4];
     int c0, c1, K;          // channel range ends of source 0 / 1 (== K when absent)
     SrcDev s;
     int b, N;
@@ -72,8 +75,17 @@ struct LoaderConcat4 {
 #pragma unroll
         for (int i = 0; i < DI2P_MAX_SRC; ++i) {
             const int j = i < s.n_src ? i : 0;
-            base[i] = s.ptr[j] + (long long)b * s.batch_stride[j] + nc;
+            base[i] = s.ptr[j] + (long long)b * s.batch_stride[j] + (DENSE ? nc : 0);
             rs[i] = s.row_stride[j];
+            if (!DENSE) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int o = nc + q;
+                    if (s.mode[j] == DI2P_SRC_GATHER) o = s.gidx[j][(long long)b * N + nc + q];
+                    else if (s.mode[j] == DI2P_SRC_GROUP) o = (nc + q) / s.group[j];
+                    off[DENSE ? 0 : i][q] = o;
+                }
+            }
         }
         c0 = s.c_end[0];
         c1 = s.n_src > 1 ? s.c_end[1] : K;
@@ -85,7 +97,12 @@ struct LoaderConcat4 {
         const float* p = s2 ? base[2] : (s1 ? base[1] : base[0]);
         const int kk = kc - (s2 ? c1 : (s1 ? c0 : 0));
         const int r = s2 ? rs[2] : (s1 ? rs[1] : rs[0]);
-        return *reinterpret_cast<const float4*>(p + kk * r);      // kk*r < 2^31 (host-checked)
+        p += kk * r;                                                  // kk*r < 2^31 (host-checked)
+        if (DENSE) return *reinterpret_cast<const float4*>(p);
+        constexpr int L = DENSE ? 0 : 1, H = DENSE ? 0 : 2;
+        const int o0 = s2 ? off[H][0] : (s1 ? off[L][0] : off[0][0]), o1 = s2 ? off[H][1] : (s1 ? off[L][1] : off[0][1]);
+        const int o2 = s2 ? off[H][2] : (s1 ? off[L][2] : off[0][2]), o3 = s2 ? off[H][3] : (s1 ? off[L][3] : off[0][3]);
+        return make_float4(p[o0], p[o1], p[o2], p[o3]);
     }
     __device__ __forceinline__ void fix(float4&, int) const {}
 };
@@ -131,7 +148,7 @@ struct EpiPointwise {
                 for (int j = 0; j < 4; ++j)
                     if (j < e.g_k) {
                         const int gi = e.g_idx[t][((long long)b * N + nc) * e.g_k + j];
-                        const float gw = e.g_w[t][((long long)b * N + nc) * e.g_k + j];
+                        const float gw = e.g_w[t] ? e.g_w[t][((long long)b * N + nc) * e.g_k + j] : 1.0f;
                         const float* gp = gt + (long long)gi * M;
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
@@ -191,12 +208,12 @@ __global__ __launch_bounds__(Cfg::THREADS) void pointwise_gemm_kernel(SrcDev src
     mfma_gemm_block<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
 }
 
-template <class Cfg>
+template <class Cfg, bool DENSE>
 __global__ __launch_bounds__(Cfg::THREADS) void pointwise_gemm_vec_kernel(SrcDev srcs, const float* __restrict__ Wt, float* __restrict__ Y,
                                                                            int M, int K, int N, EpiDev epi) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     LoaderWt4 la{Wt, K, M};
-    LoaderConcat4 lb;
+    LoaderConcat4<DENSE> lb;
     lb.s = srcs;
     lb.b = blockIdx.z;
     lb.N = N;
@@ -277,9 +294,12 @@ void launch_pw(const SrcDev& s, const float* Wt, float* Y, int B, int M, int K, 
 }
 
 template <class Cfg>
-void launch_pw_vec(const SrcDev& s, const float* Wt, float* Y, int B, int M, int K, int N, const EpiDev& e, hipStream_t st) {
+void launch_pw_vec(bool dense, const SrcDev& s, const float* Wt, float* Y, int B, int M, int K, int N, const EpiDev& e, hipStream_t st) {
     const dim3 grid(di2p_cdiv(N, Cfg::BN), di2p_cdiv(M, Cfg::BM), B);
-    hipLaunchKernelGGL(pointwise_gemm_vec_kernel<Cfg>, grid, dim3(Cfg::THREADS), Cfg::LDS_FLOATS * sizeof(float), st, s, Wt, Y, M, K, N, e);
+    if (dense)
+        hipLaunchKernelGGL((pointwise_gemm_vec_kernel<Cfg, true>), grid, dim3(Cfg::THREADS), Cfg::LDS_FLOATS * sizeof(float), st, s, Wt, Y, M, K, N, e);
+    else
+        hipLaunchKernelGGL((pointwise_gemm_vec_kernel<Cfg, false>), grid, dim3(Cfg::THREADS), Cfg::LDS_FLOATS * sizeof(float), st, s, Wt, Y, M, K, N, e);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -330,14 +350,16 @@ extern "C" int di2p_pointwise_gemm(const di2p_src_t* srcs, int n_src, const floa
         DI2P_CHECK_ARG((g & (g - 1)) == 0 && g <= 32 && N % g == 0, "group_max must be a power of two <= 32 dividing N");
     }
     hipStream_t st = (hipStream_t)stream;
-    // 16-byte staged path: all sources dense and 16-byte addressable in 4-column groups
-    bool vec = N % 4 == 0 && N >= 4 && M % 4 == 0 && aligned16(Wt) && getenv("DI2P_PW_NOVEC") == nullptr;
-    for (int i = 0; i < n_src && vec; ++i)
-        vec = srcs[i].mode == DI2P_SRC_DENSE && srcs[i].row_stride % 4 == 0 && srcs[i].batch_stride % 4 == 0 && aligned16(srcs[i].ptr);
+    // 4-column staged path (weights 16-byte addressable, whole 4-column groups); sources that are all dense and 16-byte
+    // addressable get one 16-byte load per row, gathered / group sources four dword loads
+    const bool vec = N % 4 == 0 && N >= 4 && M % 4 == 0 && aligned16(Wt) && getenv("DI2P_PW_NOVEC") == nullptr;
+    bool dense = true;
+    for (int i = 0; i < n_src; ++i)
+        dense = dense && srcs[i].mode == DI2P_SRC_DENSE && srcs[i].row_stride % 4 == 0 && srcs[i].batch_stride % 4 == 0 && aligned16(srcs[i].ptr);
     if (vec) {
-        if (M <= 32) launch_pw_vec<TileCfg<1, 4, 1, 1, 32>>(s, Wt, Y, B, M, K, N, e, st);
-        else if (M <= 64 || (long long)B * di2p_cdiv(N, 128) * di2p_cdiv(M, 128) < 256) launch_pw_vec<TileCfg<2, 2, 1, 2, 32>>(s, Wt, Y, B, M, K, N, e, st);
-        else launch_pw_vec<TileCfg<2, 2, 2, 2, 32>>(s, Wt, Y, B, M, K, N, e, st);
+        if (M <= 32) launch_pw_vec<TileCfg<1, 4, 1, 1, 32>>(dense, s, Wt, Y, B, M, K, N, e, st);
+        else if (M <= 64 || (long long)B * di2p_cdiv(N, 128) * di2p_cdiv(M, 128) < 256) launch_pw_vec<TileCfg<2, 2, 1, 2, 32>>(dense, s, Wt, Y, B, M, K, N, e, st);
+        else launch_pw_vec<TileCfg<2, 2, 2, 2, 32>>(dense, s, Wt, Y, B, M, K, N, e, st);
         DI2P_RETURN_LAUNCH();
     }
     if (M <= 32) launch_pw<Cfg32x128>(s, Wt, Y, B, M, K, N, e, st);

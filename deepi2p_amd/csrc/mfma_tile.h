@@ -185,13 +185,7 @@ __device__ __forceinline__ void mfma_gemm_block_vec(float* lds, LoaderA& la, Loa
     gload(0);
     lstore(0);
     __syncthreads();
-    for (int t = 0; t < T; ++t) {
-        const int buf = t & 1;
-        // Branch-free loop body (the last step loads one tile too many from clamped addresses; it is stored to the idle
-        // buffer and never read).  The scheduling fences pin the global loads AHEAD of the MFMA phase and their first
-        // use (fix + ds_write) BEHIND it, so the L2/HBM latency of step t+1 hides under the MFMAs of step t.
-        gload(t + 1);
-        __builtin_amdgcn_sched_barrier(0);
+    auto compute = [&](int buf) {
         const float* Ab = As + buf * BK * BM + wm * Cfg::TM * 32 + l31;
         const float* Bb = Bs + buf * BK * BN + wn * Cfg::TN * 32 + l31;
         // operand fragments double-buffered in registers: the ds_reads of k-pair kk+1 are in flight under the MFMAs of kk
@@ -213,10 +207,20 @@ __device__ __forceinline__ void mfma_gemm_block_vec(float* lds, LoaderA& la, Loa
                 for (int j = 0; j < Cfg::TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
         }
+    };
+    // Steady state: branch-free body.  The scheduling fences pin the global loads of step t+1 AHEAD of the MFMA phase of
+    // step t and their first use (fix + ds_write) BEHIND it, so the L2/HBM latency hides under the MFMAs; without them
+    // hipcc either waits for the loads right away or sinks them below the MFMAs.  The last K-step is peeled (no loads).
+    for (int t = 0; t + 1 < T; ++t) {
+        const int buf = t & 1;
+        gload(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(buf);
         __builtin_amdgcn_sched_barrier(0);
         lstore(buf ^ 1);
         __syncthreads();
     }
+    compute((T - 1) & 1);
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll

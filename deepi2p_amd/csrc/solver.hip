@@ -99,11 +99,11 @@ template <> struct __attribute__((aligned(16))) Rec<double> { double x, y, z; lo
 //   1. records with label 0/1 are sorted by (label: 1 first, Morton code of the (x,z) ground-plane cell) with an
 //      in-workgroup bitonic sort on unique 64-bit keys (key << 32 | point index): deterministic, data-independent
 //      network, 64 KB LDS chunks with the wide strides done in the (L2-resident) global scratch;
-//   2. consecutive groups of CL = 64 sorted records of one label form a CLUSTER with a bounding sphere.
-// The solver's sweeps test each sphere against the five planes of the camera frustum of the current iterate and
-// classify the points of a cluster individually only when the sphere touches a plane (see sweep_clusters).
+//   2. consecutive groups of CL = 64 sorted records of one label form a CLUSTER with an axis-aligned bounding box.
+// The solver's sweeps test each box against the five planes of the camera frustum of the current iterate and
+// classify the points of a cluster individually only when the box touches a plane (see sweep_clusters).
 constexpr int CL = 64;
-struct __attribute__((aligned(16))) Sphere { double cx, cy, cz, r; };
+struct __attribute__((aligned(16))) Box { double cx, cy, cz, hx, hy, hz; };   // axis-aligned bounds of a cluster (centre, half extents)
 
 __device__ __forceinline__ unsigned spread10(unsigned v) {
     v &= 0x3ffu;
@@ -114,7 +114,7 @@ __device__ __forceinline__ unsigned spread10(unsigned v) {
 template <typename PT>
 __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ points, const int* __restrict__ labels, int N, int P,
                                                        int NCMAX, unsigned long long* __restrict__ keys_all,
-                                                       Rec<PT>* __restrict__ packed, Sphere* __restrict__ spheres_all,
+                                                       Rec<PT>* __restrict__ packed, Box* __restrict__ boxes_all,
                                                        int* __restrict__ counts) {
     constexpr int CH = 8192;                       // LDS chunk (64 KB)
     __shared__ unsigned long long chunk[CH];
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ po
     const int* lab = labels + (long long)f * N;
     unsigned long long* keys = keys_all + (long long)f * P;
     Rec<PT>* out = packed + (long long)f * N;
-    Sphere* spheres = spheres_all + (long long)f * NCMAX;
+    Box* boxes = boxes_all + (long long)f * NCMAX;
 
     // 1. ground-plane bounding box of the valid points, label counts (fixed-order reductions)
     float mnx = __builtin_inff(), mxx = -__builtin_inff(), mnz = __builtin_inff(), mxz = -__builtin_inff();
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ po
     }
     __syncthreads();
 
-    // 5. bounding spheres: one wavefront per cluster
+    // 5. bounding boxes: one wavefront per cluster
     const int nc1 = (n1 + CL - 1) / CL, nc0 = (n0 + CL - 1) / CL;
     for (int c = wave; c < nc1 + nc0; c += 16) {
         const int start = c < nc1 ? c * CL : n1 + (c - nc1) * CL;
@@ -239,18 +239,16 @@ __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ po
         for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
             for (int a = 0; a < 3; ++a) { lo[a] = fmin(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmax(hi[a], __shfl_xor(hi[a], o)); }
-        const double cx = 0.5 * (lo[0] + hi[0]), cy = 0.5 * (lo[1] + hi[1]), cz = 0.5 * (lo[2] + hi[2]);
-        double d2 = valid ? (x - cx) * (x - cx) + (y - cy) * (y - cy) + (z - cz) * (z - cz) : 0.0;
-        // a NaN coordinate must poison the radius (fmax would drop it): such clusters are always classified per point
-        bool nan_any = valid && !(d2 == d2);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) d2 = fmax(d2, __shfl_xor(d2, o));
-        nan_any = __any(nan_any) != 0;
+        // a NaN coordinate must poison the box (fmin/fmax drop it): such clusters are always classified per point
+        const bool nan_any = __any(valid && !(x == x && y == y && z == z)) != 0;
         if (lane == 0) {
-            Sphere sp;
-            sp.cx = cx; sp.cy = cy; sp.cz = cz;
-            sp.r = nan_any ? __builtin_nan("") : sqrt(d2) * (1.0 + 1e-12);
-            spheres[c] = sp;
+            Box bx;
+            bx.cx = 0.5 * (lo[0] + hi[0]); bx.cy = 0.5 * (lo[1] + hi[1]); bx.cz = 0.5 * (lo[2] + hi[2]);
+            const double grow = 1.0 + 1e-12;     // the rounded centre +- half extent must still contain lo and hi
+            bx.hx = nan_any ? __builtin_nan("") : 0.5 * (hi[0] - lo[0]) * grow + 1e-300;
+            bx.hy = 0.5 * (hi[1] - lo[1]) * grow + 1e-300;
+            bx.hz = 0.5 * (hi[2] - lo[2]) * grow + 1e-300;
+            boxes[c] = bx;
         }
     }
     if (tid == 0) { counts[4 * f] = n1; counts[4 * f + 1] = n0; counts[4 * f + 2] = nc1; counts[4 * f + 3] = nc0; }
@@ -387,45 +385,68 @@ __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& ro
 //   p2 > 0     <=> f_Z = p2 > 0.
 struct Planes { double nL, nR, nT, nB; };
 
-// Cluster test.  A sphere (centre c, radius r) lies strictly on one side of plane i iff |f_i(c)| > (r + delta)*|n_i|.
-// If that holds for ALL five planes, every point of the cluster has the same sign pattern as the centre, none of
-// dx, dy, p2 is zero or non-finite, and the per-point classification of phase A is known without evaluating it:
+// Cluster test.  The axis-aligned box (centre c, half extents h) of a cluster, moved by the iterate (R, t), lies
+// strictly on one side of plane i iff |f_i(Rc + t)| > sum_j |(n_i^T R)_j| h_j + delta*|n_i|  (support function of the
+// rotated box).  If that holds for ALL five planes, every point of the cluster has the sign pattern of the centre,
+// none of dx, dy, p2 is zero or non-finite, and the per-point classification of phase A is known without evaluating it:
 //   label 1: inactive iff all five are positive, else every point is active;
 //   label 0: active   iff all five are positive, else every point is inactive (and cannot raise `bad`).
 // delta = 1e-9*(1+|p|) exceeds the rounding error of the per-point pixel test (~1e-13 of the same scale) by four
 // orders of magnitude, so the shortcut never disagrees with the exact test; NaN/inf anywhere fails every
-// comparison and falls back to the per-point path.  Returns 0: skip, 1: classify per point, 2: all active.
+// comparison and falls back to the per-point path.
+// Returns 0: skip, 1: classify per point, 2: all active.
 template <int NP, int LAB>
-__device__ __forceinline__ int cluster_status(const Sphere& sp, const Rot<NP>& rot, double tx, double ty, double tz, const Cam& k,
+__device__ __forceinline__ int cluster_status(const Box& bx, const Rot<NP>& rot, double tx, double ty, double tz, const Cam& k,
                                               const Planes& pl) {
-    double qx, qy, qz;
+    const double* R = rot.R;
+    double p0, p1, p2;
     if (NP == 4) {
-        qx = rot.R[0] * sp.cx + rot.R[2] * sp.cz; qy = sp.cy; qz = rot.R[6] * sp.cx + rot.R[8] * sp.cz;
+        p0 = R[0] * bx.cx + R[2] * bx.cz + tx; p1 = bx.cy + ty; p2 = R[6] * bx.cx + R[8] * bx.cz + tz;
     } else {
-        qx = rot.R[0] * sp.cx + rot.R[1] * sp.cy + rot.R[2] * sp.cz;
-        qy = rot.R[3] * sp.cx + rot.R[4] * sp.cy + rot.R[5] * sp.cz;
-        qz = rot.R[6] * sp.cx + rot.R[7] * sp.cy + rot.R[8] * sp.cz;
+        p0 = R[0] * bx.cx + R[1] * bx.cy + R[2] * bx.cz + tx;
+        p1 = R[3] * bx.cx + R[4] * bx.cy + R[5] * bx.cz + ty;
+        p2 = R[6] * bx.cx + R[7] * bx.cy + R[8] * bx.cz + tz;
     }
-    const double p0 = qx + tx, p1 = qy + ty, p2 = qz + tz;
-    const double thr = sp.r + 1e-9 * (1.0 + fabs(p0) + fabs(p1) + fabs(p2));
+    const double delta = 1e-9 * (1.0 + fabs(p0) + fabs(p1) + fabs(p2));
+    // plane normals n = a*e0 + b*e1 + c*e2 in camera coordinates -> world components (n^T R)_j = a R0j + b R1j + c R2j
+    auto support = [&](double a, double b, double c, double nrm) {
+        double sj;
+        if (NP == 4) {      // R = [[c,0,s],[0,1,0],[-s,0,c]]
+            sj = fabs(a * R[0] + c * R[6]) * bx.hx + fabs(b) * bx.hy + fabs(a * R[2] + c * R[8]) * bx.hz;
+        } else {
+            sj = fabs(a * R[0] + b * R[3] + c * R[6]) * bx.hx + fabs(a * R[1] + b * R[4] + c * R[7]) * bx.hy +
+                 fabs(a * R[2] + b * R[5] + c * R[8]) * bx.hz;
+        }
+        return sj + delta * nrm;
+    };
     const double fL = k.fx * p0 + k.cx * p2, fR = -k.fx * p0 + (k.W1 - k.cx) * p2;
     const double fT = k.fy * p1 + k.cy * p2, fB = -k.fy * p1 + (k.H1 - k.cy) * p2;
-    const double tL = thr * pl.nL, tR = thr * pl.nR, tT = thr * pl.nT, tB = thr * pl.nB;
-    const bool pL = fL > tL, pR = fR > tR, pT = fT > tT, pB = fB > tB, pZ = p2 > thr;
-    const bool certified = (pL || fL < -tL) && (pR || fR < -tR) && (pT || fT < -tT) && (pB || fB < -tB) && (pZ || p2 < -thr);
-    if (!certified) return 1;
-    const bool inside = pL && pR && pT && pB && pZ;
-    return (LAB == 1) ? (inside ? 0 : 2) : (inside ? 2 : 0);
+    const double tL = support(k.fx, 0.0, k.cx, pl.nL), tR = support(-k.fx, 0.0, k.W1 - k.cx, pl.nR);
+    const double tT = support(0.0, k.fy, k.cy, pl.nT), tB = support(0.0, -k.fy, k.H1 - k.cy, pl.nB);
+    const double tZ = support(0.0, 0.0, 1.0, 1.0);
+    const bool pL = fL > tL, pR = fR > tR, pT = fT > tT, pB = fB > tB, pZ = p2 > tZ;
+    const bool cL = pL || fL < -tL, cR = pR || fR < -tR, cT = pT || fT < -tT, cB = pB || fB < -tB, cZ = pZ || p2 < -tZ;
+    if (cL && cR && cT && cB && cZ) {
+        const bool inside = pL && pR && pT && pB && pZ;
+        return (LAB == 1) ? (inside ? 0 : 2) : (inside ? 2 : 0);
+    }
+    // a certified negative plane already decides every point: not inside.  Label 1: all active.  Label-0 points of such a
+    // cluster may still sit exactly on one of the touched planes (dx, dy or p2 == 0 is an evaluation failure in the
+    // reference), so label 0 keeps the per-point path.
+    if (LAB == 1 && ((cL && !pL) || (cR && !pR) || (cT && !pT) || (cB && !pB) || (cZ && !pZ))) return 2;
+    return 1;
 }
 
 // One label-uniform block of records [recs, recs+cnt) = nc clusters of CL records.  Cluster c belongs to wave
 // c % WPH (neighbouring clusters -- which tend to share their status -- spread over the waves).  Per round a lane
-// tests one cluster; the wave then walks the flagged ones: status 1 -> phase A (exact fp64 classification) on its 64
-// records, status 2 -> all 64 are active; active ids go to the per-wave LDS queue and are evaluated densely (phase B)
-// 64 at a time.  The queue sequence is the same as if every cluster had been classified per point, so the sums are
-// bit-identical to the unculled sweep (nocull != 0 forces status 1 everywhere: tests compare the two).
+// tests one cluster; the wave then walks the flagged ones:
+//   status 1 -> phase A (exact fp64 classification with the reference's pixel-form conditions) on its 64 records,
+//   status 2 -> all 64 records are active.
+// Active ids go to the per-wave LDS queue and are evaluated densely (phase B) 64 at a time.  The queue sequence is the
+// same as if every cluster had been classified per point, so the sums are bit-identical to the unculled sweep
+// (nocull != 0 forces status 1 everywhere: tests compare the two).
 template <int NP, typename PT, int WPH, int LAB>
-__device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs, int cnt, const Sphere* __restrict__ spheres, int nc,
+__device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs, int cnt, const Box* __restrict__ boxes, int nc,
                                                const Cam& k, const Planes& pl, const double* x, const Rot<NP>& rot, int nocull,
                                                int* queue, double& cost, double* lg, double* lA, bool& bad, int* n_active) {
     constexpr int TOFF = NP == 4 ? 1 : 3;
@@ -435,9 +456,11 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
     const double hw = k.W1 * 0.5, hh = k.H1 * 0.5;
     int qn = 0;  // wave-uniform
     auto load_rec = [&](int c) {
+        // unconditional load from a clamped index (a load inside a branch is waited for on the spot); lanes past
+        // the end of the block are marked by lab = -1
         const int n = c * CL + lane;
-        Rec<PT> r;
-        if (n < cnt) r = recs[n]; else { r.x = 0; r.y = 0; r.z = 1; r.lab = -1; }
+        Rec<PT> r = recs[min(n, cnt - 1)];
+        if (n >= cnt) r.lab = -1;
         return r;
     };
     auto drain = [&](bool flush) {
@@ -454,12 +477,25 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
             if (n >= 0) eval_active<NP, PT, LAB>(recs[n], rot, x, k, cost, lg, lA, bad);
         }
     };
+    // exact classification of one record (the reference's pixel-form conditions)
+    auto exact_active = [&](const Rec<PT>& rec, bool valid) {
+        double X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y;
+        project<NP, PT, true>(rec, rot, tx, ty, tz, k, X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y);
+        if (LAB == 1)
+            return valid && (!(-pix_x < 0.0) || !(pix_x - k.W1 < 0.0) || !(-pix_y < 0.0) || !(pix_y - k.H1 < 0.0) || !(-p2 < 0.0));
+        const double dx = hw - fabs(pix_x - hw), dy = hh - fabs(pix_y - hh);
+        // fmax(v,0)/v is NaN at v == 0 (registration_2d.hpp:53,56,58), and a non-finite pixel poisons the
+        // residual: evaluation failure.  One test: dx*dy*p2 is 0 or non-finite exactly in those cases.
+        const double chk = dx * dy * p2;
+        if (valid && (!(fabs(chk) > 0.0) || !(fabs(chk) < __builtin_inf()))) bad = true;
+        return valid && dx > 0.0 && dy > 0.0 && p2 > 0.0;
+    };
     const int mine = (nc - wave + WPH - 1) / WPH;        // clusters wave, wave+WPH, ... < nc
     for (int j0 = 0; j0 < mine; j0 += 64) {
         const int j = j0 + lane;
         int status = 0;
-        if (j < mine) status = nocull ? 1 : cluster_status<NP, LAB>(spheres[j * WPH + wave], rot, tx, ty, tz, k, pl);
-        unsigned long long mA = __ballot(status == 1), mB = __ballot(status == 2);
+        if (j < mine) status = nocull ? 1 : cluster_status<NP, LAB>(boxes[j * WPH + wave], rot, tx, ty, tz, k, pl);
+        const unsigned long long mA = __ballot(status == 1), mB = __ballot(status == 2);
         unsigned long long m = mA | mB;
         n_active[1] += __popcll(mA); n_active[2] += __popcll(mB); n_active[3] += min(mine - j0, 64);
         Rec<PT> nxt;
@@ -471,21 +507,9 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
             m &= m - 1;
             const Rec<PT> rec = nxt;
             if (m) nxt = load_rec((j0 + (int)__builtin_ctzll(m)) * WPH + wave);     // next flagged cluster in flight
-            bool act = (int)rec.lab >= 0;                                           // padding lanes of a partial cluster
-            if (isA) {
-                double X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y;
-                project<NP, PT, true>(rec, rot, tx, ty, tz, k, X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y);
-                if (LAB == 1) {
-                    act = act && (!(-pix_x < 0.0) || !(pix_x - k.W1 < 0.0) || !(-pix_y < 0.0) || !(pix_y - k.H1 < 0.0) || !(-p2 < 0.0));
-                } else {
-                    const double dx = hw - fabs(pix_x - hw), dy = hh - fabs(pix_y - hh);
-                    // fmax(v,0)/v is NaN at v == 0 (registration_2d.hpp:53,56,58), and a non-finite pixel poisons the
-                    // residual: evaluation failure.  One test: dx*dy*p2 is 0 or non-finite exactly in those cases.
-                    const double chk = dx * dy * p2;
-                    if (act && (!(fabs(chk) > 0.0) || !(fabs(chk) < __builtin_inf()))) bad = true;
-                    act = act && dx > 0.0 && dy > 0.0 && p2 > 0.0;
-                }
-            }
+            const bool valid = (int)rec.lab >= 0;                                   // padding lanes of a partial cluster
+            bool act = valid;
+            if (isA) act = exact_active(rec, valid);
             const unsigned long long bal = __ballot(act);
             if (act) queue[qn + __popcll(bal & lt)] = c * CL + lane;
             qn += __popcll(bal);
@@ -499,7 +523,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
 // barrier.  Records are sorted by label (prepare_kernel): the label-1 block and the label-0 block are swept by two
 // specialised loops.
 template <int NP, typename PT, int WPH>
-__device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Sphere* __restrict__ spheres, int cnt1, int cnt0, int nc1,
+__device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Box* __restrict__ boxes, int cnt1, int cnt0, int nc1,
                                      int nc0, const Cam& k, const Planes& pl, const double* x, int nocull, SweepShared<NP, WPH>& sh, int* n_active) {
     constexpr int NV = Tri<NP>::N + NP + 2;
     Rot<NP> rot;
@@ -513,8 +537,8 @@ __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Sp
 #pragma unroll
     for (int i = 0; i < Tri<NP>::N; ++i) lA[i] = 0.0;
     bool bad = false;
-    sweep_clusters<NP, PT, WPH, 1>(recs, cnt1, spheres, nc1, k, pl, x, rot, nocull, queue, cost, lg, lA, bad, n_active);
-    sweep_clusters<NP, PT, WPH, 0>(recs + cnt1, cnt0, spheres + nc1, nc0, k, pl, x, rot, nocull, queue, cost, lg, lA, bad, n_active);
+    sweep_clusters<NP, PT, WPH, 1>(recs, cnt1, boxes, nc1, k, pl, x, rot, nocull, queue, cost, lg, lA, bad, n_active);
+    sweep_clusters<NP, PT, WPH, 0>(recs + cnt1, cnt0, boxes + nc1, nc0, k, pl, x, rot, nocull, queue, cost, lg, lA, bad, n_active);
 
     double* mine = sh.red[wave];
     double v = wave_sum(cost);
@@ -716,7 +740,7 @@ __device__ void lm_after_sweep(LMState<NP>& st, bool ok, double fe, const double
 }
 
 template <int NP, typename PT, int MINW, int WPH>
-__global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __restrict__ packed, const Sphere* __restrict__ spheres_all,
+__global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __restrict__ packed, const Box* __restrict__ boxes_all,
                                                        int NCMAX, int nocull, const int* __restrict__ counts,
                                                        const double* __restrict__ Kmat, const double* __restrict__ init_y,
                                                        const double* __restrict__ init_T, const double* __restrict__ yaw0,
@@ -733,7 +757,7 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
     __shared__ SweepShared<NP, WPH> sh;
     __shared__ LMState<NP> st;
     const Rec<PT>* recs = packed + (long long)f * N;
-    const Sphere* spheres = spheres_all + (long long)f * NCMAX;
+    const Box* boxes = boxes_all + (long long)f * NCMAX;
     const int cnt1 = counts[4 * f], cnt0 = counts[4 * f + 1], nc1 = counts[4 * f + 2], nc0 = counts[4 * f + 3];
     const double* Kf = Kmat + (long long)f * 9;
     const Cam k{Kf[0], Kf[4], Kf[2], Kf[5], H - 1.0, W - 1.0};
@@ -759,7 +783,7 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
 #pragma unroll
         for (int i = 0; i < NP; ++i) xe[i] = st.xe[i];
         const long long t0 = prof ? clock64() : 0;
-        sweep<NP, PT, WPH>(recs, spheres, cnt1, cnt0, nc1, nc0, k, pl, xe, nocull, sh, n_act);
+        sweep<NP, PT, WPH>(recs, boxes, cnt1, cnt0, nc1, nc0, k, pl, xe, nocull, sh, n_act);
         const long long t1 = prof ? clock64() : 0;
         __syncthreads();
         const long long t2 = prof ? clock64() : 0;
@@ -961,7 +985,7 @@ __global__ __launch_bounds__(256) void residuals_kernel(const double* __restrict
 
 static long long* g_prof = nullptr;   // diagnostics hook, see di2p_solver_set_profile_buffer
 
-struct SolveWs { int P, NCMAX; size_t off_recs, off_spheres, off_keys, bytes; };
+struct SolveWs { int P, NCMAX; size_t off_recs, off_boxes, off_keys, bytes; };
 static SolveWs solve_ws_layout(int F, int N) {
     SolveWs w;
     w.P = 64;
@@ -969,8 +993,8 @@ static SolveWs solve_ws_layout(int F, int N) {
     w.NCMAX = (N + CL - 1) / CL + 2;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     w.off_recs = up((size_t)F * 4 * sizeof(int));
-    w.off_spheres = up(w.off_recs + (size_t)F * N * 32);
-    w.off_keys = up(w.off_spheres + (size_t)F * w.NCMAX * sizeof(Sphere));
+    w.off_boxes = up(w.off_recs + (size_t)F * N * 32);
+    w.off_keys = up(w.off_boxes + (size_t)F * w.NCMAX * sizeof(Box));
     w.bytes = up(w.off_keys + (size_t)F * w.P * 8) + 256;
     return w;
 }
@@ -981,21 +1005,21 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
                  int R, int N, double* params, double* cost, int* iters, int* sweeps, void* workspace, hipStream_t st) {
     Bounds b;
     for (int i = 0; i < 3; ++i) { b.lb[i] = lb[i]; b.ub[i] = ub[i]; }
-    // workspace: counts i32[F][4] | records Rec[F][N] | spheres [F][NCMAX] | sort keys u64[F][P]
+    // workspace: counts i32[F][4] | records Rec[F][N] | cluster boxes [F][NCMAX] | sort keys u64[F][P]
     const SolveWs ws = solve_ws_layout(F, N);
     char* base = (char*)workspace;
     int* counts = (int*)base;
     Rec<PT>* packed = (Rec<PT>*)(base + ws.off_recs);
-    Sphere* spheres = (Sphere*)(base + ws.off_spheres);
+    Box* boxes = (Box*)(base + ws.off_boxes);
     unsigned long long* keys = (unsigned long long*)(base + ws.off_keys);
-    hipLaunchKernelGGL(prepare_kernel<PT>, dim3(F), dim3(1024), 0, st, points, labels, N, ws.P, ws.NCMAX, keys, packed, spheres, counts);
+    hipLaunchKernelGGL(prepare_kernel<PT>, dim3(F), dim3(1024), 0, st, points, labels, N, ws.P, ws.NCMAX, keys, packed, boxes, counts);
     // DI2P_SOLVER_CFG=<waves per hypothesis><min waves/SIMD>, e.g. 43 (default); DI2P_SOLVER_NOCULL=1 classifies every
     // cluster per point (the sums are bit-identical by construction: tests compare the two)
     static int cfg = -1, nocull = -1;
     if (cfg < 0) { const char* e = getenv("DI2P_SOLVER_CFG"); cfg = e ? atoi(e) : 43; }
     { const char* e = getenv("DI2P_SOLVER_NOCULL"); nocull = e ? atoi(e) : 0; }
     const dim3 grid(R * F);
-#define DI2P_LAUNCH_SOLVE(NPV, MW, WP) hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP>), grid, dim3(WP * 64), 0, st, packed, spheres, ws.NCMAX, nocull, counts, K, init_y, init_T, yaw0, H, W, b, max_iter, F, R, N, params, cost, iters, sweeps, g_prof)
+#define DI2P_LAUNCH_SOLVE(NPV, MW, WP) hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP>), grid, dim3(WP * 64), 0, st, packed, boxes, ws.NCMAX, nocull, counts, K, init_y, init_T, yaw0, H, W, b, max_iter, F, R, N, params, cost, iters, sweeps, g_prof)
     if (is_2d) {
         switch (cfg) {
             case 42: DI2P_LAUNCH_SOLVE(4, 2, 4); break;

@@ -143,6 +143,18 @@ def _run_layer(srcs, layer, N, **kw):
     return ops.pointwise_gemm(srcs, Wt, Wt.shape[1], N, scale=scale, shift=shift, relu=act, **kw)
 
 
+def _run_split_layer(dense_srcs, dense_rows, node_feats, node_rows, idx, layer, N, **kw):
+    """W @ cat(dense, node_feats[:, :, idx]) == W_d @ dense + (W_n @ node_feats)[:, :, idx]: the gathered (or
+    group-broadcast) half of a concatenation is contracted ONCE PER NODE ([B,nodes,M], node-major) and added per column
+    by the epilogue (unit-weight gathered add), so the big GEMM only sees the dense channels."""
+    Wt, scale, shift, act = layer
+    M = Wt.shape[1]
+    B = node_feats.shape[0]
+    G = ops.pointwise_gemm([Src(node_feats)], Wt[node_rows[0]:node_rows[1]], M, node_feats.shape[2], transpose_out=True)
+    return ops.pointwise_gemm(dense_srcs, Wt[dense_rows[0]:dense_rows[1]], M, N, scale=scale, shift=shift, relu=act,
+                              gathered=[(G, idx.reshape(B, N, 1), None)], **kw)
+
+
 def _run_pn(x, layers):
     N = x.shape[2]
     for layer in layers:
@@ -173,6 +185,14 @@ class PCEncoder(_PackedModule):
             self._packed = p
         return self._packed
 
+    def _group_index(self, B, Mb, K, device):
+        """i32[B, Mb*K]: column n of the neighbour-expanded tensor belongs to node n // K (cached constant)."""
+        key = (B, Mb, K, str(device))
+        cache = self.__dict__.setdefault("_gidx_cache", {})
+        if key not in cache:
+            cache[key] = (torch.arange(Mb * K, dtype=torch.int32, device=device) // K).unsqueeze(0).expand(B, -1).contiguous()
+        return cache[key]
+
     def forward_device(self, pc, intensity, sn, node_a, node_b):
         """Returns the reference 8-tuple plus the device-side extras the fusion head re-uses."""
         if pc.size(2) != self.opt.input_pt_num:
@@ -184,19 +204,20 @@ class PCEncoder(_PackedModule):
         pc_centers, aug = ops.build_point_input(pc, intensity, sn, cluster_mean, min_idx)
         first = _run_pn(aug, p["first"])
         _, first_max = ops.index_max(first, min_idx, Ma, return_values=True, mask=mask)
-        second = _run_layer([Src(first), Src(first_max, _lib.SRC_GATHER, gidx=min_idx)], p["second"][0], N)
+        Ch = first.shape[1]
+        second = _run_split_layer([Src(first)], (0, Ch), first_max, (Ch, 2 * Ch), min_idx, p["second"][0], N)   # cat(first, first_max[min_idx])
         second = _run_pn(second, p["second"][1:])
         _, node_a_features = ops.index_max(second, min_idx, Ma, return_values=True, mask=mask)
         # GeneralKNNFusionModule (layers_pc.py:779-818)
         K = self.opt.k_ab
         knn_I = ops.knn_nodes(node_b, cluster_mean, K)
         coord = ops.gather_neighbors(cluster_mean, node_b, knn_I)
-        y = _run_layer([Src(coord), Src(node_a_features, _lib.SRC_GATHER, gidx=knn_I.view(B, Mb * K))],
-                       p["layers_before.0"], Mb * K)
+        y = _run_split_layer([Src(coord)], (0, 3), node_a_features, (3, 3 + node_a_features.shape[1]), knn_I.view(B, Mb * K),
+                             p["layers_before.0"], Mb * K)
         y = _run_layer([Src(y)], p["layers_before.1"], Mb * K)
         Cb = y.shape[1]
         fmax = ops.channel_max(y.view(B, Cb * Mb, K)).view(B, Cb, Mb)
-        y = _run_layer([Src(fmax, _lib.SRC_GROUP, group=K), Src(y)], p["layers_after.0"], Mb * K)
+        y = _run_split_layer([Src(y)], (Cb, 2 * Cb), fmax, (0, Cb), self._group_index(B, Mb, K, pc.device), p["layers_after.0"], Mb * K)
         if K & (K - 1) == 0 and K <= 32:
             node_b_features = _run_layer([Src(y)], p["layers_after.1"], Mb * K, group_max=K)
         else:

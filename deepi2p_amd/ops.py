@@ -150,6 +150,8 @@ def pointwise_gemm(srcs, Wt, M, N, scale=None, shift=None, batch_bias=None, relu
     if gathered:
         for t, (tab, gi, gw) in enumerate(gathered):
             require_cuda(tab, gi, gw)
+            if gi.dtype != _i32 or not gi.is_contiguous() or not tab.is_contiguous():
+                raise RuntimeError("gathered tables must be contiguous, indices int32 contiguous")
             e.g_table[t], e.g_idx[t], e.g_w[t] = ptr(tab), ptr(gi), ptr(gw)
             assert tab.shape[2] == M
             e.g_nodes[t] = tab.shape[1]

@@ -117,7 +117,7 @@ typedef struct {
     /* optional gathered add (per_point_pn layer 0 with W*interp == interp(W*nodes)):            */
     const float* g_table[2];   /* each f32[B,g_nodes,M] (node-major, M % 4 == 0; what transpose_out writes) or NULL */
     const int32_t* g_idx[2];   /* i32[B,N,g_k] */
-    const float* g_w[2];       /* f32[B,N,g_k] */
+    const float* g_w[2];       /* f32[B,N,g_k], or NULL for unit weights (plain gather) */
     int g_nodes[2];
     int g_k;
     int transpose_out;         /* 1: Y is written f32[B,N,M] (needs M % 4 == 0, group_max == 1) */

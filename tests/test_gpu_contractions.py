@@ -84,6 +84,14 @@ def test_pointwise_gemm_concat_gather_group_bias(dev):
                       grpsrc.repeat_interleave(grp, dim=2), bvec.unsqueeze(2).expand(B, 40, N)), dim=1)
     ref = torch.einsum("mk,bkn->bmn", W, full)
     assert (y - ref).abs().max() <= _tol(ref, K)
+    import os
+    os.environ["DI2P_PW_NOVEC"] = "1"           # scalar stager: same operands element by element
+    try:
+        y0 = ops.pointwise_gemm([ops.Src(a.to(dev)), ops.Src(tab.to(dev), _lib.SRC_GATHER, gidx=gi.to(dev)),
+                                 ops.Src(grpsrc.to(dev), _lib.SRC_GROUP, group=grp)], Wt_dense, M, N, batch_bias=bias).cpu()
+    finally:
+        del os.environ["DI2P_PW_NOVEC"]
+    assert (y - y0).abs().max() <= _tol(ref, K)
     # fused max over groups of 16 consecutive columns (torch.max(dim=3) of layers_pc.py:811,816)
     ym = ops.pointwise_gemm([ops.Src(full.to(dev))], Wt, M, N, relu=True, group_max=grp).cpu()
     refm = torch.relu(ref).view(B, M, N // grp, grp).max(dim=3)[0]
