@@ -302,8 +302,24 @@ __device__ __forceinline__ void project(const Rec<PT>& rc, const Rot<NP>& rot, d
     pix_y = p1 * k.fy * iz + k.cy;
 }
 
+// sum_i log(1 + s_i) of a lane, kept as the PRODUCT prod_i (1 + s_i) = m * 2^e with m in [0.5, 1): one multiply and two
+// frexp pairs per block instead of a ~70-instruction fp64 log, one log per lane per sweep at the end; the relative error
+// of the product (n * 2^-53) becomes an ABSOLUTE error of the sum, i.e. it is more accurate than adding rounded logs.
+struct LogProd {
+    double m;
+    int e;
+    __device__ __forceinline__ void init() { m = 0.5; e = 1; }
+    __device__ __forceinline__ void mul(double v) {       // v >= 1 finite (non-finite v poisons m; the caller flags `bad`)
+        e += __builtin_amdgcn_frexp_exp(v);
+        m *= __builtin_amdgcn_frexp_mant(v);              // in [0.25, 1)
+        e += __builtin_amdgcn_frexp_exp(m);
+        m = __builtin_amdgcn_frexp_mant(m);
+    }
+    __device__ __forceinline__ double log_value() const { return log(m) + (double)e * 0.69314718055994530942; }
+};
+
 template <int NP, typename PT, int LAB>
-__device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& rot, const double* x, const Cam& k, double& cost,
+__device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& rot, const double* x, const Cam& k, LogProd& cost,
                                             double* lg, double* lA, bool& bad) {
     constexpr int TOFF = NP == 4 ? 1 : 3;
     double X, Y, Z, qx, qz, p0, p1, p2, iz, pix_x, pix_y;
@@ -337,7 +353,7 @@ __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& ro
     for (int i = 0; i < (LAB == 1 ? 3 : 1); ++i) s += rv[i] * rv[i];
     if (!isfinite(s)) bad = true;
     const double s1 = 1.0 + s;
-    if (s > 0.0) cost += 0.5 * log(s1);          // rho(s) = log(1+s); absolute error <= 1 ulp(1) per block
+    cost.mul(s1);                                // rho(s) = log(1+s), accumulated as a product
     const double rho1 = fast_rcp(s1);
     const double ax = k.fx * iz, bx = -k.fx * p0 * iz * iz;   // dpix_x = ax*dp0 + bx*dp2
     const double ay = k.fy * iz, by = -k.fy * p1 * iz * iz;   // dpix_y = ay*dp1 + by*dp2
@@ -366,7 +382,6 @@ __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& ro
             } else {
                 J[a] = sx[0] * (ax * dp0[a] + bx * dp2[a]) + sy[0] * (ay * dp1[a] + by * dp2[a]);
             }
-            if (!isfinite(J[a])) bad = true;
         }
         const double wr = rho1 * rv[i];
 #pragma unroll
@@ -448,7 +463,7 @@ __device__ __forceinline__ int cluster_status(const Box& bx, const Rot<NP>& rot,
 template <int NP, typename PT, int WPH, int LAB>
 __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs, int cnt, const Box* __restrict__ boxes, int nc,
                                                const Cam& k, const Planes& pl, const double* x, const Rot<NP>& rot, int nocull,
-                                               int* queue, double& cost, double* lg, double* lA, bool& bad, int* n_active) {
+                                               int* queue, LogProd& cost, double* lg, double* lA, bool& bad, int* n_active) {
     constexpr int TOFF = NP == 4 ? 1 : 3;
     const double tx = x[TOFF], ty = x[TOFF + 1], tz = x[TOFF + 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -530,7 +545,8 @@ __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Bo
     make_rot<NP>(x, rot);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int* queue = sh.queue[wave];
-    double cost = 0.0;
+    LogProd cost;
+    cost.init();
     double lg[NP], lA[Tri<NP>::N];
 #pragma unroll
     for (int i = 0; i < NP; ++i) lg[i] = 0.0;
@@ -540,8 +556,13 @@ __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Bo
     sweep_clusters<NP, PT, WPH, 1>(recs, cnt1, boxes, nc1, k, pl, x, rot, nocull, queue, cost, lg, lA, bad, n_active);
     sweep_clusters<NP, PT, WPH, 0>(recs + cnt1, cnt0, boxes + nc1, nc0, k, pl, x, rot, nocull, queue, cost, lg, lA, bad, n_active);
 
+    // a non-finite Jacobian entry (evaluation failure in the reference) makes a sum non-finite: tested once per sweep
+#pragma unroll
+    for (int i = 0; i < NP; ++i) if (!isfinite(lg[i])) bad = true;
+#pragma unroll
+    for (int i = 0; i < Tri<NP>::N; ++i) if (!isfinite(lA[i])) bad = true;
     double* mine = sh.red[wave];
-    double v = wave_sum(cost);
+    double v = wave_sum(0.5 * cost.log_value());
     if (lane == 0) mine[0] = v;
 #pragma unroll
     for (int i = 0; i < NP; ++i) { v = wave_sum(lg[i]); if (lane == 0) mine[1 + i] = v; }
