@@ -1,5 +1,6 @@
-// Standalone calibration of the two fp32-MFMA tile engines on dense GEMM shapes (GPU box):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I deepi2p_amd/csrc -I include tools/exp_gemm_kc.hip -o tools/bin/exp_gemm_kc
+// Standalone calibration of the fp32-MFMA tile engine (mfma_tile.h, production) and of the experimental k-contiguous
+// variant (tools/mfma_tile_kc.h) on dense GEMM shapes with trivial loaders (GPU box):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I deepi2p_amd/csrc -I include -I tools tools/exp_gemm_kc.hip -o tools/bin/exp_gemm_kc
 //   tools/bin/exp_gemm_kc M K N [M K N ...]
 #include <hip/hip_runtime.h>
 
@@ -26,9 +27,11 @@ struct EpiStore {
 };
 // old engine loaders: At [K][M], X [K][N]
 struct OldA { const float* At; int K, M; __device__ __forceinline__ float4 load4(int k, int m) const {
-    if (k < K && m + 3 < M) return *reinterpret_cast<const float4*>(At + (size_t)k * M + m); return make_float4(0, 0, 0, 0); } };
-struct OldB { const float* X; int K, N; int n; __device__ __forceinline__ void column4(int j) { n = j; } __device__ __forceinline__ void begin_tile(int) {}
-    __device__ __forceinline__ float4 load4(int k) const { if (k < K && n + 3 < N) return *reinterpret_cast<const float4*>(X + (size_t)k * N + n); return make_float4(0, 0, 0, 0); } };
+    return *reinterpret_cast<const float4*>(At + (size_t)min(k, K - 1) * M + min(m, M - 4)); }
+    __device__ __forceinline__ void fix(float4& v, int k) const { if (k >= K) v = make_float4(0, 0, 0, 0); } };
+struct OldB { const float* X; int K, N; int n; __device__ __forceinline__ void column4(int j) { n = min(j, N - 4); } __device__ __forceinline__ void begin_tile(int) {}
+    __device__ __forceinline__ float4 load4(int k) const { return *reinterpret_cast<const float4*>(X + (size_t)min(k, K - 1) * N + n); }
+    __device__ __forceinline__ void fix(float4&, int) const {} };
 // new engine loaders: A [M][K], X [K][N]
 struct NewA { const float* A; int M, K; __device__ __forceinline__ float4 load4(int m, int k) const {   // K % 32 == 0 (zero padded)
     return *reinterpret_cast<const float4*>(A + (size_t)min(m, M - 1) * K + k); } };
@@ -78,7 +81,7 @@ template <class OC, class NC> void run(int M, int K, int N, const char* name) {
         CK(hipMemset(dC, 0, (size_t)M * N * 4));
         float ms = time_ms([&]() { old_kernel<OC><<<g, OC::THREADS, OC::LDS_FLOATS * 4>>>(dAt, dX, dC, M, K, N); }, 10);
         CK(hipGetLastError());
-        printf("%-10s M=%d K=%d N=%d  old(vec,[k][m]) %8.3f ms %6.1f TF  err %.2e\n", name, M, K, N, ms, flop / ms / 1e9, check(A, X, dC, M, K, N));
+        printf("%-10s M=%d K=%d N=%d  vec engine [k][m] %8.3f ms %6.1f TF  err %.2e\n", name, M, K, N, ms, flop / ms / 1e9, check(A, X, dC, M, K, N));
     }
     {
         CK(hipFuncSetAttribute((const void*)new_kernel<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, NC::LDS_FLOATS * 4));
@@ -86,7 +89,7 @@ template <class OC, class NC> void run(int M, int K, int N, const char* name) {
         CK(hipMemset(dC, 0, (size_t)M * N * 4));
         float ms = time_ms([&]() { new_kernel<NC><<<g, NC::THREADS, NC::LDS_FLOATS * 4>>>(dA, dX, dC, M, K, N); }, 10);
         CK(hipGetLastError());
-        printf("%-10s M=%d K=%d N=%d  new(kc ,[m][k]) %8.3f ms %6.1f TF  err %.2e\n", name, M, K, N, ms, flop / ms / 1e9, check(A, X, dC, M, K, N));
+        printf("%-10s M=%d K=%d N=%d  kc  engine [m][k] %8.3f ms %6.1f TF  err %.2e\n", name, M, K, N, ms, flop / ms / 1e9, check(A, X, dC, M, K, N));
     }
     CK(hipFree(dA)); CK(hipFree(dAt)); CK(hipFree(dX)); CK(hipFree(dC));
 }
