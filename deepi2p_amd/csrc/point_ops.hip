@@ -168,17 +168,20 @@ __global__ __launch_bounds__(256) void argmax_channels_kernel(const float* __res
     out[(long long)b * N + n] = bi;
 }
 
-// one wavefront per (b,c) row
-__global__ __launch_bounds__(256) void channel_max_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows, int N) {
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+// max over the last axis of [rows][N].  A row is handled by G = min(64, pow2 >= N) consecutive lanes, so short rows
+// (the K = 16 neighbour axis of the kNN fusion) pack 64/G rows into a wavefront and stay coalesced.
+__global__ __launch_bounds__(256) void channel_max_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows, int N, int G) {
     const int lane = threadIdx.x & 63;
-    const float* r = x + row * N;
+    const int rpw = 64 / G;                                    // rows per wavefront
+    const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + lane / G;
+    const int n0 = lane % G;
     float m = -__builtin_inff();
-    for (int n = lane; n < N; n += 64) m = fmaxf(m, r[n]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (lane == 0) y[row] = m;
+    if (row < rows) {
+        const float* r = x + row * N;
+        for (int n = n0; n < N; n += G) m = fmaxf(m, r[n]);
+    }
+    for (int o = G >> 1; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (row < rows && n0 == 0) y[row] = m;
 }
 
 __global__ void f32_to_f64_kernel(const float* __restrict__ in, double* __restrict__ out, long long n) {
@@ -259,7 +262,9 @@ extern "C" int di2p_channel_max(const float* x, float* y, int B, int C, int N, v
     DI2P_CHECK_ARG(B >= 0 && C >= 0 && N >= 1, "bad size");
     const long long rows = (long long)B * C;
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(channel_max_kernel, dim3(di2p_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, rows, N);
+    int G = 1;
+    while (G < N && G < 64) G <<= 1;
+    hipLaunchKernelGGL(channel_max_kernel, dim3(di2p_cdiv(rows, 4 * (64 / G))), dim3(256), 0, (hipStream_t)stream, x, y, rows, N, G);
     DI2P_RETURN_LAUNCH();
 }
 

@@ -318,7 +318,9 @@ struct LogProd {
     __device__ __forceinline__ double log_value() const { return log(m) + (double)e * 0.69314718055994530942; }
 };
 
-template <int NP, typename PT, int LAB>
+// WITH_J == false: cost only (line-search trials beyond the first, 92 % of which are rejected): the residual rows, s and
+// the cost product are computed by the SAME operations in the same order, so the cost is bit-identical to a full sweep's.
+template <int NP, typename PT, int LAB, bool WITH_J>
 __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& rot, const double* x, const Cam& k, LogProd& cost,
                                             double* lg, double* lA, bool& bad) {
     constexpr int TOFF = NP == 4 ? 1 : 3;
@@ -354,6 +356,7 @@ __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& ro
     if (!isfinite(s)) bad = true;
     const double s1 = 1.0 + s;
     cost.mul(s1);                                // rho(s) = log(1+s), accumulated as a product
+    if (!WITH_J) return;
     const double rho1 = fast_rcp(s1);
     const double ax = k.fx * iz, bx = -k.fx * p0 * iz * iz;   // dpix_x = ax*dp0 + bx*dp2
     const double ay = k.fy * iz, by = -k.fy * p1 * iz * iz;   // dpix_y = ay*dp1 + by*dp2
@@ -460,7 +463,7 @@ __device__ __forceinline__ int cluster_status(const Box& bx, const Rot<NP>& rot,
 // Active ids go to the per-wave LDS queue and are evaluated densely (phase B) 64 at a time.  The queue sequence is the
 // same as if every cluster had been classified per point, so the sums are bit-identical to the unculled sweep
 // (nocull != 0 forces status 1 everywhere: tests compare the two).
-template <int NP, typename PT, int WPH, int LAB>
+template <int NP, typename PT, int WPH, int LAB, bool WITH_J>
 __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs, int cnt, const Box* __restrict__ boxes, int nc,
                                                const Cam& k, const Planes& pl, const double* x, const Rot<NP>& rot, int nocull,
                                                int* queue, LogProd& cost, double* lg, double* lA, bool& bad, int* n_active) {
@@ -489,7 +492,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
             n_active[0] += qn > 64 ? 64 : qn;
             qn = qn > 64 ? qn - 64 : 0;
             __builtin_amdgcn_wave_barrier();
-            if (n >= 0) eval_active<NP, PT, LAB>(recs[n], rot, x, k, cost, lg, lA, bad);
+            if (n >= 0) eval_active<NP, PT, LAB, WITH_J>(recs[n], rot, x, k, cost, lg, lA, bad);
         }
     };
     // exact classification of one record (the reference's pixel-form conditions)
@@ -537,7 +540,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
 // Leaves the WPH wave partials {cost, g[NP], A[tri], bad} in sh.red[wave][*]; the caller combines them after a
 // barrier.  Records are sorted by label (prepare_kernel): the label-1 block and the label-0 block are swept by two
 // specialised loops.
-template <int NP, typename PT, int WPH>
+template <int NP, typename PT, int WPH, bool WITH_J>
 __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Box* __restrict__ boxes, int cnt1, int cnt0, int nc1,
                                      int nc0, const Cam& k, const Planes& pl, const double* x, int nocull, SweepShared<NP, WPH>& sh, int* n_active) {
     constexpr int NV = Tri<NP>::N + NP + 2;
@@ -553,14 +556,16 @@ __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Bo
 #pragma unroll
     for (int i = 0; i < Tri<NP>::N; ++i) lA[i] = 0.0;
     bool bad = false;
-    sweep_clusters<NP, PT, WPH, 1>(recs, cnt1, boxes, nc1, k, pl, x, rot, nocull, queue, cost, lg, lA, bad, n_active);
-    sweep_clusters<NP, PT, WPH, 0>(recs + cnt1, cnt0, boxes + nc1, nc0, k, pl, x, rot, nocull, queue, cost, lg, lA, bad, n_active);
+    sweep_clusters<NP, PT, WPH, 1, WITH_J>(recs, cnt1, boxes, nc1, k, pl, x, rot, nocull, queue, cost, lg, lA, bad, n_active);
+    sweep_clusters<NP, PT, WPH, 0, WITH_J>(recs + cnt1, cnt0, boxes + nc1, nc0, k, pl, x, rot, nocull, queue, cost, lg, lA, bad, n_active);
 
     // a non-finite Jacobian entry (evaluation failure in the reference) makes a sum non-finite: tested once per sweep
+    if (WITH_J) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) if (!isfinite(lg[i])) bad = true;
+        for (int i = 0; i < NP; ++i) if (!isfinite(lg[i])) bad = true;
 #pragma unroll
-    for (int i = 0; i < Tri<NP>::N; ++i) if (!isfinite(lA[i])) bad = true;
+        for (int i = 0; i < Tri<NP>::N; ++i) if (!isfinite(lA[i])) bad = true;
+    }
     double* mine = sh.red[wave];
     double v = wave_sum(0.5 * cost.log_value());
     if (lane == 0) mine[0] = v;
@@ -631,13 +636,15 @@ struct Bounds { double lb[3], ub[3]; };
 
 // Levenberg-Marquardt state of one hypothesis.  Lives ONCE per workgroup in LDS; thread 0 advances it between
 // sweeps (a few hundred scalar flops), so the sweep's register budget is not shared with it.
-enum { PH_INIT = 0, PH_TRIAL = 1, PH_RESWEEP = 2 };
+enum { PH_INIT = 0, PH_TRIAL = 1, PH_RESWEEP = 2, PH_CONFIRM = 3 };
 template <int NP>
 struct LMState {
     double x[NP], g[NP], A[Tri<NP>::N], S[NP], diag[NP], delta[NP], xe[NP];
     double lb[NP], ub[NP];
     double cost, gmax, radius, decrease, gd, dmax, t, f1, model_change;
     int iter, nsweep, invalid_run, ls_it, phase, reuse_diag, ok1, done, max_iter;
+    int want_j;        // the NEXT sweep needs the normal equations (0: cost only)
+    int n_ls_extra, n_ls_late_accept, n_resweep;      // diagnostics: line-search trials beyond the first, accepted ones among them, re-sweeps
 };
 
 template <int NP>
@@ -682,7 +689,7 @@ __device__ void lm_begin_iteration(LMState<NP>& st) {
         }
         st.gd = gd; st.dmax = dmax; st.t = 1.0; st.ls_it = 0;
         plus_proj<NP>(st.x, st.delta, 1.0, st.lb, st.ub, st.xe);
-        st.phase = PH_TRIAL;
+        st.phase = PH_TRIAL; st.want_j = 1;
         return;   // needs a sweep at xe
     }
 }
@@ -725,12 +732,25 @@ __device__ void lm_after_sweep(LMState<NP>& st, bool ok, double fe, const double
         return;
     }
     if (st.phase == PH_RESWEEP) {   // normal equations of the unscaled first trial, whose cost was kept in f1
+        ++st.n_resweep;
         lm_finish_iteration<NP>(st, st.f1, ge, Ae);
         return;
     }
-    // PH_TRIAL: projected Armijo search along delta
-    if (st.ls_it == 0) { st.f1 = ok ? fe : DBL_MAX; st.ok1 = ok; }
-    if (ok && fe <= st.cost + 1e-4 * st.gd * st.t) { lm_finish_iteration<NP>(st, fe, ge, Ae); return; }
+    // PH_TRIAL: projected Armijo search along delta.  The first trial (t = 1) is swept WITH its normal equations (it is
+    // accepted most of the time, so an accepted step costs one sweep); later trials are swept cost-only, and the rare
+    // one that satisfies Armijo is confirmed by a full sweep at the same point (PH_CONFIRM) before it is used.
+    if (st.phase == PH_CONFIRM) {
+        st.phase = PH_TRIAL;
+        if (ok) { ++st.n_ls_late_accept; lm_finish_iteration<NP>(st, fe, ge, Ae); return; }
+        // non-finite Jacobian: this trial is an evaluation failure, exactly as if it had been swept in full right away
+    } else {
+        if (st.ls_it == 0) { st.f1 = ok ? fe : DBL_MAX; st.ok1 = ok; } else ++st.n_ls_extra;
+        if (ok && fe <= st.cost + 1e-4 * st.gd * st.t) {
+            if (st.ls_it > 0) { st.phase = PH_CONFIRM; st.want_j = 1; return; }      // same xe again, with J
+            lm_finish_iteration<NP>(st, fe, ge, Ae);
+            return;
+        }
+    }
     bool give_up = ++st.ls_it >= 20;
     double tn = 0.0;
     if (!give_up) {
@@ -752,11 +772,12 @@ __device__ void lm_after_sweep(LMState<NP>& st, bool ok, double fe, const double
     }
     if (give_up) {   // delta stays unscaled: the candidate is the first trial point
         plus_proj<NP>(st.x, st.delta, 1.0, st.lb, st.ub, st.xe);
-        if (st.ls_it > 1 || st.t != 1.0) { st.phase = PH_RESWEEP; return; }   // sums on hand belong to another point
+        if (st.ls_it > 1 || st.t != 1.0) { st.phase = PH_RESWEEP; st.want_j = 1; return; }   // sums on hand belong to another point
         lm_finish_iteration<NP>(st, st.f1, ge, Ae);
         return;
     }
     st.t = tn;
+    st.want_j = 0;
     plus_proj<NP>(st.x, st.delta, tn, st.lb, st.ub, st.xe);
 }
 
@@ -795,6 +816,7 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
         for (int i = 0; i < NP; ++i) { st.x[i] = fmin(fmax(st.x[i], st.lb[i]), st.ub[i]); st.xe[i] = st.x[i]; }
         st.radius = 1e4; st.decrease = 2.0; st.reuse_diag = 0; st.invalid_run = 0; st.iter = 0; st.nsweep = 0;
         st.phase = PH_INIT; st.done = 0; st.max_iter = max_iter; st.cost = 0.0; st.gmax = 0.0;
+        st.n_ls_extra = 0; st.n_ls_late_accept = 0; st.n_resweep = 0; st.want_j = 1;
     }
     __syncthreads();
     long long c_sweep = 0, c_wait = 0, c_lm = 0;
@@ -804,7 +826,8 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
 #pragma unroll
         for (int i = 0; i < NP; ++i) xe[i] = st.xe[i];
         const long long t0 = prof ? clock64() : 0;
-        sweep<NP, PT, WPH>(recs, boxes, cnt1, cnt0, nc1, nc0, k, pl, xe, nocull, sh, n_act);
+        if (st.want_j) sweep<NP, PT, WPH, true>(recs, boxes, cnt1, cnt0, nc1, nc0, k, pl, xe, nocull, sh, n_act);
+        else sweep<NP, PT, WPH, false>(recs, boxes, cnt1, cnt0, nc1, nc0, k, pl, xe, nocull, sh, n_act);
         const long long t1 = prof ? clock64() : 0;
         __syncthreads();
         const long long t2 = prof ? clock64() : 0;
@@ -825,7 +848,8 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
     }
     if (prof && threadIdx.x == 0) {   // diagnostics: shader-clock cycles of wave 0 per phase, phase-B evaluations of wave 0
         prof[hr * 8 + 0] = c_sweep; prof[hr * 8 + 1] = c_wait; prof[hr * 8 + 2] = c_lm; prof[hr * 8 + 3] = n_act[0];
-        prof[hr * 8 + 4] = n_act[1]; prof[hr * 8 + 5] = n_act[2]; prof[hr * 8 + 6] = n_act[3]; prof[hr * 8 + 7] = 0;
+        prof[hr * 8 + 4] = n_act[1]; prof[hr * 8 + 5] = n_act[2]; prof[hr * 8 + 6] = n_act[3];
+        prof[hr * 8 + 7] = (long long)st.n_ls_extra | ((long long)st.n_ls_late_accept << 20) | ((long long)st.n_resweep << 40);
     }
     if (threadIdx.x == 0) {
         for (int i = 0; i < NP; ++i) params_out[hr * NP + i] = st.x[i];

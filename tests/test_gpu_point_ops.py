@@ -98,3 +98,6 @@ def test_interpolate_gather_argmax_channelmax(dev):
     sl = s.to(dev)[:, 2:, :]                                                 # channel slice with foreign batch stride
     assert torch.equal(ops.argmax_channels(sl).cpu().long(), torch.max(s[:, 2:, :], dim=1)[1])
     assert torch.equal(ops.channel_max(s.to(dev)).cpu(), s.max(dim=2)[0])
+    for n in (1, 3, 16, 33, 64, 65):                                         # short rows share a wavefront
+        t = torch.randn(3, 37, n, generator=g)
+        assert torch.equal(ops.channel_max(t.to(dev)).cpu(), t.max(dim=2)[0])

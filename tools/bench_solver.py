@@ -43,6 +43,9 @@ for name, lab_np in (("noisy-gt", np.stack([f["labels"] for f in frames])),):
         print("  per-sweep cycles (mean over hyps): sweep %.0f  barrier-wait %.0f  LM %.0f ; active evals/sweep (wave0) %.1f of %d records/wave"
               % ((p[:, 0] / sw).mean(), (p[:, 1] / sw).mean(), (p[:, 2] / sw).mean(), (p[:, 3] / sw).mean(), kept / 4))
         print("  clusters per sweep (wave 0): tested %.1f  per-point %.1f  all-active %.1f" % ((p[:, 6] / sw).mean(), (p[:, 4] / sw).mean(), (p[:, 5] / sw).mean()))
+        q = prof.cpu().numpy().reshape(-1, 8)[:, 7]
+        print("  line search: extra trials %.1f / hyp, of which accepted %.1f, re-sweeps %.1f (iterations %.1f, sweeps %.1f)" % (
+            (q & 0xfffff).mean(), ((q >> 20) & 0xfffff).mean(), (q >> 40).mean(), iters.float().mean().item(), sw.mean()))
         i = int(np.argmax(sw))
         print("  slowest hyp: sweeps %d cycles total %.3g (sweep %.3g wait %.3g lm %.3g) active/sweep %.1f" % (sw[i], tot[i], p[i, 0], p[i, 1], p[i, 2], p[i, 3] / sw[i]))
         print("  sum over hyps of block cycles %.3g ; max %.3g" % (tot.sum(), tot.max()))
