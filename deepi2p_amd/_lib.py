@@ -48,6 +48,7 @@ _SIGS = {
     "di2p_batch_gemv": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "di2p_attention_pool": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "di2p_conv2d": [c_void_p] * 6 + [c_int] * 11 + [c_void_p],
+    "di2p_conv2d_ws": [c_void_p] * 6 + [c_int] * 11 + [c_void_p, c_ll, c_void_p],
     "di2p_maxpool3x3s2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "di2p_global_avgpool": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "di2p_channel_max": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
@@ -66,7 +67,8 @@ _SIGS = {
     "di2p_pnp_ransac": [c_void_p] * 5 + [c_int, c_void_p, c_int, c_double, c_int, c_int, c_int, c_int] + [c_void_p] * 7,
     "di2p_pack_pc_label": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
 }
-EXPORTS = sorted(list(_SIGS) + ["di2p_last_error", "di2p_version", "di2p_solve_workspace_bytes", "di2p_solver_set_profile_buffer", "di2p_pnp_workspace_bytes"])
+EXPORTS = sorted(list(_SIGS) + ["di2p_last_error", "di2p_version", "di2p_solve_workspace_bytes", "di2p_solver_set_profile_buffer", "di2p_pnp_workspace_bytes",
+                 "di2p_conv2d_workspace_bytes"])
 
 
 def load():
@@ -88,6 +90,8 @@ def load():
         lib.di2p_solve_workspace_bytes.argtypes = [c_int, c_int]
         lib.di2p_pnp_workspace_bytes.restype = c_ll
         lib.di2p_pnp_workspace_bytes.argtypes = [c_int, c_int, c_int]
+        lib.di2p_conv2d_workspace_bytes.restype = c_ll
+        lib.di2p_conv2d_workspace_bytes.argtypes = [c_int] * 10
         lib.di2p_solver_set_profile_buffer.restype = None
         lib.di2p_solver_set_profile_buffer.argtypes = [c_void_p]
         _lib = lib

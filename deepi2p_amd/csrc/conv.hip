@@ -117,7 +117,15 @@ struct LoaderIm2colTap4 {
         ih0 = oh * STRIDE - pad;
         iw0 = ow * STRIDE - pad;
         ci0 = -bk; kh = 0; kw = 0;
+        if (pending_seek > 0) seek(pending_seek);
         tile_ptr = xb; shift = 0; okmask = 0; c0 = c1 = c2 = c3 = 0;
+    }
+    int pending_seek = 0;
+    // position the tap walk so that the next begin_tile() lands on K-step t0 (split-K blocks start mid-way)
+    __device__ __forceinline__ void seek(int t0) {
+        const int k0 = t0 * bk, tap = k0 / Cin;
+        ci0 = k0 - tap * Cin - bk;
+        kh = tap / KW; kw = tap - kh * KW;
     }
     __device__ __forceinline__ void begin_tile(int) {
         ci0 += bk;
@@ -221,34 +229,83 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv2d_kernel(const float* __res
     }
 }
 
+// split-K: raw partial sums of K-slice z, same [b][Cout][pix] layout as y
+struct EpiPartial {
+    float* part;
+    int Cout, opix, Ntot;
+    __device__ __forceinline__ void tile(int mrow0, int j, const f32x16& acc) {
+        if (j >= Ntot) return;
+        const int b = j / opix, pix = j - b * opix;
+        float* o = part + (long long)b * Cout * opix + pix;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+            if (m < Cout) o[(long long)m * opix] = acc[r];
+        }
+    }
+};
+
+// y = relu?( scale * (part_0 + part_1 + ...) + shift + residual ), partials added in slice order (deterministic)
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ part, int splits, long long slice,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 const float* __restrict__ residual, float* __restrict__ y, int Cout,
+                                                                 int opix, int relu) {
+    const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;      // opix % 4 == 0: one channel per float4
+    if (i4 >= slice) return;
+    float4 a = *reinterpret_cast<const float4*>(part + i4);
+    for (int z = 1; z < splits; ++z) {
+        const float4 p = *reinterpret_cast<const float4*>(part + z * slice + i4);
+        a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+    }
+    const int m = (int)((i4 / opix) % Cout);
+    const float sc = scale[m], sh = shift[m];
+    float4 v = make_float4(a.x * sc + sh, a.y * sc + sh, a.z * sc + sh, a.w * sc + sh);
+    if (residual) { const float4 r = *reinterpret_cast<const float4*>(residual + i4); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<float4*>(y + i4) = v;
+}
+
 template <class Cfg, int STRIDE>
 __global__ __launch_bounds__(Cfg::THREADS) void conv2d_vec_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    const float* __restrict__ residual, float* __restrict__ y, int Cin,
                                                                    int H, int W, int Cout, int OH, int OW, int KH, int KW, int pad,
-                                                                   int Ntot, int relu) {
+                                                                   int Ntot, int relu, float* __restrict__ part, int splits) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int K = Cin * KH * KW;
     LoaderWt4 la{Wt, K, Cout};
-    EpiConv ep{scale, shift, residual, y, Cout, OH * OW, Ntot, relu};
     LoaderIm2colTap4<STRIDE> lb;
     lb.x = x; lb.Cin = Cin; lb.H = H; lb.W = W; lb.OH = OH; lb.OW = OW; lb.KH = KH; lb.KW = KW;
     lb.pad = pad; lb.Ntot = Ntot; lb.bk = Cfg::BK;
-    mfma_gemm_block_vec<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
+    if (splits <= 1) {
+        EpiConv ep{scale, shift, residual, y, Cout, OH * OW, Ntot, relu};
+        mfma_gemm_block_vec<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
+    } else {      // K-slice blockIdx.z: raw partial sums, combined by conv_splitk_reduce_kernel
+        const int T = K / Cfg::BK, z = blockIdx.z;
+        const int t0 = (int)((long long)T * z / splits), t1 = (int)((long long)T * (z + 1) / splits);
+        EpiPartial ep{part + (long long)z * Cout * Ntot, Cout, OH * OW, Ntot};
+        lb.pending_seek = t0;
+        mfma_gemm_block_vec<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN, t0, t1);
+    }
 }
 
 template <class Cfg>
 void launch_conv_vec(const float* x, const float* Wt, const float* scale, const float* shift, const float* residual, float* y,
                      int Cin, int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride, int pad, int Ntot, int relu,
-                     hipStream_t st) {
-    const dim3 grid(di2p_cdiv(Ntot, Cfg::BN), di2p_cdiv(Cout, Cfg::BM)), block(Cfg::THREADS);
+                     float* part, int splits, hipStream_t st) {
+    const dim3 grid(di2p_cdiv(Ntot, Cfg::BN), di2p_cdiv(Cout, Cfg::BM), splits), block(Cfg::THREADS);
     const size_t lds = Cfg::LDS_FLOATS * sizeof(float);
     if (stride == 1)
         hipLaunchKernelGGL((conv2d_vec_kernel<Cfg, 1>), grid, block, lds, st, x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW,
-                           KH, KW, pad, Ntot, relu);
+                           KH, KW, pad, Ntot, relu, part, splits);
     else
         hipLaunchKernelGGL((conv2d_vec_kernel<Cfg, 2>), grid, block, lds, st, x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW,
-                           KH, KW, pad, Ntot, relu);
+                           KH, KW, pad, Ntot, relu, part, splits);
+    if (splits > 1) {
+        const long long slice = (long long)Cout * Ntot;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((slice / 4 + 255) / 256)), dim3(256), 0, st, part, splits, slice,
+                           scale, shift, residual, y, Cout, OH * OW, relu);
+    }
 }
 
 template <class Cfg>
@@ -312,9 +369,27 @@ using CfgC64x128k32 = TileCfg<2, 2, 1, 2, 32>;
 using CfgC64x64k32 = TileCfg<2, 2, 1, 1, 32>;
 using CfgC128x64k32 = TileCfg<2, 2, 2, 1, 32>;
 
-extern "C" int di2p_conv2d(const float* x, const float* Wt, const float* scale, const float* shift, const float* residual,
-                           float* y, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int relu,
-                           int tap_major, void* stream) {
+namespace {
+// split-K factor the dispatcher uses for a shape (1 = none): the vector path with 64x64 tiles leaves the small-N layers
+// (ResNet stage 4 at 160x512: 320 workgroups for 256 CUs) latency-bound; K-slices along the filter taps give the chip
+// >= 3 workgroups per CU.  Partials are combined in slice order by a separate pass (deterministic, no atomics).
+int conv_splits(int Cin, int Cout, int KH, int KW, int OW, long long opix, int tap_major) {
+    const char* e = getenv("DI2P_CONV_NOSPLIT");     // read per call: tests compare both paths
+    if ((e && atoi(e)) || !tap_major || Cin % 32 != 0 || OW % 4 != 0 || Cout % 4 != 0 || Cout < 128) return 1;
+    // The decision depends on the PER-FRAME shape only, never on the batch size: a frame's result must not change with
+    // the batch it is computed in (data-parallel shards reproduce the unsharded run bit for bit).  The limit is the
+    // number of 64x64 workgroups one frame contributes below which a 32-frame batch leaves CUs idle.
+    const long long per_frame = di2p_cdiv(opix, 64) * (long long)di2p_cdiv(Cout, 64);
+    const int T = Cin * KH * KW / 32;
+    const char* t = getenv("DI2P_CONV_SPLIT_BLOCKS");   // tuning knob (per-frame workgroups), default 32
+    const long long limit = t ? atoll(t) : 32;
+    if (per_frame >= limit || T < 24) return 1;
+    return per_frame * 2 >= limit * 3 / 2 ? 2 : 3;
+}
+
+int conv2d_impl(const float* x, const float* Wt, const float* scale, const float* shift, const float* residual,
+                float* y, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int relu,
+                int tap_major, void* workspace, long long workspace_bytes, void* stream) {
     DI2P_CHECK_ARG(x && Wt && scale && shift && y, "null pointer");
     DI2P_CHECK_ARG(B >= 0 && Cin >= 1 && H >= 1 && W >= 1 && Cout >= 1 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0, "bad size");
     if (B == 0) return 0;
@@ -348,7 +423,11 @@ extern "C" int di2p_conv2d(const float* x, const float* Wt, const float* scale, 
     const bool vec = !novec && use32 && OW % 4 == 0 && Cout % 4 == 0 && ((uintptr_t)Wt & 15) == 0 &&
                      ((stride == 1 && pad <= 1 && KW <= 2 * pad + 1 && W >= 4) || stride == 2);
     if (vec && force < 0) choice = Cout <= 64 ? 1 : 0;   // measured: 64x64 tiles (more, smaller workgroups) win for Cout >= 128
-#define DI2P_CONVV(CFG) launch_conv_vec<CFG>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, st)
+    int splits = vec ? conv_splits(Cin, Cout, KH, KW, OW, (long long)OH * OW, tap_major) : 1;
+    if (splits > 1 && (!workspace || workspace_bytes < (long long)splits * Cout * Ntot * (long long)sizeof(float) || ((uintptr_t)workspace & 15))) splits = 1;
+    if (splits > 1) choice = 0;
+    float* part = (float*)workspace;
+#define DI2P_CONVV(CFG) launch_conv_vec<CFG>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, part, splits, st)
     if (vec) {
         switch (choice) { case 3: DI2P_CONVV(CfgC128x128k32); break; case 2: DI2P_CONVV(CfgC128x64k32); break;
                           case 1: DI2P_CONVV(CfgC64x128k32); break; default: DI2P_CONVV(CfgC64x64k32); }
@@ -362,6 +441,31 @@ extern "C" int di2p_conv2d(const float* x, const float* Wt, const float* scale, 
 #undef DI2P_CONV
 #undef DI2P_CONVV
     DI2P_RETURN_LAUNCH();
+}
+}  // namespace
+
+extern "C" int di2p_conv2d(const float* x, const float* Wt, const float* scale, const float* shift, const float* residual,
+                           float* y, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int relu,
+                           int tap_major, void* stream) {
+    return conv2d_impl(x, Wt, scale, shift, residual, y, B, Cin, H, W, Cout, KH, KW, stride, pad, relu, tap_major, nullptr, 0, stream);
+}
+
+extern "C" int di2p_conv2d_ws(const float* x, const float* Wt, const float* scale, const float* shift, const float* residual,
+                              float* y, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int relu,
+                              int tap_major, void* workspace, long long workspace_bytes, void* stream) {
+    return conv2d_impl(x, Wt, scale, shift, residual, y, B, Cin, H, W, Cout, KH, KW, stride, pad, relu, tap_major, workspace,
+                       workspace_bytes, stream);
+}
+
+extern "C" long long di2p_conv2d_workspace_bytes(int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                                                 int tap_major) {
+    if (B <= 0 || Cin < 1 || H < 1 || W < 1 || Cout < 1 || KH < 1 || KW < 1 || stride < 1 || pad < 0) return 0;
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    if (OH < 1 || OW < 1) return 0;
+    const bool shape_ok = (stride == 1 && pad <= 1 && KW <= 2 * pad + 1 && W >= 4) || stride == 2;
+    const long long Ntot = (long long)B * OH * OW;
+    const int splits = shape_ok ? conv_splits(Cin, Cout, KH, KW, OW, (long long)OH * OW, tap_major) : 1;
+    return splits > 1 ? (long long)splits * Cout * Ntot * (long long)sizeof(float) : 0;
 }
 
 extern "C" int di2p_maxpool3x3s2(const float* x, float* y, int B, int C, int H, int W, void* stream) {

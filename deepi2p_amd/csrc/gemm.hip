@@ -352,14 +352,19 @@ extern "C" int di2p_pointwise_gemm(const di2p_src_t* srcs, int n_src, const floa
     hipStream_t st = (hipStream_t)stream;
     // 4-column staged path (weights 16-byte addressable, whole 4-column groups); sources that are all dense and 16-byte
     // addressable get one 16-byte load per row, gathered / group sources four dword loads
-    const bool vec = N % 4 == 0 && N >= 4 && M % 4 == 0 && aligned16(Wt) && getenv("DI2P_PW_NOVEC") == nullptr;
+    // (narrow layers, M <= 64, are HBM/latency-bound and measured 25-35 % faster on the scalar stager below, whose K-step 16
+    //  skips the rows k >= K instead of re-reading clamped ones)
+    const bool vec = M > 64 && N % 4 == 0 && N >= 4 && M % 4 == 0 && aligned16(Wt) && getenv("DI2P_PW_NOVEC") == nullptr;
     bool dense = true;
     for (int i = 0; i < n_src; ++i)
         dense = dense && srcs[i].mode == DI2P_SRC_DENSE && srcs[i].row_stride % 4 == 0 && srcs[i].batch_stride % 4 == 0 && aligned16(srcs[i].ptr);
     if (vec) {
-        if (M <= 32) launch_pw_vec<TileCfg<1, 4, 1, 1, 32>>(dense, s, Wt, Y, B, M, K, N, e, st);
-        else if (M <= 64 || (long long)B * di2p_cdiv(N, 128) * di2p_cdiv(M, 128) < 256) launch_pw_vec<TileCfg<2, 2, 1, 2, 32>>(dense, s, Wt, Y, B, M, K, N, e, st);
-        else launch_pw_vec<TileCfg<2, 2, 2, 2, 32>>(dense, s, Wt, Y, B, M, K, N, e, st);
+        // small grids (node-level layers: N = 128 columns per frame) take smaller tiles to spread over the CUs
+        const long long wg128 = (long long)B * di2p_cdiv(N, 128) * di2p_cdiv(M, 128);
+        const long long wg64x128 = (long long)B * di2p_cdiv(N, 128) * di2p_cdiv(M, 64);
+        if (wg128 >= 1024) launch_pw_vec<TileCfg<2, 2, 2, 2, 32>>(dense, s, Wt, Y, B, M, K, N, e, st);
+        else if (wg64x128 >= 1024 || N % 64 != 0) launch_pw_vec<TileCfg<2, 2, 1, 2, 32>>(dense, s, Wt, Y, B, M, K, N, e, st);
+        else launch_pw_vec<TileCfg<2, 2, 1, 1, 32>>(dense, s, Wt, Y, B, M, K, N, e, st);
         DI2P_RETURN_LAUNCH();
     }
     if (M <= 32) launch_pw<Cfg32x128>(s, Wt, Y, B, M, K, N, e, st);

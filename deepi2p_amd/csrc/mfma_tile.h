@@ -134,12 +134,15 @@ struct LoaderWt4 {
 };
 
 template <class Cfg, class LoaderA, class LoaderB, class Epi>
-__device__ __forceinline__ void mfma_gemm_block_vec(float* lds, LoaderA& la, LoaderB& lb, Epi& epi, int K, int m_blk, int j_blk) {
+__device__ __forceinline__ void mfma_gemm_block_vec(float* lds, LoaderA& la, LoaderB& lb, Epi& epi, int K, int m_blk, int j_blk,
+                                                    int t_begin = 0, int t_end = -1) {   // K-steps [t_begin, t_end) (split-K); default: all
     constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
     constexpr int A_TPR = BM / 4, B_TPR = BN / 4;                       // threads per panel row
     constexpr int A_RPP = Cfg::THREADS / A_TPR, B_RPP = Cfg::THREADS / B_TPR;
-    constexpr int A_PASSES = BK / A_RPP, B_PASSES = BK / B_RPP;
-    static_assert(BK % A_RPP == 0 && BK % B_RPP == 0 && A_PASSES >= 1 && B_PASSES >= 1, "tile too small for the vector stager");
+    // a panel with fewer float4s than threads (narrow BM at K-step 16) is staged by the first waves only
+    constexpr int A_PASSES = BK >= A_RPP ? BK / A_RPP : 1, B_PASSES = BK >= B_RPP ? BK / B_RPP : 1;
+    static_assert((BK % A_RPP == 0 || A_RPP % BK == 0) && (BK % B_RPP == 0 || B_RPP % BK == 0), "tile/threads mismatch");
+    static_assert(A_RPP * A_TPR == Cfg::THREADS && B_RPP * B_TPR == Cfg::THREADS, "panel rows must divide the workgroup");
     float* As = lds;
     float* Bs = lds + 2 * BK * BM;
     const int tid = threadIdx.x;
@@ -148,6 +151,7 @@ __device__ __forceinline__ void mfma_gemm_block_vec(float* lds, LoaderA& la, Loa
     const int l31 = lane & 31, half = lane >> 5;
     const int a_col = (tid % A_TPR) * 4, a_row0 = tid / A_TPR;
     const int b_col = (tid % B_TPR) * 4, b_row0 = tid / B_TPR;
+    const bool a_on = A_RPP <= BK || a_row0 < BK, b_on = B_RPP <= BK || b_row0 < BK;      // wave-uniform
     lb.column4(j_blk + b_col);
 
     f32x16 acc[Cfg::TM][Cfg::TN];
@@ -159,10 +163,10 @@ __device__ __forceinline__ void mfma_gemm_block_vec(float* lds, LoaderA& la, Loa
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     float4 ra[A_PASSES], rb[B_PASSES];
-    const int T = (K + BK - 1) / BK;
+    const int T = (t_end < 0 ? (K + BK - 1) / BK : t_end) - t_begin;      // number of K-steps of this block (>= 1)
     int k_loaded = 0;
     auto gload = [&](int t) {
-        const int k0 = t * BK;
+        const int k0 = (t_begin + t) * BK;
         k_loaded = k0;
         lb.begin_tile(k0);
 #pragma unroll
@@ -174,12 +178,12 @@ __device__ __forceinline__ void mfma_gemm_block_vec(float* lds, LoaderA& la, Loa
 #pragma unroll
         for (int p = 0; p < A_PASSES; ++p) {
             la.fix(ra[p], k_loaded + a_row0 + p * A_RPP);
-            *reinterpret_cast<float4*>(&As[(buf * BK + a_row0 + p * A_RPP) * BM + a_col]) = ra[p];
+            if (a_on) *reinterpret_cast<float4*>(&As[(buf * BK + a_row0 + p * A_RPP) * BM + a_col]) = ra[p];
         }
 #pragma unroll
         for (int p = 0; p < B_PASSES; ++p) {
             lb.fix(rb[p], p);
-            *reinterpret_cast<float4*>(&Bs[(buf * BK + b_row0 + p * B_RPP) * BN + b_col]) = rb[p];
+            if (b_on) *reinterpret_cast<float4*>(&Bs[(buf * BK + b_row0 + p * B_RPP) * BN + b_col]) = rb[p];
         }
     };
     gload(0);

@@ -190,8 +190,14 @@ def conv2d(x, Wt, scale, shift, KH, KW, stride, pad, relu, residual=None, tap_ma
     OH = (H + 2 * pad - KH) // stride + 1
     OW = (W + 2 * pad - KW) // stride + 1
     y = torch.empty((B, Cout, OH, OW), dtype=_f32, device=x.device)
-    call("di2p_conv2d", ptr(x), ptr(Wt), ptr(scale), ptr(shift), ptr(residual), ptr(y), B, Cin, H, W, Cout, KH, KW,
-         stride, pad, int(bool(relu)), int(bool(tap_major)), stream())
+    args = (ptr(x), ptr(Wt), ptr(scale), ptr(shift), ptr(residual), ptr(y), B, Cin, H, W, Cout, KH, KW,
+            stride, pad, int(bool(relu)), int(bool(tap_major)))
+    nws = _lib.load().di2p_conv2d_workspace_bytes(B, Cin, H, W, Cout, KH, KW, stride, pad, int(bool(tap_major)))
+    if nws > 0:       # split-K scratch (stream-ordered: the caching allocator hands it out per stream)
+        ws = torch.empty((nws,), dtype=torch.uint8, device=x.device)
+        call("di2p_conv2d_ws", *args, ptr(ws), nws, stream())
+    else:
+        call("di2p_conv2d", *args, stream())
     return y
 
 

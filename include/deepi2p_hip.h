@@ -145,6 +145,16 @@ int di2p_attention_pool(const float* feat, const float* score, float* out, int B
 int di2p_conv2d(const float* x, const float* Wt, const float* scale, const float* shift,
                 const float* residual, float* y, int B, int Cin, int H, int W, int Cout,
                 int KH, int KW, int stride, int pad, int relu, int tap_major, void* stream);
+/* Same, with scratch for split-K: layers with few output pixels (ResNet stage 4) are cut into K-slices along the
+ * filter taps, the partial sums (slices x B*Cout*OH*OW floats) are combined in slice order by a second pass.
+ * di2p_conv2d_workspace_bytes returns the size this shape wants (0: no split); a NULL / too small workspace
+ * silently runs unsplit.  Results are deterministic either way. */
+int di2p_conv2d_ws(const float* x, const float* Wt, const float* scale, const float* shift,
+                   const float* residual, float* y, int B, int Cin, int H, int W, int Cout,
+                   int KH, int KW, int stride, int pad, int relu, int tap_major,
+                   void* workspace, long long workspace_bytes, void* stream);
+long long di2p_conv2d_workspace_bytes(int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                                      int tap_major);
 int di2p_maxpool3x3s2(const float* x, float* y, int B, int C, int H, int W, void* stream);
 int di2p_global_avgpool(const float* x, float* y, int B, int C, int HW, void* stream);
 /* out[b,c] = max_n x[b,c,n]  (networks_pc.py:115) */

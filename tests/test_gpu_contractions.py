@@ -26,7 +26,7 @@ def test_pointwise_gemm_dense(dev, B, M, K, N):
 
 
 @pytest.mark.parametrize("B,chans,M,N", [(3, (24, 40, 5), 100, 1500), (2, (96,), 128, 20480), (1, (7,), 32, 260),
-                                        (2, (64, 64), 512, 2048), (2, (33,), 4, 8)])
+                                        (2, (64, 64), 512, 2048), (2, (33,), 4, 8), (2, (33,), 68, 12)])
 def test_pointwise_gemm_dense_vector_path(dev, B, chans, M, N):
     """16-byte staged path (all sources dense, N % 4 == 0, M % 4 == 0): ragged K, M and N against torch and against the
     scalar stager."""
@@ -157,10 +157,19 @@ def test_conv2d(dev, B, Cin, H, W, Cout, k, s, p):
     assert (y - ref).abs().max() <= _tol(ref0, Cin * k * k)
     y2 = ops.conv2d(x.to(dev), Wt, scale.to(dev), shift.to(dev), k, k, s, p, False).cpu()
     assert (y2 - ref0).abs().max() <= _tol(ref0, Cin * k * k)
-    if Cin % 16 == 0:   # tap-major weight packing (kh,kw,ci): same result
+    if Cin % 16 == 0:   # tap-major weight packing (kh,kw,ci): same result (split-K with its ordered reduce pass where the shape asks for it)
         Wtap = w.permute(2, 3, 1, 0).reshape(-1, Cout).contiguous().to(dev)
         y3 = ops.conv2d(x.to(dev), Wtap, scale.to(dev), shift.to(dev), k, k, s, p, True, residual=res.to(dev), tap_major=True).cpu()
         assert (y3 - ref).abs().max() <= _tol(ref0, Cin * k * k)
+        import os
+        os.environ["DI2P_CONV_NOSPLIT"] = "1"
+        try:
+            y4 = ops.conv2d(x.to(dev), Wtap, scale.to(dev), shift.to(dev), k, k, s, p, True, residual=res.to(dev), tap_major=True).cpu()
+        finally:
+            del os.environ["DI2P_CONV_NOSPLIT"]
+        assert (y4 - y3).abs().max() <= _tol(ref0, Cin * k * k)
+        y5 = ops.conv2d(x.to(dev), Wtap, scale.to(dev), shift.to(dev), k, k, s, p, True, residual=res.to(dev), tap_major=True).cpu()
+        assert torch.equal(y5, y3)                                    # run-to-run identical (ordered split-K reduce, no atomics)
 
 
 def test_pools(dev):
