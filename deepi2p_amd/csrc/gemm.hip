@@ -129,6 +129,8 @@ struct EpiPointwise {
     EpiDev e;
     float* Y;
     int b, M, N;
+    float* lds_tile = nullptr;   // fused chains: write the tile to LDS as the next layer's [k = m][n - lds_n0] operand panel
+    int lds_n0 = 0, lds_ld = 0;
     __device__ __forceinline__ void tile(int mrow0, int n, const f32x16& acc) {
         const bool col_ok = n < N;
         const int nc = col_ok ? n : N - 1;
@@ -169,7 +171,13 @@ struct EpiPointwise {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
         }
-        if (e.group_max > 1) {
+        if (lds_tile) {          // columns past N hold clamped (finite) duplicates; they are never stored to memory
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+                if (m < M) lds_tile[m * lds_ld + (n - lds_n0)] = v[r];
+            }
+        } else if (e.group_max > 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mrow0 + (r & 3) + 8 * (r >> 2);
@@ -220,6 +228,67 @@ __global__ __launch_bounds__(Cfg::THREADS) void pointwise_gemm_vec_kernel(SrcDev
     lb.K = K;
     EpiPointwise ep{epi, Y, (int)blockIdx.z, M, N};
     mfma_gemm_block_vec<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
+}
+
+// ---- fused per-point head (per_point_pn of networks_united.py:57-74,194-197, coarse variant 736 -> 128 -> 128 -> P):
+// layer 0 (dense channels + gathered per-node products), layer 1 and the P-channel output layer in ONE kernel.  A
+// workgroup owns 64 points; the 128 x 64 activation tile of layer 0 is written to LDS in operand layout, layer 1 reads
+// it from there (mfma_gemm_block_blds) and overwrites it with its own output, and the output layer is a 128-term fma
+// chain per (point, class) in the k order of the MFMA -- so the result is BIT-IDENTICAL to the three separate launches,
+// while the two 128-channel activations (2 x 335 MB written and read back per 32-frame step) never leave the CU.
+struct HeadTail {
+    const float* W1t;      // [M][M]   layer-1 weight, k-major
+    const float* sc1;
+    const float* sh1;
+    const float* W2t;      // [M][P]
+    const float* sc2;
+    const float* sh2;
+    int relu1, relu2, P;
+};
+using HeadCfg = TileCfg<2, 2, 2, 1, 32>;       // 128 rows x 64 points, 4 waves of 64 x 32
+constexpr int HEAD_M = 128, HEAD_BN = 64;
+
+__global__ __launch_bounds__(HeadCfg::THREADS) void point_head_kernel(SrcDev srcs, const float* __restrict__ W0t, int K0, EpiDev e0,
+                                                                       HeadTail tl, float* __restrict__ out, int N) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* stage = lds;                              // operand staging of the tile engine
+    float* hbuf = lds + HeadCfg::LDS_FLOATS;         // [HEAD_M][HEAD_BN] activation tile
+    const int b = blockIdx.y, j_blk = blockIdx.x * HEAD_BN;
+    {   // layer 0
+        LoaderWt4 la{W0t, K0, HEAD_M};
+        LoaderConcat4<true> lb;
+        lb.s = srcs; lb.b = b; lb.N = N; lb.K = K0;
+        EpiPointwise ep{e0, nullptr, b, HEAD_M, N};
+        ep.lds_tile = hbuf; ep.lds_n0 = j_blk; ep.lds_ld = HEAD_BN;
+        mfma_gemm_block_vec<HeadCfg>(stage, la, lb, ep, K0, 0, j_blk);
+    }
+    __syncthreads();
+    {   // layer 1: B operand = hbuf, output back into hbuf
+        LoaderWt4 la{tl.W1t, HEAD_M, HEAD_M};
+        EpiDev e1{};
+        e1.scale = tl.sc1; e1.shift = tl.sh1; e1.relu = tl.relu1; e1.group_max = 1;
+        EpiPointwise ep{e1, nullptr, b, HEAD_M, N};
+        ep.lds_tile = hbuf; ep.lds_n0 = j_blk; ep.lds_ld = HEAD_BN;
+        mfma_gemm_block_blds<HeadCfg>(stage, la, hbuf, HEAD_BN, ep, HEAD_M, 0, j_blk);
+    }
+    __syncthreads();
+    // output layer: wave p computes class p for the 64 points (k ascending: the order of the MFMA accumulation)
+    const int lane = threadIdx.x & 63, p = threadIdx.x >> 6;
+    const int n = j_blk + lane;
+    if (p < tl.P) {
+        float a = 0.0f;
+        for (int k0 = 0; k0 < HEAD_M; k0 += 16) {      // operands of 16 steps fetched together, then the ordered fma chain
+            float w[16], h[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { w[u] = tl.W2t[(k0 + u) * tl.P + p]; h[u] = hbuf[(k0 + u) * HEAD_BN + lane]; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a = fmaf(w[u], h[u], a);
+        }
+        if (tl.sc2) a *= tl.sc2[p];
+        if (tl.sh2) a += tl.sh2[p];
+        if (tl.relu2) a = fmaxf(a, 0.0f);
+        if (n < N) out[((long long)b * tl.P + p) * N + n] = a;
+    }
 }
 
 // ---- attention pooling: out[b,c,m] = (1/HW) sum_hw feat[b,c,hw] * score[b,hw,m]
@@ -370,6 +439,44 @@ extern "C" int di2p_pointwise_gemm(const di2p_src_t* srcs, int n_src, const floa
     if (M <= 32) launch_pw<Cfg32x128>(s, Wt, Y, B, M, K, N, e, st);
     else if (M <= 64 || (long long)B * di2p_cdiv(N, 128) * di2p_cdiv(M, 128) < 256) launch_pw<Cfg64x128>(s, Wt, Y, B, M, K, N, e, st);
     else launch_pw<Cfg128x128>(s, Wt, Y, B, M, K, N, e, st);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_point_head(const di2p_src_t* srcs, int n_src, const float* W0t, int K0, const di2p_epilogue_t* epi0,
+                               const float* W1t, const float* scale1, const float* shift1, int relu1, const float* W2t,
+                               const float* scale2, const float* shift2, int relu2, float* out, int B, int M, int P, int N,
+                               void* stream) {
+    DI2P_CHECK_ARG(srcs && n_src >= 1 && n_src <= DI2P_MAX_SRC && W0t && W1t && W2t && out && epi0, "null pointer");
+    DI2P_CHECK_ARG(M == HEAD_M && P >= 1 && P <= 4, "fused head: hidden width 128, at most 4 outputs (use the separate layers otherwise)");
+    DI2P_CHECK_ARG(B >= 0 && N >= 4 && N % 4 == 0 && K0 >= 1, "bad size");
+    DI2P_CHECK_ARG(epi0->group_max <= 1 && !epi0->transpose_out, "fused head: layer 0 takes scale/shift/relu/bias/gathered only");
+    if (B == 0) return 0;
+    SrcDev s{};
+    int ctot = 0;
+    for (int i = 0; i < DI2P_MAX_SRC; ++i) {
+        if (i < n_src) {
+            DI2P_CHECK_ARG(srcs[i].ptr && srcs[i].channels > 0 && srcs[i].mode == DI2P_SRC_DENSE, "fused head: dense sources only");
+            DI2P_CHECK_ARG(srcs[i].row_stride % 4 == 0 && srcs[i].batch_stride % 4 == 0 && aligned16(srcs[i].ptr), "sources must be 16-byte addressable");
+            DI2P_CHECK_ARG((long long)srcs[i].channels * srcs[i].row_stride < (1ll << 31), "per-frame source extent must fit 31 bits");
+            s.ptr[i] = srcs[i].ptr; s.batch_stride[i] = srcs[i].batch_stride; s.row_stride[i] = srcs[i].row_stride; s.mode[i] = DI2P_SRC_DENSE; s.group[i] = 1;
+            ctot += srcs[i].channels;
+        }
+        s.c_end[i] = ctot;
+    }
+    s.n_src = n_src;
+    DI2P_CHECK_ARG(ctot == K0, "source channels do not sum to K0");
+    DI2P_CHECK_ARG(aligned16(W0t) && aligned16(W1t), "weights must be 16-byte aligned");
+    EpiDev e{};
+    e.group_max = 1;
+    e.scale = epi0->scale; e.shift = epi0->shift; e.batch_bias = epi0->batch_bias; e.relu = epi0->relu;
+    for (int t = 0; t < 2; ++t) { e.g_table[t] = epi0->g_table[t]; e.g_idx[t] = epi0->g_idx[t]; e.g_w[t] = epi0->g_w[t]; e.g_nodes[t] = epi0->g_nodes[t]; }
+    e.g_k = epi0->g_k;
+    DI2P_CHECK_ARG(e.g_k >= 0 && e.g_k <= 4, "g_k must be <= 4");
+    HeadTail tl{W1t, scale1, shift1, W2t, scale2, shift2, relu1, relu2, P};
+    const size_t lds = (HeadCfg::LDS_FLOATS + HEAD_M * HEAD_BN) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)point_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    hipLaunchKernelGGL(point_head_kernel, dim3(di2p_cdiv(N, HEAD_BN), B), dim3(HeadCfg::THREADS), lds, (hipStream_t)stream, s, W0t, K0, e, tl, out, N);
     DI2P_RETURN_LAUNCH();
 }
 

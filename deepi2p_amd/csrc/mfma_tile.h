@@ -234,3 +234,93 @@ __device__ __forceinline__ void mfma_gemm_block_vec(float* lds, LoaderA& la, Loa
             epi.tile(mrow0, jcol, acc[i][j]);
         }
 }
+
+
+// ----------------------------------------------------------------------------------------------------------------
+// Variant for fused layer chains: the B operand is ALREADY in LDS as a [K][ldb] panel (the previous layer's output tile),
+// only A (weights [K][M], M % 4 == 0) is staged.  Same K order, same MFMA sequence as mfma_gemm_block_vec, so a layer
+// computed here is bit-identical to the same layer computed from global memory.  The accumulators are handed to
+// epi.tile() after a workgroup barrier (the epilogue may overwrite the B panel).
+template <class Cfg, class LoaderA, class Epi>
+__device__ __forceinline__ void mfma_gemm_block_blds(float* lds, LoaderA& la, const float* Bpanel, int ldb, Epi& epi, int K, int m_blk,
+                                                     int j_blk) {
+    constexpr int BM = Cfg::BM, BK = Cfg::BK;
+    constexpr int A_TPR = BM / 4;
+    constexpr int A_RPP = Cfg::THREADS / A_TPR;
+    constexpr int A_PASSES = BK >= A_RPP ? BK / A_RPP : 1;
+    static_assert(BK % A_RPP == 0 || A_RPP % BK == 0, "tile/threads mismatch");
+    float* As = lds;       // [2][BK][BM]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int a_col = (tid % A_TPR) * 4, a_row0 = tid / A_TPR;
+    const bool a_on = A_RPP <= BK || a_row0 < BK;
+
+    f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 ra[A_PASSES];
+    const int T = (K + BK - 1) / BK;
+    int k_loaded = 0;
+    auto gload = [&](int t) {
+        k_loaded = t * BK;
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) ra[p] = la.load4(k_loaded + a_row0 + p * A_RPP, m_blk + a_col);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) {
+            la.fix(ra[p], k_loaded + a_row0 + p * A_RPP);
+            if (a_on) *reinterpret_cast<float4*>(&As[(buf * BK + a_row0 + p * A_RPP) * BM + a_col]) = ra[p];
+        }
+    };
+    auto compute = [&](int t) {
+        const float* Ab = As + (t & 1) * BK * BM + wm * Cfg::TM * 32 + l31;
+        const float* Bb = Bpanel + (long long)t * BK * ldb + wn * Cfg::TN * 32 + l31;
+        float a[2][Cfg::TM], b[2][Cfg::TN];
+        auto fread = [&](int kk, int s) {
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i) a[s][i] = Ab[(kk + half) * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) b[s][j] = (t * BK + kk + half < K) ? Bb[(kk + half) * ldb + j * 32] : 0.0f;
+        };
+        fread(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int s = (kk >> 1) & 1;
+            if (kk + 2 < BK) fread(kk + 2, s ^ 1);
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+        }
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int t = 0; t + 1 < T; ++t) {
+        gload(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(t);
+        __builtin_amdgcn_sched_barrier(0);
+        lstore((t & 1) ^ 1);
+        __syncthreads();
+    }
+    compute(T - 1);
+    __syncthreads();          // every wave is done with the B panel: the epilogue may overwrite it
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) {
+            const int jcol = j_blk + (wn * Cfg::TN + j) * 32 + l31;
+            const int mrow0 = m_blk + (wm * Cfg::TM + i) * 32 + 4 * half;
+            epi.tile(mrow0, jcol, acc[i][j]);
+        }
+}

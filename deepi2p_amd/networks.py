@@ -294,6 +294,8 @@ class ImageEncoder(_PackedModule):
 
 # ------------------------------------------------------------------ fusion classifier
 class KeypointDetector(_PackedModule):
+    fuse_head = True      # coarse per_point_pn as ONE launch (ops.point_head); False: three pointwise_gemm launches (tests compare)
+
     def __init__(self, opt):
         super().__init__()
         self.opt = opt
@@ -364,9 +366,14 @@ class KeypointDetector(_PackedModule):
         M0 = Wt.shape[1]
         G_a = ops.pointwise_gemm([Src(up_a)], Wt[0:128], M0, Ma, transpose_out=True)     # [B,Ma,M0] node-major
         G_b = ops.pointwise_gemm([Src(up_b)], Wt[128:640], M0, Mb, transpose_out=True)
-        h = ops.pointwise_gemm([Src(first), Src(second)], Wt[640:736], M0, N, scale=sc, shift=sh, relu=act,
-                               gathered=[(G_a, idx_a, ex["w_a"]), (G_b, idx_pb, w_pb)])
-        scores = _run_pn(h, p["per_point_pn"][1:])
+        gathered = [(G_a, idx_a, ex["w_a"]), (G_b, idx_pb, w_pb)]
+        l1, l2 = p["per_point_pn"][1], p["per_point_pn"][2]
+        if M0 == 128 and l1[0].shape[1] == 128 and l2[0].shape[1] <= 4 and N % 4 == 0 and self.fuse_head:
+            # coarse head: the three layers in one launch, hidden activations stay in LDS (bit-identical to the chain below)
+            scores = ops.point_head([Src(first), Src(second)], (Wt[640:736], sc, sh, act), l1, l2, N, gathered=gathered)
+        else:
+            h = ops.pointwise_gemm([Src(first), Src(second)], Wt[640:736], M0, N, scale=sc, shift=sh, relu=act, gathered=gathered)
+            scores = _run_pn(h, p["per_point_pn"][1:])
         coarse = scores[:, 0:2, :]
         if self.opt.is_fine_resolution:
             return coarse, scores[:, 2:, :]

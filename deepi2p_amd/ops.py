@@ -163,6 +163,44 @@ def pointwise_gemm(srcs, Wt, M, N, scale=None, shift=None, batch_bias=None, relu
     return Y
 
 
+def _fill_srcs(srcs):
+    arr = (SrcT * len(srcs))()
+    for i, s in enumerate(srcs):
+        arr[i].ptr = ptr(s.t)
+        arr[i].gidx = ptr(s.gidx)
+        arr[i].batch_stride = s.t.stride(0)
+        arr[i].row_stride = s.t.stride(1)
+        arr[i].channels = s.t.shape[1]
+        arr[i].mode = s.mode
+        arr[i].group = s.group
+    return arr
+
+
+def point_head(srcs, layer0, layer1, layer2, N, batch_bias=None, gathered=None):
+    """Fused three-layer per-point head (di2p_point_head): layers are (Wt[K,M], scale, shift, relu) tuples with hidden
+    width 128 and at most 4 outputs; layer0's Wt holds only the rows of the dense `srcs`.  -> f32[B, P, N]."""
+    Wt0, sc0, sh0, act0 = layer0
+    Wt1, sc1, sh1, act1 = layer1
+    Wt2, sc2, sh2, act2 = layer2
+    B = srcs[0].t.shape[0]
+    M, P = Wt0.shape[1], Wt2.shape[1]
+    require_cuda(Wt0, Wt1, Wt2, sc0, sh0, sc1, sh1, sc2, sh2, batch_bias)
+    e = EpilogueT()
+    e.scale, e.shift, e.batch_bias = ptr(sc0), ptr(sh0), ptr(batch_bias)
+    e.relu, e.group_max, e.g_k, e.transpose_out = int(bool(act0)), 1, 0, 0
+    if gathered:
+        for t, (tab, gi, gw) in enumerate(gathered):
+            require_cuda(tab, gi, gw)
+            assert tab.shape[2] == M and gi.dtype == _i32
+            e.g_table[t], e.g_idx[t], e.g_w[t] = ptr(tab), ptr(gi), ptr(gw)
+            e.g_nodes[t] = tab.shape[1]
+            e.g_k = gi.shape[2]
+    out = torch.empty((B, P, N), dtype=_f32, device=Wt0.device)
+    call("di2p_point_head", _fill_srcs(srcs), len(srcs), ptr(Wt0), Wt0.shape[0], ctypes.byref(e), ptr(Wt1), ptr(sc1), ptr(sh1),
+         int(bool(act1)), ptr(Wt2), ptr(sc2), ptr(sh2), int(bool(act2)), ptr(out), B, M, P, N, stream())
+    return out
+
+
 def batch_gemv(Wt, k0, v):
     """out[b,m] = sum_k Wt[k0+k, m] v[b,k]."""
     require_cuda(Wt, v)

@@ -128,6 +128,16 @@ int di2p_pointwise_gemm(const di2p_src_t* srcs_host, int n_src, const float* Wt,
 
 /* Y[b,m] = sum_k Wt[k0+k, m] * v[b,k]  (the broadcast part of a concatenated input, folded into
  * batch_bias: networks_united.py:139-155,170-187 expand()s).  v f32[B,Kv]. */
+/* Fused per-point head (per_point_pn, networks_united.py:57-74,194-197, coarse variant): three pointwise layers in
+ * one launch, out = L2(L1(L0(concat(srcs)))) with
+ *   L0: K0 dense channels -> M = 128, epilogue epi0 (scale/shift/relu, batch_bias, gathered node tables),
+ *   L1: 128 -> 128 (W1t f32[128,128] k-major, scale1/shift1, relu1),   L2: 128 -> P <= 4 (W2t f32[128,P], scale2/shift2 or NULL).
+ * out f32[B,P,N].  Bit-identical to three di2p_pointwise_gemm calls; the hidden activations stay in LDS. */
+int di2p_point_head(const di2p_src_t* srcs_host, int n_src, const float* W0t, int K0, const di2p_epilogue_t* epi0_host,
+                    const float* W1t, const float* scale1, const float* shift1, int relu1,
+                    const float* W2t, const float* scale2, const float* shift2, int relu2,
+                    float* out, int B, int M, int P, int N, void* stream);
+
 int di2p_batch_gemv(const float* Wt, int M, int k0, const float* v, int Kv, float* out, int B, void* stream);
 
 /* Batched attention contraction of networks_united.py:147-150,170-174:

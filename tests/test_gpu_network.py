@@ -114,3 +114,23 @@ def test_full_size_forward_properties(dev):
     assert torch.equal(out, out2)
     one = det(*[t[k][2:3].contiguous() for k in ("pc", "intensity", "sn", "node_a", "node_b", "img")])
     assert torch.equal(one[0], out[2])
+
+
+@pytest.mark.parametrize("N", [2048, 1000])
+def test_fused_point_head_is_bit_identical(dev, N):
+    """The coarse per_point_pn as one launch (hidden activations in LDS) must reproduce the three separate pointwise
+    launches bit for bit: same K order in the MFMA chain, same epilogue arithmetic; N = 1000 leaves a ragged last tile."""
+    from deepi2p_amd import synthetic
+    H, W = 64, 128
+    det, opt = _detector(dev, N, H, W, False)
+    batch = synthetic.make_batch(5, 2, N=N, H=H, W=W)
+    x = [torch.from_numpy(batch[k]).to(dev) for k in ("pc", "intensity", "sn", "node_a", "node_b", "img")]
+    assert det.fuse_head
+    fused = det(*x)
+    det.fuse_head = False
+    try:
+        chain = det(*x)
+    finally:
+        del det.fuse_head
+    assert fused.shape == chain.shape == (2, 2, N)
+    assert torch.equal(fused, chain)

@@ -104,6 +104,10 @@ int main(int argc, char** argv) {
         if (M >= 128) run<TileCfg<2, 2, 2, 2, 32>, KcCfg<2, 2, 2, 2>>(M, K, N, "128x128");
         run<TileCfg<2, 2, 1, 2, 32>, KcCfg<2, 2, 1, 2>>(M, K, N, "64x128");
         run<TileCfg<2, 2, 1, 1, 32>, KcCfg<2, 1, 1, 2>>(M, K, N, "64x64");
+        // 8-wave workgroups (second column is the kc engine at the nearest shape it supports; ignore it here)
+        if (M >= 128) run<TileCfg<2, 4, 2, 1, 32>, KcCfg<2, 2, 2, 2>>(M, K, N, "128x128w8");
+        run<TileCfg<2, 4, 1, 1, 32>, KcCfg<2, 2, 1, 2>>(M, K, N, "64x128w8");
+        if (M >= 128) run<TileCfg<4, 2, 1, 2, 32>, KcCfg<2, 2, 2, 2>>(M, K, N, "128x128w8b");
     }
     return 0;
 }
