@@ -167,6 +167,53 @@ struct LoaderIm2colTap4 {
     }
 };
 
+// Vector stager for weights in their own (ci,kh,kw) order -- the 7x7/2 stem (Cin = 3: no tap holds a whole K-step).  Each
+// staged row decodes its own (ci,kh,kw) (divisions by compile-time constants), loads 4 output pixels of one output row as
+// four clamped scalars (unconditional), and remembers the in-image mask of the pass for fix().
+template <int KH_, int KW_, int STRIDE>
+struct LoaderIm2colRow4 {
+    const float* x;
+    int Cin, H, W, OH, OW, pad, K, Ntot;
+    const float* xb;
+    int ih0, iw0, HW;
+    unsigned okmask[4];
+    int pass;
+    __device__ __forceinline__ void column4(int j) {
+        const int jj = j < Ntot ? j : 0;
+        const int opix = OH * OW;
+        const int b = jj / opix, pix = jj - b * opix;
+        const int oh = pix / OW, ow = pix - oh * OW;
+        HW = H * W;
+        xb = x + (long long)b * Cin * HW;
+        ih0 = oh * STRIDE - pad;
+        iw0 = ow * STRIDE - pad;
+        pass = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) okmask[p] = 0;
+    }
+    __device__ __forceinline__ void begin_tile(int) { pass = 0; }
+    __device__ __forceinline__ float4 load4(int k) {
+        const int kc = min(k, K - 1);                 // rows k >= K meet zero weights
+        const int ci = kc / (KH_ * KW_), rem = kc - ci * (KH_ * KW_);
+        const int kh = rem / KW_, kw = rem - kh * KW_;
+        const int ih = ih0 + kh, iw = iw0 + kw;
+        const bool row_ok = (unsigned)ih < (unsigned)H;
+        const float* r = xb + (ci * H + min(max(ih, 0), H - 1)) * W;
+        const int c0 = min(max(iw, 0), W - 1), c1 = min(max(iw + STRIDE, 0), W - 1);
+        const int c2 = min(max(iw + 2 * STRIDE, 0), W - 1), c3 = min(max(iw + 3 * STRIDE, 0), W - 1);
+        const unsigned m = !row_ok ? 0u : ((unsigned)iw < (unsigned)W ? 1u : 0u) | ((unsigned)(iw + STRIDE) < (unsigned)W ? 2u : 0u) |
+                                          ((unsigned)(iw + 2 * STRIDE) < (unsigned)W ? 4u : 0u) | ((unsigned)(iw + 3 * STRIDE) < (unsigned)W ? 8u : 0u);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) if (p == pass) okmask[p] = m;      // pass is a compile-time constant after unrolling
+        ++pass;
+        return make_float4(r[c0], r[c1], r[c2], r[c3]);
+    }
+    __device__ __forceinline__ void fix(float4& v, int p) const {
+        const unsigned m = okmask[p & 3];
+        v.x = (m & 1u) ? v.x : 0.0f; v.y = (m & 2u) ? v.y : 0.0f; v.z = (m & 4u) ? v.z : 0.0f; v.w = (m & 8u) ? v.w : 0.0f;
+    }
+};
+
 // BN(eval) + residual + ReLU.  Per-row operands and the residual are fetched first (clamped addresses, independent
 // loads), arithmetic and stores follow: no load -> wait -> store chain per accumulator register.
 struct EpiConv {
@@ -287,6 +334,21 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv2d_vec_kernel(const float* _
         lb.pending_seek = t0;
         mfma_gemm_block_vec<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN, t0, t1);
     }
+}
+
+// the 7x7 stride-2 pad-3 stem on the vector stager
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::THREADS) void conv2d_stem_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
+                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                    const float* __restrict__ residual, float* __restrict__ y, int Cin,
+                                                                    int H, int W, int Cout, int OH, int OW, int pad, int Ntot, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int K = Cin * 49;
+    LoaderWt4 la{Wt, K, Cout};
+    EpiConv ep{scale, shift, residual, y, Cout, OH * OW, Ntot, relu};
+    LoaderIm2colRow4<7, 7, 2> lb;
+    lb.x = x; lb.Cin = Cin; lb.H = H; lb.W = W; lb.OH = OH; lb.OW = OW; lb.pad = pad; lb.K = K; lb.Ntot = Ntot;
+    mfma_gemm_block_vec<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
 }
 
 template <class Cfg>
@@ -417,6 +479,15 @@ int conv2d_impl(const float* x, const float* Wt, const float* scale, const float
     else choice = 0;
     if (force >= 0) { choice = force % 10; if (choice >= 2 && Cout < 128) choice = 1; }
     const bool use32 = k32 && (force < 0 || force >= 10);
+    // the 7x7/2 stem (weights in their own order): row-decoding vector stager
+    if (!tap_major && KH == 7 && KW == 7 && stride == 2 && OW % 4 == 0 && Cout % 4 == 0 && ((uintptr_t)Wt & 15) == 0 &&
+        getenv("DI2P_CONV_NOVEC") == nullptr) {
+        using CfgS = TileCfg<2, 2, 1, 2, 32>;      // 64 x 128, B_PASSES = 4 (one mask per pass)
+        const dim3 grid(di2p_cdiv(Ntot, CfgS::BN), di2p_cdiv(Cout, CfgS::BM));
+        hipLaunchKernelGGL(conv2d_stem_kernel<CfgS>, grid, dim3(CfgS::THREADS), CfgS::LDS_FLOATS * sizeof(float), st, x, Wt, scale, shift,
+                           residual, y, Cin, H, W, Cout, OH, OW, pad, Ntot, relu);
+        DI2P_RETURN_LAUNCH();
+    }
     // vector stager: tap-major weights, 32-channel taps, whole 4-pixel groups per output row, 16-byte aligned weights
     static int novec = -1;
     if (novec < 0) { const char* e = getenv("DI2P_CONV_NOVEC"); novec = e ? atoi(e) : 0; }
