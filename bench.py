@@ -47,6 +47,27 @@ def conv_flops_per_frame(H, W):
     return 2 * total
 
 
+def conv_bytes_per_frame(H, W):
+    """Compulsory HBM bytes of the same convolutions: every input / residual read once, every output written once
+    (fp32); the weights (85 MB, shared by the batch) are added once per step by the caller."""
+    def out(h, k, s, p):
+        return (h + 2 * p - k) // s + 1
+    h, w = out(H, 7, 2, 3), out(W, 7, 2, 3)
+    elems = 3 * H * W + 64 * h * w
+    h, w = out(h, 3, 2, 1), out(w, 3, 2, 1)
+    inpl = 64
+    for li, (planes, nb) in enumerate(zip((64, 128, 256, 512), (3, 4, 6, 3)), start=1):
+        for bi in range(nb):
+            s = 2 if (bi == 0 and li > 1) else 1
+            oh, ow = out(h, 3, s, 1), out(w, 3, s, 1)
+            elems += inpl * h * w + planes * oh * ow                 # conv1: in, out
+            elems += planes * oh * ow * 3                            # conv2: in, residual, out
+            if bi == 0 and li > 1:
+                elems += inpl * h * w + planes * oh * ow             # 1x1 downsample: in, out
+            h, w, inpl = oh, ow, planes
+    return 4 * elems
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,7 +186,7 @@ def main():
     dt = time.perf_counter() - t0
     # per-kernel-family durations: HIP events on the launch stream, in a SERIAL pass right after the timed region
     # (with several batches in flight, events inside the timed region would measure contention, not the kernels)
-    timed_names = ("di2p_conv2d", "di2p_conv2d_ws", "di2p_pointwise_gemm", "di2p_index_max_values", "di2p_solve_batched_f32", "di2p_knn_nodes")
+    timed_names = ("di2p_conv2d", "di2p_conv2d_ws", "di2p_pointwise_gemm", "di2p_point_head", "di2p_index_max_values", "di2p_solve_batched_f32", "di2p_knn_nodes")
     prof_steps = 2
     overlap_saved, overlap = overlap, False
     _lib.TIMED = {n: [] for n in timed_names}
@@ -188,6 +209,9 @@ def main():
     # the convolution family = the plain entry point + the split-K one (stage-4 layers: K-slice kernel + ordered reduce pass)
     fam_ms["di2p_conv2d"] += fam_ms.pop("di2p_conv2d_ws")
     launches["di2p_conv2d"] += launches.pop("di2p_conv2d_ws")
+    # pointwise family = the single-layer launches + the fused three-layer point head
+    fam_ms["di2p_pointwise_gemm"] += fam_ms.pop("di2p_point_head")
+    launches["di2p_pointwise_gemm"] += launches.pop("di2p_point_head")
     conv_flops = conv_flops_per_frame(H, W) * B
     idx_bytes = B * (4 * 32 * N + 4 * N + 2 * 4 * 32 * 128) + B * (4 * 64 * N + 4 * N + 2 * 4 * 64 * 128)
     iters = out["iters"].float()
@@ -203,21 +227,22 @@ def main():
         "solve_kernel(fp64 VALU, not hbm/mfma bound)": {
             "ms_per_step": fam_ms["di2p_solve_batched_f32"], "mean_iters": float(iters.mean()), "max_iters": float(iters.max()),
             "points_per_sweep": n_active, "sweeps_lower_bound": solver_sweeps},
-        "pointwise_gemm_kernel": {"ms_per_step": fam_ms["di2p_pointwise_gemm"], "launches_per_step": launches["di2p_pointwise_gemm"]},
+        "pointwise_gemm_kernel(+point_head)": {"ms_per_step": fam_ms["di2p_pointwise_gemm"], "launches_per_step": launches["di2p_pointwise_gemm"]},
         "knn_nodes_kernel": {"ms_per_step": fam_ms["di2p_knn_nodes"], "launches_per_step": launches["di2p_knn_nodes"]},
     }
     for r in roofs.values():
         if "achieved" in r:
             r["frac"] = r["achieved"] / r["peak"]
     dom = roofs["conv2d_kernel(implicit-GEMM fp32 MFMA)"]
-    # HBM traffic per launch from the committed PMC passes of the same kernels on the same shapes (separate
-    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, profiles/r01_pmc_traffic.json); None if the file is absent
+    # HBM traffic per convolution call from the committed PMC passes of the same kernels on the same shapes (separate
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH x2 for the 16-byte/lane loads as MI355X_MICROARCH.md prescribes;
+    # profiles/r01_pmc_traffic.json); None if the file is absent
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
             pmc = json.load(fh)
         if B == 32 and (H, W) == (160, 512):
-            traffic = pmc["conv2d_resnet34_B32_160x512"]["hbm_bytes_per_launch_raw"]
+            traffic = pmc["conv2d_resnet34_B32_160x512"]["hbm_bytes_per_call_corrected"]
             roofs["index_max_kernel"]["traffic_C64"] = pmc["index_max_C64_B32_N20480_K128"]["hbm_bytes_corrected"]
             roofs["index_max_kernel"]["algorithmic_C64"] = pmc["index_max_C64_B32_N20480_K128"]["algorithmic_bytes"]
     except (OSError, KeyError, ValueError):
@@ -225,6 +250,7 @@ def main():
     roofline = {"kernel": "conv2d_kernel", "bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"],
                 "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
                 "algorithmic_flop_per_launch": conv_flops / 36.0,
+                "compulsory_bytes_per_launch": (conv_bytes_per_frame(H, W) * B + 85.1e6) / 36.0,
                 "note": "algorithmic 2*MAC of the 36 ResNet-34 convolution calls of one step / their summed HIP-event time "
                         "(events on the launch stream, serial pass of %d steps directly after the timed region)" % prof_steps}
 
