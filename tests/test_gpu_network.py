@@ -134,3 +134,24 @@ def test_fused_point_head_is_bit_identical(dev, N):
         del det.fuse_head
     assert fused.shape == chain.shape == (2, 2, N)
     assert torch.equal(fused, chain)
+
+
+def test_forward_and_pose_are_run_to_run_identical(dev):
+    """No result depends on the order in which atomics or workgroups retire: segment maxima merge through order-free
+    u64 max, cluster sums are fixed-point integers, split-K partials and the solver's wave partials are combined in a fixed
+    order.  Two runs of the network and of the pose pipeline must agree bit for bit."""
+    from deepi2p_amd import synthetic
+    from deepi2p_amd.registration import RegistrationPipeline
+    N, H, W = 4096, 160, 512
+    det, opt = _detector(dev, N, H, W, False)
+    batch = synthetic.make_batch(9, 2, N=N, H=H, W=W)
+    x = [torch.from_numpy(batch[k]).to(dev) for k in ("pc", "intensity", "sn", "node_a", "node_b", "img")]
+    a, b = det(*x), det(*x)
+    assert torch.equal(a, b)
+    pipe = RegistrationPipeline(H, W, R=12, seed=3)
+    lab = torch.from_numpy(batch["labels"]).to(dev)
+    K = torch.from_numpy(batch["K"]).to(dev)
+    restarts = pipe.draw(2, dev)
+    o1, o2 = pipe(x[0], lab, K, restarts), pipe(x[0], lab, K, restarts)
+    for key in ("P", "costs", "iters", "best"):
+        assert torch.equal(o1[key], o2[key]), key
