@@ -2,10 +2,11 @@
 //
 // conv + BN(eval) + [residual] + [ReLU] as ONE implicit-GEMM kernel on fp32 MFMA:
 //   M = Cout, N = B*OH*OW (output pixels of the whole batch, so /32 maps still fill the chip),
-//   K = Cin*KH*KW in the weight's own (ci,kh,kw) order.  The B operand is the im2col view of the
-//   NCHW input gathered on the fly (never materialised): for a fixed k the 32 lanes of an MFMA
-//   operand read 32 consecutive output pixels = consecutive input addresses (stride 1) of one
-//   input row, i.e. coalesced 128-B segments straight from the reference's own layout.
+//   K = Cin*KH*KW, tap-major (kh,kw,ci) for the 3x3 / 1x1 layers (one filter tap per K-step), the weight's own
+//   (ci,kh,kw) order for the 7x7 stem.  The B operand is the im2col view of the NCHW input gathered on the fly (never
+//   materialised): for a fixed k the lanes of an MFMA operand read consecutive output pixels = consecutive input
+//   addresses (stride 1) of one input row, straight from the reference's own layout; 16-byte loads, padding applied
+//   at LDS-store time, XCD-aware tile order, deterministic split-K for the layers with few output pixels.
 #include "mfma_tile.h"
 
 #include <stdlib.h>

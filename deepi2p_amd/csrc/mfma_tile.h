@@ -8,6 +8,8 @@
 //     (both 32-lane halves read 32 consecutive floats of one panel row);
 //   * the next K-step's global loads are issued before the current step's MFMAs (register
 //     prefetch), so HBM/L2 latency hides under the 64-cycle matrix instructions;
+//   * three entry points: mfma_gemm_block (scalar stager, any shape), mfma_gemm_block_vec (16-byte stager, branch-free
+//     K-loop: the production path) and mfma_gemm_block_blds (B panel already in LDS: fused layer chains);
 //   * accumulators: TM x TN tiles of 16 VGPRs per wave; C/D layout col = lane&31,
 //     row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #pragma once

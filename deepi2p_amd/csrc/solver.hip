@@ -5,16 +5,18 @@
 // functors registration_2d.hpp:35-69,107-129 / registration_3d.hpp:35-68,106-127, and the process
 // waves of evaluation/registration_lsq.py:142-186.
 //
-// One WAVEFRONT per pose hypothesis; a 256-thread workgroup holds 4 hypotheses of one frame so they
-// share the frame's points in L1/L2.  Each lane strides over the points, evaluates residual and
-// ANALYTIC Jacobian rows (the reference differentiates with Jets), robustifies with the Cauchy
-// corrector, and accumulates its share of J^T J (upper triangle), J^T r and the cost in fp64
-// registers; a 6-step xor-butterfly leaves every lane with bit-identical sums, so the whole
-// Levenberg-Marquardt state machine (damping, box projection, Armijo search, accept/reject,
-// termination tests) runs redundantly on all lanes with wave-uniform control flow and needs no LDS
-// and no barriers.  Every trial point is evaluated with its normal equations in the same pass, so an
-// accepted step costs ONE sweep over the points.  The algorithm statement is the oracle's
-// (oracle/frustum_lm.cpp); DESIGN.md lists it step by step.
+// One 4-wave WORKGROUP per pose hypothesis (frame = block % F, so a frame's hypotheses share an XCD's L2).  A sweep
+// over the frame's records evaluates residuals and ANALYTIC Jacobian rows (the reference differentiates with Jets),
+// robustifies with the Cauchy corrector and accumulates J^T J (upper triangle), J^T r and the cost in fp64 registers:
+//   * the records are sorted once per call by (label, Morton cell) into 64-point clusters with bounding boxes
+//     (prepare_kernel); per sweep a box test against the five frustum planes settles most clusters without touching
+//     their points, exactly (cluster_status);
+//   * the remaining clusters are classified per point (phase A), the ACTIVE records are compacted into a per-wave LDS
+//     queue and evaluated densely (phase B); line-search trials beyond the first are swept cost-only;
+//   * wave butterflies + a fixed-order combination of the 4 wave partials give deterministic sums; the
+//     Levenberg-Marquardt state machine (damping, box projection, Armijo search, accept/reject, termination tests) lives
+//     in LDS and is advanced by thread 0 between sweeps.
+// The algorithm statement is the oracle's (oracle/frustum_lm.cpp); DESIGN.md lists it step by step.
 #include "common.h"
 
 #include <float.h>
