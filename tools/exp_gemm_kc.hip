@@ -40,6 +40,103 @@ template <int NB> struct NewB { const float* X; int K, N; int n[NB];
     __device__ __forceinline__ float4 load_row(int g, int k) const { return *reinterpret_cast<const float4*>(X + (size_t)min(k, K - 1) * N + min(n[g], N - 4)); }
     __device__ __forceinline__ void fix(int, float4 (&)[4]) const {} };
 
+template <class F> float time_ms(F f, int iters) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    f(); f(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0)); for (int i = 0; i < iters; ++i) f(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms / iters;
+}
+
+// Ablation copy of mfma_gemm_block_vec: FLAGS bit0 = skip the global loads + LDS stores inside the loop (MFMA + LDS-read
+// loop only, results wrong), bit1 = also skip the barrier, bit2 = skip the LDS operand reads (MFMA issue only).
+template <class Cfg, int FLAGS, class LoaderA, class LoaderB, class Epi>
+__device__ __forceinline__ void ablate_block(float* lds, LoaderA& la, LoaderB& lb, Epi& epi, int K, int m_blk, int j_blk) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
+    constexpr int A_TPR = BM / 4, B_TPR = BN / 4;
+    constexpr int A_RPP = Cfg::THREADS / A_TPR, B_RPP = Cfg::THREADS / B_TPR;
+    constexpr int A_PASSES = BK / A_RPP, B_PASSES = BK / B_RPP;
+    float* As = lds;
+    float* Bs = lds + 2 * BK * BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN, l31 = lane & 31, half = lane >> 5;
+    const int a_col = (tid % A_TPR) * 4, a_row0 = tid / A_TPR, b_col = (tid % B_TPR) * 4, b_row0 = tid / B_TPR;
+    lb.column4(j_blk + b_col);
+    f32x16 acc[Cfg::TM][Cfg::TN];
+    for (int i = 0; i < Cfg::TM; ++i) for (int j = 0; j < Cfg::TN; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    float4 ra[A_PASSES], rb[B_PASSES];
+    const int T = (K + BK - 1) / BK;
+    auto gload = [&](int t) {
+        const int k0 = t * BK;
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) ra[p] = la.load4(k0 + a_row0 + p * A_RPP, m_blk + a_col);
+#pragma unroll
+        for (int p = 0; p < B_PASSES; ++p) rb[p] = lb.load4(k0 + b_row0 + p * B_RPP);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<float4*>(&As[(buf * BK + a_row0 + p * A_RPP) * BM + a_col]) = ra[p];
+#pragma unroll
+        for (int p = 0; p < B_PASSES; ++p) *reinterpret_cast<float4*>(&Bs[(buf * BK + b_row0 + p * B_RPP) * BN + b_col]) = rb[p];
+    };
+    float a0[Cfg::TM], b0[Cfg::TN];
+    for (int i = 0; i < Cfg::TM; ++i) a0[i] = 1.0f + lane; 
+    for (int j = 0; j < Cfg::TN; ++j) b0[j] = 2.0f + lane;
+    auto compute = [&](int buf) {
+        const float* Ab = As + buf * BK * BM + wm * Cfg::TM * 32 + l31;
+        const float* Bb = Bs + buf * BK * BN + wn * Cfg::TN * 32 + l31;
+        float a[2][Cfg::TM], b[2][Cfg::TN];
+        auto fread = [&](int kk, int s) {
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i) a[s][i] = (FLAGS & 4) ? a0[i] : Ab[(kk + half) * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) b[s][j] = (FLAGS & 4) ? b0[j] : Bb[(kk + half) * BN + j * 32];
+        };
+        fread(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int s = (kk >> 1) & 1;
+            if (kk + 2 < BK) fread(kk + 2, s ^ 1);
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+        }
+    };
+    gload(0); lstore(0); __syncthreads();
+    for (int t = 0; t + 1 < T; ++t) {
+        const int buf = t & 1;
+        if (!(FLAGS & 1)) gload(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(FLAGS & 1)) lstore(buf ^ 1);
+        if (!(FLAGS & 2)) __syncthreads();
+    }
+    compute((T - 1) & 1);
+    for (int i = 0; i < Cfg::TM; ++i) for (int j = 0; j < Cfg::TN; ++j)
+        epi.tile(m_blk + (wm * Cfg::TM + i) * 32 + 4 * half, j_blk + (wn * Cfg::TN + j) * 32 + l31, acc[i][j]);
+}
+template <class Cfg, int FLAGS> __global__ __launch_bounds__(Cfg::THREADS) void ablate_kernel(const float* At, const float* X, float* C, int M, int K, int N) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    OldA la{At, K, M}; OldB lb{X, K, N, 0}; EpiStore epi{C, M, N};
+    ablate_block<Cfg, FLAGS>(lds, la, lb, epi, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
+}
+template <class Cfg, int FLAGS> void run_ablate(int M, int K, int N, const char* name) {
+    float *dAt, *dX, *dC; CK(hipMalloc(&dAt, (size_t)K * M * 4)); CK(hipMalloc(&dX, (size_t)K * N * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4));
+    CK(hipMemset(dAt, 0, (size_t)K * M * 4)); CK(hipMemset(dX, 0, (size_t)K * N * 4));
+    if (getenv("EXP_RANDOM")) {       // same kernels on uniform [-1,1) operands: the fp32-MFMA rate is DATA dependent (power / clocks)
+        std::vector<float> h((size_t)K * (M > N ? M : N));
+        unsigned s = 7; for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 32768.0f - 1.0f; }
+        CK(hipMemcpy(dAt, h.data(), (size_t)K * M * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dX, h.data(), (size_t)K * N * 4, hipMemcpyHostToDevice));
+    }
+    CK(hipFuncSetAttribute((const void*)ablate_kernel<Cfg, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_FLOATS * 4));
+    dim3 g((N + Cfg::BN - 1) / Cfg::BN, (M + Cfg::BM - 1) / Cfg::BM);
+    float ms = time_ms([&]() { ablate_kernel<Cfg, FLAGS><<<g, Cfg::THREADS, Cfg::LDS_FLOATS * 4>>>(dAt, dX, dC, M, K, N); }, 10);
+    CK(hipGetLastError());
+    printf("%-10s M=%d K=%d N=%d  ablation flags %d: %8.3f ms %6.1f TF\n", name, M, K, N, FLAGS, ms, 2.0 * M * K * N / ms / 1e9);
+    CK(hipFree(dAt)); CK(hipFree(dX)); CK(hipFree(dC));
+}
+
 template <class Cfg> __global__ __launch_bounds__(Cfg::THREADS) void old_kernel(const float* At, const float* X, float* C, int M, int K, int N) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     OldA la{At, K, M}; OldB lb{X, K, N, 0}; EpiStore epi{C, M, N};
@@ -51,12 +148,6 @@ template <class Cfg> __global__ __launch_bounds__(Cfg::THREADS) void new_kernel(
     mfma_gemm_block_kc<Cfg>(lds, la, lb, epi, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
 }
 
-template <class F> float time_ms(F f, int iters) {
-    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    f(); f(); CK(hipDeviceSynchronize());
-    CK(hipEventRecord(e0)); for (int i = 0; i < iters; ++i) f(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms / iters;
-}
 double check(const std::vector<float>& A, const std::vector<float>& X, const float* dC, int M, int K, int N) {
     std::vector<float> C((size_t)M * N); CK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
     double worst = 0; unsigned s = 12345;
@@ -95,7 +186,18 @@ template <class OC, class NC> void run(int M, int K, int N, const char* name) {
 }
 }  // namespace
 
+template <class Cfg> void ablations(int M, int K, int N, const char* name) {
+    run_ablate<Cfg, 0>(M, K, N, name); run_ablate<Cfg, 1>(M, K, N, name); run_ablate<Cfg, 3>(M, K, N, name); run_ablate<Cfg, 7>(M, K, N, name);
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'a') {       // exp_gemm_kc a : ablation study of the vec engine
+        ablations<TileCfg<2, 2, 2, 2, 32>>(4096, 4096, 4096, "128x128");
+        ablations<TileCfg<2, 2, 1, 2, 32>>(64, 576, 163840, "64x128");
+        ablations<TileCfg<2, 2, 1, 1, 32>>(128, 1152, 40960, "64x64");
+        ablations<TileCfg<2, 2, 1, 1, 32>>(256, 2304, 10240, "64x64");
+        return 0;
+    }
     std::vector<int> dims;
     for (int i = 1; i < argc; ++i) dims.push_back(atoi(argv[i]));
     if (dims.empty()) dims = {4096, 4096, 4096, 64, 576, 163840, 128, 1152, 40960, 256, 2304, 10240, 512, 4608, 2560, 128, 128, 655360};
