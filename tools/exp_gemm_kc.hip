@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 
 #include "mfma_tile_kc.h"
 
@@ -186,6 +187,110 @@ template <class OC, class NC> void run(int M, int K, int N, const char* name) {
 }
 }  // namespace
 
+// Persistent variant: gridDim.x workgroups walk the tiles (m fastest) with stride gridDim.x; the first K-step of the NEXT
+// tile is requested before the epilogue of the current one, so the per-tile prologue latency hides under the stores.
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::THREADS) void persist_kernel(const float* At, const float* X, float* C, int M, int K, int N) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
+    constexpr int A_TPR = BM / 4, B_TPR = BN / 4;
+    constexpr int A_RPP = Cfg::THREADS / A_TPR, B_RPP = Cfg::THREADS / B_TPR;
+    constexpr int A_PASSES = BK / A_RPP, B_PASSES = BK / B_RPP;
+    float* As = lds;
+    float* Bs = lds + 2 * BK * BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN, l31 = lane & 31, half = lane >> 5;
+    const int a_col = (tid % A_TPR) * 4, a_row0 = tid / A_TPR, b_col = (tid % B_TPR) * 4, b_row0 = tid / B_TPR;
+    const int gm = (M + BM - 1) / BM, gn = (N + BN - 1) / BN, ntiles = gm * gn;
+    const int T = (K + BK - 1) / BK;
+    OldA la{At, K, M};
+    EpiStore epi{C, M, N};
+    float4 ra[A_PASSES], rb[B_PASSES];
+    int m_blk = 0, j_blk = 0;
+    auto gload = [&](int mb, int jb, int t) {
+        const int k0 = t * BK;
+        const int n = min(jb + b_col, N - 4);
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) ra[p] = la.load4(k0 + a_row0 + p * A_RPP, mb + a_col);
+#pragma unroll
+        for (int p = 0; p < B_PASSES; ++p) rb[p] = *reinterpret_cast<const float4*>(X + (size_t)min(k0 + b_row0 + p * B_RPP, K - 1) * N + n);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<float4*>(&As[(buf * BK + a_row0 + p * A_RPP) * BM + a_col]) = ra[p];
+#pragma unroll
+        for (int p = 0; p < B_PASSES; ++p) *reinterpret_cast<float4*>(&Bs[(buf * BK + b_row0 + p * B_RPP) * BN + b_col]) = rb[p];
+    };
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    m_blk = (tile % gm) * BM; j_blk = (tile / gm) * BN;
+    gload(m_blk, j_blk, 0);
+    for (; tile < ntiles; tile += gridDim.x) {
+        f32x16 acc[Cfg::TM][Cfg::TN];
+        for (int i = 0; i < Cfg::TM; ++i) for (int j = 0; j < Cfg::TN; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        auto compute = [&](int buf) {
+            const float* Ab = As + buf * BK * BM + wm * Cfg::TM * 32 + l31;
+            const float* Bb = Bs + buf * BK * BN + wn * Cfg::TN * 32 + l31;
+            float a[2][Cfg::TM], b[2][Cfg::TN];
+            auto fread = [&](int kk, int s) {
+#pragma unroll
+                for (int i = 0; i < Cfg::TM; ++i) a[s][i] = Ab[(kk + half) * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j) b[s][j] = Bb[(kk + half) * BN + j * 32];
+            };
+            fread(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const int s = (kk >> 1) & 1;
+                if (kk + 2 < BK) fread(kk + 2, s ^ 1);
+#pragma unroll
+                for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+            }
+        };
+        lstore(0);
+        __syncthreads();
+        for (int t = 0; t + 1 < T; ++t) {
+            gload(m_blk, j_blk, t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(t & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            lstore((t & 1) ^ 1);
+            __syncthreads();
+        }
+        const int cm = m_blk, cj = j_blk;
+        const int next = tile + gridDim.x;
+        if (next < ntiles) { m_blk = (next % gm) * BM; j_blk = (next / gm) * BN; gload(m_blk, j_blk, 0); }   // in flight under the last MFMAs + epilogue
+        __builtin_amdgcn_sched_barrier(0);
+        compute((T - 1) & 1);
+        for (int i = 0; i < Cfg::TM; ++i) for (int j = 0; j < Cfg::TN; ++j)
+            epi.tile(cm + (wm * Cfg::TM + i) * 32 + 4 * half, cj + (wn * Cfg::TN + j) * 32 + l31, acc[i][j]);
+        __syncthreads();      // everyone is done reading the panels before the next tile's first store
+    }
+}
+template <class Cfg> void run_persist(int M, int K, int N, const char* name, int blocks_per_cu) {
+    std::vector<float> A((size_t)M * K), At((size_t)K * M), X((size_t)K * N);
+    unsigned s = 1; auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    for (int m = 0; m < M; ++m) for (int k = 0; k < K; ++k) { A[(size_t)m * K + k] = rnd(); At[(size_t)k * M + m] = A[(size_t)m * K + k]; }
+    for (auto& v : X) v = rnd();
+    float *dAt, *dX, *dC; CK(hipMalloc(&dAt, At.size() * 4)); CK(hipMalloc(&dX, X.size() * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4));
+    CK(hipMemcpy(dAt, At.data(), At.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice));
+    CK(hipFuncSetAttribute((const void*)persist_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_FLOATS * 4));
+    CK(hipFuncSetAttribute((const void*)old_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_FLOATS * 4));
+    const int ntiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((N + Cfg::BN - 1) / Cfg::BN);
+    const int grid = std::min(ntiles, 256 * blocks_per_cu);
+    CK(hipMemset(dC, 0, (size_t)M * N * 4));
+    float ms = time_ms([&]() { persist_kernel<Cfg><<<grid, Cfg::THREADS, Cfg::LDS_FLOATS * 4>>>(dAt, dX, dC, M, K, N); }, 10);
+    CK(hipGetLastError());
+    const double err = check(A, X, dC, M, K, N);
+    dim3 g((N + Cfg::BN - 1) / Cfg::BN, (M + Cfg::BM - 1) / Cfg::BM);
+    float ms0 = time_ms([&]() { old_kernel<Cfg><<<g, Cfg::THREADS, Cfg::LDS_FLOATS * 4>>>(dAt, dX, dC, M, K, N); }, 10);
+    printf("%-8s M=%d K=%d N=%d  tile-per-workgroup %7.3f ms %6.1f TF | persistent x%d %7.3f ms %6.1f TF  err %.2e\n", name, M, K, N, ms0,
+           2.0 * M * K * N / ms0 / 1e9, blocks_per_cu, ms, 2.0 * M * K * N / ms / 1e9, err);
+    CK(hipFree(dAt)); CK(hipFree(dX)); CK(hipFree(dC));
+}
+
 template <class Cfg> void ablations(int M, int K, int N, const char* name) {
     run_ablate<Cfg, 0>(M, K, N, name); run_ablate<Cfg, 1>(M, K, N, name); run_ablate<Cfg, 3>(M, K, N, name); run_ablate<Cfg, 7>(M, K, N, name);
 }
@@ -196,6 +301,16 @@ int main(int argc, char** argv) {
         ablations<TileCfg<2, 2, 1, 2, 32>>(64, 576, 163840, "64x128");
         ablations<TileCfg<2, 2, 1, 1, 32>>(128, 1152, 40960, "64x64");
         ablations<TileCfg<2, 2, 1, 1, 32>>(256, 2304, 10240, "64x64");
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'p') {       // exp_gemm_kc p : persistent tile loop vs one tile per workgroup
+        for (int bpc : {2, 3, 4}) {
+            run_persist<TileCfg<2, 2, 1, 2, 32>>(64, 576, 163840, "64x128", bpc);
+            run_persist<TileCfg<2, 2, 1, 1, 32>>(128, 1152, 40960, "64x64", bpc);
+            run_persist<TileCfg<2, 2, 1, 1, 32>>(256, 2304, 10240, "64x64", bpc);
+            run_persist<TileCfg<2, 2, 1, 1, 32>>(512, 4608, 2560, "64x64", bpc);
+        }
+        run_persist<TileCfg<2, 2, 2, 2, 32>>(4096, 4096, 4096, "128x128", 2);
         return 0;
     }
     std::vector<int> dims;
