@@ -66,16 +66,36 @@ __device__ __forceinline__ void ablate_block(float* lds, LoaderA& la, LoaderB& l
     for (int i = 0; i < Cfg::TM; ++i) for (int j = 0; j < Cfg::TN; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     float4 ra[A_PASSES], rb[B_PASSES];
     const int T = (K + BK - 1) / BK;
-    auto gload = [&](int t) {
+    // FLAGS bit3: the A panel goes global -> LDS directly (global_load_lds_dwordx4: 1 KB per wave-instruction, LDS image =
+    // wave-uniform base + lane*16, which IS the [k][m] panel when rows are unpadded); no VGPR staging, no ds_write for A.
+    constexpr int ROWS_PER_GLDS = 256 / BM;                    // panel rows covered by one 1 KB instruction
+    constexpr int GLDS_PER_WAVE = BK / ROWS_PER_GLDS / (Cfg::THREADS / 64);
+    auto glds_A = [&](int t, int buf) {
         const int k0 = t * BK;
 #pragma unroll
-        for (int p = 0; p < A_PASSES; ++p) ra[p] = la.load4(k0 + a_row0 + p * A_RPP, m_blk + a_col);
+        for (int i = 0; i < GLDS_PER_WAVE; ++i) {
+            const int r0 = (wave * GLDS_PER_WAVE + i) * ROWS_PER_GLDS;
+            const int row = r0 + lane / (BM / 4), col = (lane % (BM / 4)) * 4;
+            const float* src = la.At + (size_t)min(k0 + row, K - 1) * la.M + min(m_blk + col, la.M - 4);
+            float* dst = &As[(buf * BK + r0) * BM];            // wave-uniform
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    auto gload = [&](int t) {
+        const int k0 = t * BK;
+        if (!(FLAGS & 8)) {
+#pragma unroll
+            for (int p = 0; p < A_PASSES; ++p) ra[p] = la.load4(k0 + a_row0 + p * A_RPP, m_blk + a_col);
+        }
 #pragma unroll
         for (int p = 0; p < B_PASSES; ++p) rb[p] = lb.load4(k0 + b_row0 + p * B_RPP);
     };
     auto lstore = [&](int buf) {
+        if (!(FLAGS & 8)) {
 #pragma unroll
-        for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<float4*>(&As[(buf * BK + a_row0 + p * A_RPP) * BM + a_col]) = ra[p];
+            for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<float4*>(&As[(buf * BK + a_row0 + p * A_RPP) * BM + a_col]) = ra[p];
+        }
 #pragma unroll
         for (int p = 0; p < B_PASSES; ++p) *reinterpret_cast<float4*>(&Bs[(buf * BK + b_row0 + p * B_RPP) * BN + b_col]) = rb[p];
     };
@@ -103,10 +123,11 @@ __device__ __forceinline__ void ablate_block(float* lds, LoaderA& la, LoaderB& l
                 for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
         }
     };
+    if (FLAGS & 8) glds_A(0, 0);
     gload(0); lstore(0); __syncthreads();
     for (int t = 0; t + 1 < T; ++t) {
         const int buf = t & 1;
-        if (!(FLAGS & 1)) gload(t + 1);
+        if (!(FLAGS & 1)) { if (FLAGS & 8) glds_A(t + 1, buf ^ 1); gload(t + 1); }
         __builtin_amdgcn_sched_barrier(0);
         compute(buf);
         __builtin_amdgcn_sched_barrier(0);
@@ -134,7 +155,10 @@ template <class Cfg, int FLAGS> void run_ablate(int M, int K, int N, const char*
     dim3 g((N + Cfg::BN - 1) / Cfg::BN, (M + Cfg::BM - 1) / Cfg::BM);
     float ms = time_ms([&]() { ablate_kernel<Cfg, FLAGS><<<g, Cfg::THREADS, Cfg::LDS_FLOATS * 4>>>(dAt, dX, dC, M, K, N); }, 10);
     CK(hipGetLastError());
-    printf("%-10s M=%d K=%d N=%d  ablation flags %d: %8.3f ms %6.1f TF\n", name, M, K, N, FLAGS, ms, 2.0 * M * K * N / ms / 1e9);
+    std::vector<float> hc(4096);
+    CK(hipMemcpy(hc.data(), dC + (size_t)(M / 2) * N, sizeof(float) * std::min<size_t>(4096, N), hipMemcpyDeviceToHost));
+    double checksum = 0; for (float v : hc) checksum += v;
+    printf("%-10s M=%d K=%d N=%d  ablation flags %d: %8.3f ms %6.1f TF  (row checksum %.6g)\n", name, M, K, N, FLAGS, ms, 2.0 * M * K * N / ms / 1e9, checksum);
     CK(hipFree(dAt)); CK(hipFree(dX)); CK(hipFree(dC));
 }
 
@@ -292,7 +316,7 @@ template <class Cfg> void run_persist(int M, int K, int N, const char* name, int
 }
 
 template <class Cfg> void ablations(int M, int K, int N, const char* name) {
-    run_ablate<Cfg, 0>(M, K, N, name); run_ablate<Cfg, 1>(M, K, N, name); run_ablate<Cfg, 3>(M, K, N, name); run_ablate<Cfg, 7>(M, K, N, name);
+    run_ablate<Cfg, 0>(M, K, N, name); run_ablate<Cfg, 8>(M, K, N, name); run_ablate<Cfg, 1>(M, K, N, name); run_ablate<Cfg, 3>(M, K, N, name); run_ablate<Cfg, 7>(M, K, N, name);
 }
 
 int main(int argc, char** argv) {
