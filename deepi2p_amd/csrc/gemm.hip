@@ -74,15 +74,22 @@ struct LoaderConcat4 {
         const int nc = min(n, N - 4);
 #pragma unroll
         for (int i = 0; i < DI2P_MAX_SRC; ++i) {
-            const int j = i < s.n_src ? i : 0;
-            base[i] = s.ptr[j] + (long long)b * s.batch_stride[j] + (DENSE ? nc : 0);
-            rs[i] = s.row_stride[j];
+            // static indices + selects (a runtime index into the kernel-argument arrays would push them to scratch);
+            // absent sources alias source 0 and are never selected
+            const bool on = i < s.n_src;
+            const float* pp = on ? s.ptr[i] : s.ptr[0];
+            const long long bs = on ? s.batch_stride[i] : s.batch_stride[0];
+            base[i] = pp + (long long)b * bs + (DENSE ? nc : 0);
+            rs[i] = on ? s.row_stride[i] : s.row_stride[0];
             if (!DENSE) {
+                const int mode = on ? s.mode[i] : s.mode[0];
+                const int* gi = on ? s.gidx[i] : s.gidx[0];
+                const int grp = on ? s.group[i] : s.group[0];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     int o = nc + q;
-                    if (s.mode[j] == DI2P_SRC_GATHER) o = s.gidx[j][(long long)b * N + nc + q];
-                    else if (s.mode[j] == DI2P_SRC_GROUP) o = (nc + q) / s.group[j];
+                    if (mode == DI2P_SRC_GATHER) o = gi[(long long)b * N + nc + q];
+                    else if (mode == DI2P_SRC_GROUP) o = (nc + q) / grp;
                     off[DENSE ? 0 : i][q] = o;
                 }
             }
@@ -474,8 +481,8 @@ extern "C" int di2p_point_head(const di2p_src_t* srcs, int n_src, const float* W
     DI2P_CHECK_ARG(e.g_k >= 0 && e.g_k <= 4, "g_k must be <= 4");
     HeadTail tl{W1t, scale1, shift1, W2t, scale2, shift2, relu1, relu2, P};
     const size_t lds = (HeadCfg::LDS_FLOATS + HEAD_M * HEAD_BN) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)point_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    // > 64 KB of dynamic LDS needs the opt-in (per device; the call is cheap, so it is simply made every time)
+    (void)hipFuncSetAttribute((const void*)point_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(point_head_kernel, dim3(di2p_cdiv(N, HEAD_BN), B), dim3(HeadCfg::THREADS), lds, (hipStream_t)stream, s, W0t, K0, e, tl, out, N);
     DI2P_RETURN_LAUNCH();
 }
