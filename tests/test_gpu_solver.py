@@ -208,3 +208,25 @@ def test_small_and_ragged_frames(dev, N):
     np.testing.assert_allclose(cg[ok], co[ok], rtol=1e-6, atol=1e-12)
     assert abs(cg.min() - co.min()) <= 1e-6 * max(co.min(), 1e-9) + 1e-12
     assert ok.mean() >= 0.5
+
+
+@pytest.mark.parametrize("seed,is_2d,N,HW,flip", [(31, True, 8192, (384, 640), 0.1), (32, False, 3000, (64, 128), 0.02),
+                                                  (33, True, 20480, (160, 512), 0.05)])
+def test_solver_matches_oracle_other_cameras(dev, seed, is_2d, N, HW, flip):
+    """Same parity statement as above on other image sizes / intrinsics / label noise (the cluster shortcut and the
+    cost-only line-search sweeps must not move any iterate: >= 90 % of hypotheses agree, best cost to 1e-6)."""
+    from deepi2p_amd import registration
+    h, w = HW
+    rng = np.random.default_rng(seed)
+    f = synthetic.make_frame(rng, N=N, H=h, W=w, flip=flip, with_image=False)
+    pts, lab = f["pc"].astype(np.float64), f["labels"]
+    _, y0, pcf, labf = flm.get_initial_guess(pts, lab)
+    R = 12
+    ys, Ts = flm.draw_restarts(rng, R, y0, 10 * math.pi / 180, 10)
+    Po, co, it_o, term_o, par_o = flm.solve_restarts(pcf, labf, f["K"], ys, Ts, h, w, LB, UB, 500, is_2d, nthreads=8)
+    Pg, cg, best, par_g, it_g = registration.solvePGivenK_batched(pcf, labf, f["K"], ys, Ts, h, w, LB, UB, 500, is_2d, return_all=True)
+    ok = _agreement(par_o, par_g, is_2d)
+    assert ok.mean() >= 0.9, "only %.0f%% of hypotheses agree (iters oracle %s, hip %s)" % (100 * ok.mean(), it_o, it_g)
+    np.testing.assert_allclose(cg[ok], co[ok], rtol=1e-6)
+    assert abs(cg.min() - co.min()) <= 1e-6 * co.min()
+    np.testing.assert_array_equal(it_g[ok], it_o[ok])            # same number of LM iterations where the iterates agree
