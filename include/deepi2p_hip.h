@@ -177,13 +177,14 @@ int di2p_channel_max(const float* x, float* y, int B, int C, int N, void* stream
  * di2p_initial_guess: registration_lsq.py:196-220 on device.  points f64[F,3,N], labels
  *   i32[F,N] -> yaw0 f64[F]; labels_out i32[F,N] = label, or -1 for points removed by the front
  *   filter (the solver skips labels not in {0,1}, registration.cpp:87-125); has_inside i32[F].
- * di2p_solve_batched: F frames x R hypotheses.  One wavefront per hypothesis; Cauchy-robust
+ * di2p_solve_batched: F frames x R hypotheses.  One 4-wavefront workgroup per hypothesis; Cauchy-robust
  *   Levenberg-Marquardt with box bounds on t (see DESIGN.md for the exact algorithm statement).
  *   points f64[F,3,N], labels i32[F,N], K f64[F,3,3] (fx,fy,cx,cy used), init_y f64[F,R],
  *   init_T f64[F,R,3], lb/ub f64[3] HOST arrays, is_2d: 4 params [ry,tx,ty,tz] else 6
  *   [angle-axis, t].  Outputs: params f64[F,R,np], cost f64[F,R], iters i32[F,R], sweeps i32[F,R] (optional).
  *   If yaw0 != NULL it is added to init_y per frame (restart noise drawn before yaw0 is known).
- *   workspace: di2p_solve_workspace_bytes(F, N) bytes of scratch (packed point records).
+ *   workspace: di2p_solve_workspace_bytes(F, N) bytes of scratch (sorted point records, cluster boxes, sort keys);
+ *   N <= 130944 is not required: any N >= 0 works.
  * di2p_select_best: argmin cost over R per frame (ties -> lowest r; frames with has_inside==0 get
  *   identity and cost 1e4, registration_lsq.py:329-332) -> best i32[F], P f64[F,4,4], cost f64[F].
  * di2p_solver_residuals: Problem::Evaluate of registration.cpp:150-155 at given params:
