@@ -183,8 +183,7 @@ int di2p_channel_max(const float* x, float* y, int B, int C, int N, void* stream
  *   init_T f64[F,R,3], lb/ub f64[3] HOST arrays, is_2d: 4 params [ry,tx,ty,tz] else 6
  *   [angle-axis, t].  Outputs: params f64[F,R,np], cost f64[F,R], iters i32[F,R], sweeps i32[F,R] (optional).
  *   If yaw0 != NULL it is added to init_y per frame (restart noise drawn before yaw0 is known).
- *   workspace: di2p_solve_workspace_bytes(F, N) bytes of scratch (sorted point records, cluster boxes, sort keys);
- *   N <= 130944 is not required: any N >= 0 works.
+ *   workspace: di2p_solve_workspace_bytes(F, N) bytes of scratch (sorted point records, cluster boxes, sort keys).
  * di2p_select_best: argmin cost over R per frame (ties -> lowest r; frames with has_inside==0 get
  *   identity and cost 1e4, registration_lsq.py:329-332) -> best i32[F], P f64[F,4,4], cost f64[F].
  * di2p_solver_residuals: Problem::Evaluate of registration.cpp:150-155 at given params:
