@@ -4,27 +4,38 @@
 One "step" = one batch of BASELINE.json configs[1]: 32 synthetic KITTI-shaped frames (20480 points,
 160x512 image), coarse frustum classification (image + point + fusion network, fp32) -> argmax labels ->
 initial guess -> 60-restart Gauss-Newton/LM pose solve (fp64) -> argmin.  Inputs are resident in HBM when
-the timed region starts; weights are random-init closed-form (no checkpoints available).  N>1: one process
-per GPU (torchrun), frames sharded across ranks, no data-path collective (weak scaling).
+the timed region starts (`value`); the same loop with the per-step H2D copy of the batch from pinned host
+memory inside the step is timed right after it and reported as `value_with_h2d` (SURVEY.md 8d's definition).
+Weights are random-init closed-form (no checkpoints available).
 
-    python bench.py --gpus 1 --steps 10 --warmup 2
+Multi-GPU: one process per GPU over RCCL.  `python bench.py --gpus N` launches the N ranks itself
+(torch.distributed.run, 127.0.0.1 rendezvous) unless it already runs under a launcher (WORLD_SIZE set).
+  --mode frames (default)  frames sharded across ranks, no data-path collective, weak scaling (configs[1]/[3])
+  --mode hyp               BASELINE configs[4]: every rank classifies the same frames, the R=256 pose hypotheses
+                           of each frame are sharded across ranks, ONE all_gather of (cost, params) + identical
+                           argmin on every rank; strong scaling, collective latency reported
+
+    python bench.py --gpus 1 --steps 12 --warmup 3
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32-input MFMA peak (same guide)
-FP64_VALU_PEAK_TFLOPS = 78.6
+FP64_VALU_PEAK_TFLOPS = 78.6   # fp64 vector peak (256 CUs x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
+SOLVER_FLOP_PER_POINT = 150.0  # SURVEY.md 8(d): flop per point per hypothesis-iteration (rotate, project, residual, J, J^T J)
+# reference-algorithmic MACs per frame of the pointwise (Conv1d / 1x1 Conv2d) layers, SURVEY.md 8(d) [probed]:
+# knnlayer, per_point_pn (coarse), node_b_pn, second_pointnet, node_a_pn, first_pointnet, attention PNs, final_pointnet
+POINTWISE_REF_GMAC_COARSE = 0.975 + 2.270 + 0.336 + 0.168 + 0.065 + 0.047 + 0.057 + 0.025
 
 
 def conv_flops_per_frame(H, W):
@@ -68,19 +79,45 @@ def conv_bytes_per_frame(H, W):
     return 4 * elems
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--points", type=int, default=20480)
-    ap.add_argument("--restarts", type=int, default=60)
+    ap.add_argument("--mode", choices=("frames", "hyp"), default="frames")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (frames: 32, hyp: 16 in total)")
+    ap.add_argument("--points", type=int, default=None)
+    ap.add_argument("--restarts", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams = batches in flight (1 = fully serial)")
-    ap.add_argument("--priority", type=int, default=0, help="1: classifier on a high-priority stream, solves on --streams low-priority streams")
-    args = ap.parse_args()
+    ap.add_argument("--no-h2d-pass", action="store_true", help="skip the second timed loop with the H2D copy inside the step")
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="only launch the ranks, rendezvous, run one barrier + all_reduce and print n_gpus (no GPU work)")
+    return ap.parse_args(argv)
 
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def maybe_spawn(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def init_dist(args):
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,39 +125,90 @@ def main():
     backend = os.environ.get("DI2P_BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
     if os.environ.get("DI2P_BENCH_ONE_DEVICE"):
         local_rank = 0
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl" and not args.launch_selftest:
+            torch.cuda.set_device(local_rank)
         dist.init_process_group(backend)
+    return rank, local_rank, world, backend, dist
+
+
+def launch_selftest(args):
+    """Rendezvous + one barrier + one all_reduce on the configured backend; no HIP kernels (CPU-testable with gloo)."""
+    import torch
+    rank, local_rank, world, backend, dist = init_dist(args)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        if backend == "nccl":
+            t = t.cuda()
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_selftest": True, "n_gpus": world, "requested_gpus": args.gpus, "backend": backend if world > 1 else None,
+                          "max_rank_plus_one": float(t.item())}))
+
+
+def broadcast_weights(detector, dist, backend):
+    """Weights broadcast ONCE as one flat fp32 buffer over RCCL/xGMI (stands in for nn.DataParallel's per-step replicate,
+    models/multimodal_classifier.py:37-38): 26 M parameters = 105 MB, one collective instead of 361."""
+    import torch
+    tensors = [t for t in detector.state_dict().values() if t.dtype == torch.float32]
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    if backend == "nccl":
+        dist.broadcast(flat, 0)
+    else:                       # gloo (test mode): via host memory
+        h = flat.cpu()
+        dist.broadcast(h, 0)
+        flat.copy_(h)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n
+    detector._invalidate()
+    return flat.numel() * 4
+
+
+def main():
+    args = parse_args()
+    maybe_spawn(args)
+    if args.launch_selftest:
+        launch_selftest(args)
+        return
+    import numpy as np
+    import torch
+    rank, local_rank, world, backend, dist = init_dist(args)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     from deepi2p_amd import _lib, ops, synthetic
+    from deepi2p_amd.distributed import shard_range, solve_hypotheses_sharded
     from deepi2p_amd.networks import MMClassiferCoarse
     from deepi2p_amd.registration import RegistrationPipeline
 
-    B, N, H, W, R = args.batch, args.points, 160, 512, args.restarts
+    hyp = args.mode == "hyp"
+    if hyp:      # BASELINE configs[4]: Oxford-shaped 40960 pts / 384x640, 256 hypotheses per frame, same frames on every rank
+        B, N, H, W, R = args.batch or 16, args.points or 40960, 384, 640, args.restarts or 256
+    else:        # BASELINE configs[1]
+        B, N, H, W, R = args.batch or 32, args.points or 20480, 160, 512, args.restarts or 60
     opt = synthetic.OptLike(N, H, W, False)
     opt.device = dev
     sd = synthetic.synthetic_state_dict(opt)
     mm = MMClassiferCoarse(opt)
     mm.detector.load_state_dict(sd)
-    if world > 1:  # weights broadcast once over RCCL/xGMI (stands in for nn.DataParallel's per-step replicate)
-        for t in mm.detector.state_dict().values():
-            if backend == "nccl":
-                dist.broadcast(t, 0)
-            else:                       # gloo (test mode): via host memory
-                h = t.cpu()
-                dist.broadcast(h, 0)
-                t.copy_(h)
-        mm.detector._invalidate()
-    batch = synthetic.make_batch(1000 + rank, B, N=N, H=H, W=W)
-    t = {k: torch.from_numpy(batch[k]) for k in ("pc", "intensity", "sn", "node_a", "node_b", "img")}
-    mm.set_input(t["pc"], t["intensity"], t["sn"], t["node_a"], t["node_b"], torch.zeros(B, 3, 4), t["img"],
+    bcast_bytes = broadcast_weights(mm.detector, dist, backend) if world > 1 else 0
+    mm.detector.prepack()                 # derive the kernel operands now, on this stream, before other streams use them
+    batch = synthetic.make_batch(1000 + (0 if hyp else rank), B, N=N, H=H, W=W)
+    names = ("pc", "intensity", "sn", "node_a", "node_b", "img")
+    host = {k: torch.from_numpy(batch[k]).pin_memory() for k in names}
+    mm.set_input(host["pc"], host["intensity"], host["sn"], host["node_a"], host["node_b"], torch.zeros(B, 3, 4), host["img"],
                  torch.from_numpy(batch["K"]).float())
     K64 = torch.from_numpy(batch["K"]).to(dev)
-    pipe = RegistrationPipeline(H, W, R=R, seed=rank)
+    pipe = RegistrationPipeline(H, W, R=R, seed=0 if hyp else rank)
     restarts = pipe.draw(B, dev)
     torch.cuda.synchronize()
 
@@ -131,43 +219,48 @@ def main():
     solver_labels = torch.from_numpy(batch["labels"]).to(dev)
 
     # S HIP streams, round-robin: whole steps (classifier -> pose solve of one batch) are independent, so several are
-    # kept in flight.  The solver's tail (a few long-running hypotheses keep a handful of CUs busy while the rest of
-    # the chip idles) is filled by the next batches' kernels.  Each step is still one full batch through the whole
-    # path on its own stream, and all K steps complete inside the timed region.
+    # kept in flight; every step is still one full batch through the whole path on its own stream, and all K steps
+    # complete inside the timed region.  Each stream owns a slot of input buffers for the H2D-inclusive pass.
     n_streams = max(1, args.streams)
-    overlap = n_streams > 1
-    prio = args.priority and overlap
-    if prio:
-        # one HIGH-priority stream for the classifier (short MFMA kernels) running ahead, S low-priority streams for
-        # the pose solves: network workgroups are dispatched first whenever a CU frees up, the long fp64 solver
-        # workgroups fill the rest and overlap each other's tails
-        s_net = torch.cuda.Stream(priority=-1)
-        streams = [torch.cuda.Stream(priority=0) for _ in range(n_streams)]
-    else:
-        streams = [torch.cuda.Stream() for _ in range(n_streams)]
+    streams = [torch.cuda.Stream() for _ in range(n_streams)]
+    resident = {k: getattr(mm, k) for k in names}
+    slots = [resident] + [{k: torch.empty_like(v) for k, v in resident.items()} for _ in range(n_streams - 1)]
     step_no = [0]
+    coll_events = []
 
-    def step():
-        if not overlap:
-            pred = mm.inference_labels()                   # image + point + fusion network, argmax (i32 [B,N])
-            o = pipe(mm.pc, solver_labels, K64, restarts)
-            o["pred"] = pred
-            return o
-        st = streams[step_no[0] % n_streams]
+    def solve(pc, labels):
+        if not hyp:
+            return pipe(pc, labels, K64, restarts)
+        # hypothesis fan-out: rank r solves restarts [lo, hi) of every frame; one all_gather + identical argmin
+        pts64 = torch.empty((B, 3, N), dtype=torch.float64, device=dev)
+        ops.call("di2p_f32_to_f64", ops.ptr(pc), ops.ptr(pts64), B * 3 * N, ops.stream())
+        yaw0, lab_front, has_inside = ops.initial_guess(pts64, labels)
+        iters_box = {}
+
+        def solve_fn(iy, iT):
+            p, c, it = ops.solve_batched(pc, lab_front, K64, iy, iT, H, W, pipe.lb, pipe.ub, pipe.max_iter, True, yaw0=yaw0)
+            iters_box["iters"] = it
+            return p, c
+        ev = None
+        if coll_events is not None and world > 1 and backend == "nccl":
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        best, bp, bc, allc = solve_hypotheses_sharded(solve_fn, restarts[0], restarts[1], gather_events=ev)
+        if ev is not None:
+            coll_events.append(ev)
+        _, P, _ = ops.select_best(bp.view(B, 1, -1).contiguous(), bc.view(B, 1).contiguous(), True, has_inside=has_inside)
+        return dict(P=P, cost=bc, best=best.int(), yaw0=yaw0, costs=allc, iters=iters_box["iters"], labels_front=lab_front)
+
+    def step(with_h2d=False, serial=False):
+        i = step_no[0] % n_streams
         step_no[0] += 1
-        if prio:
-            with torch.cuda.stream(s_net):
-                pred = mm.inference_labels()
-                ev = torch.cuda.Event()
-                ev.record()
-            with torch.cuda.stream(st):
-                st.wait_event(ev)                          # the pose solve of a batch follows its classification
-                o = pipe(mm.pc, solver_labels, K64, restarts)
-                pred.record_stream(st)
-        else:
-            with torch.cuda.stream(st):
-                pred = mm.inference_labels()
-                o = pipe(mm.pc, solver_labels, K64, restarts)   # same stream: the pose solve of a batch follows its classification
+        st = torch.cuda.current_stream() if serial else streams[i]
+        slot = slots[i] if with_h2d else resident
+        with torch.cuda.stream(st):
+            if with_h2d:        # a1: MMClassifer.set_input's copies (50 MB per 32-frame batch) from pinned host memory
+                for k in names:
+                    slot[k].copy_(host[k], non_blocking=True)
+            pred = ops.argmax_channels(mm.detector(slot["pc"], slot["intensity"], slot["sn"], slot["node_a"], slot["node_b"], slot["img"]))
+            o = solve(slot["pc"], solver_labels)    # same stream: the pose solve of a batch follows its classification
         o["pred"] = pred
         return o
 
@@ -176,100 +269,140 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    sync_all()
-    dt = time.perf_counter() - t0
+    def timed_loop(with_h2d):
+        for _ in range(args.warmup):
+            step(with_h2d)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            o = step(with_h2d)
+        sync_all()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, o
+
+    dt, out = timed_loop(False)
+    dt_h2d = None
+    if not args.no_h2d_pass:
+        dt_h2d, _ = timed_loop(True)
+
     # per-kernel-family durations: HIP events on the launch stream, in a SERIAL pass right after the timed region
     # (with several batches in flight, events inside the timed region would measure contention, not the kernels)
-    timed_names = ("di2p_conv2d", "di2p_conv2d_ws", "di2p_pointwise_gemm", "di2p_point_head", "di2p_index_max_values", "di2p_solve_batched_f32", "di2p_knn_nodes")
+    timed_names = ("di2p_conv2d", "di2p_conv2d_ws", "di2p_pointwise_gemm", "di2p_point_head", "di2p_index_max_values",
+                   "di2p_solve_batched_f32", "di2p_knn_nodes")
     prof_steps = 2
-    overlap_saved, overlap = overlap, False
     _lib.TIMED = {n: [] for n in timed_names}
+    _lib.WORK = {}
+    coll_events = None
     for _ in range(prof_steps):
-        out = step()
+        out = step(serial=True)
     torch.cuda.synchronize()
-    timed = _lib.TIMED
-    _lib.TIMED = None
-    overlap = overlap_saved
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    frames = B * args.steps * world
+    timed, work = _lib.TIMED, _lib.WORK
+    _lib.TIMED = _lib.WORK = None
+    frames_per_step = B if hyp else B * world
+    frames = frames_per_step * args.steps
     ms_per_step = dt / args.steps * 1e3
 
-    # ---- per-kernel-family time from the events recorded inside the timed region
     fam_ms = {n: sum(e0.elapsed_time(e1) for e0, e1, _ in v) / prof_steps for n, v in timed.items()}
     launches = {n: len(v) // prof_steps for n, v in timed.items()}
-    # the convolution family = the plain entry point + the split-K one (stage-4 layers: K-slice kernel + ordered reduce pass)
+    # the convolution family = the plain entry point + the split-K one (K-slice kernel + ordered reduce pass)
     fam_ms["di2p_conv2d"] += fam_ms.pop("di2p_conv2d_ws")
     launches["di2p_conv2d"] += launches.pop("di2p_conv2d_ws")
     # pointwise family = the single-layer launches + the fused three-layer point head
     fam_ms["di2p_pointwise_gemm"] += fam_ms.pop("di2p_point_head")
     launches["di2p_pointwise_gemm"] += launches.pop("di2p_point_head")
+    pw_exec_flops = 2.0 * (work.get("di2p_pointwise_gemm", 0) + work.get("di2p_point_head", 0)) / prof_steps
     conv_flops = conv_flops_per_frame(H, W) * B
     idx_bytes = B * (4 * 32 * N + 4 * N + 2 * 4 * 32 * 128) + B * (4 * 64 * N + 4 * N + 2 * 4 * 64 * 128)
     iters = out["iters"].float()
-    n_active = float((out["labels_front"] >= 0).float().sum(dim=1).mean())
-    solver_sweeps = float(iters.sum()) * 1.0
+    sweeps = out.get("sweeps")
+    n_front = float((out["labels_front"] >= 0).float().sum(dim=1).mean())
+    n_hyp = int(out["iters"].numel())
+    sol_ms = fam_ms["di2p_solve_batched_f32"]
+    sol_flop_iters = SOLVER_FLOP_PER_POINT * n_front * float(iters.sum())
     roofs = {
-        "conv2d_kernel(implicit-GEMM fp32 MFMA)": {
+        "solve_kernel": {
+            "bound": "valu-fp64 (the frame's records are L2-resident: neither hbm nor mfma applies)",
+            "achieved": sol_flop_iters / (sol_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "ms_per_step": sol_ms, "launches_per_step": launches["di2p_solve_batched_f32"], "hypotheses": n_hyp,
+            "mean_iters": float(iters.mean()), "max_iters": float(iters.max()), "points_per_sweep": n_front,
+            "algorithmic_flop_per_launch": sol_flop_iters,
+            "note": "SURVEY 8(d) unit: 150 flop x front-filtered points x LM iterations of all hypotheses of the launch"},
+        "conv2d_kernel": {
             "bound": "mfma", "achieved": conv_flops / (fam_ms["di2p_conv2d"] * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "ms_per_step": fam_ms["di2p_conv2d"], "launches_per_step": launches["di2p_conv2d"]},
+            "unit": "TFLOP/s", "ms_per_step": fam_ms["di2p_conv2d"], "launches_per_step": launches["di2p_conv2d"],
+            "algorithmic_flop_per_launch": conv_flops / 36.0,
+            "compulsory_bytes_per_launch": (conv_bytes_per_frame(H, W) * B + 85.1e6) / 36.0},
+        "pointwise_gemm_kernel(+point_head)": {
+            "bound": "mfma", "achieved": 2e9 * POINTWISE_REF_GMAC_COARSE * B / (fam_ms["di2p_pointwise_gemm"] * 1e-3) / 1e12,
+            "achieved_executed": pw_exec_flops / (fam_ms["di2p_pointwise_gemm"] * 1e-3) / 1e12,
+            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "ms_per_step": fam_ms["di2p_pointwise_gemm"],
+            "launches_per_step": launches["di2p_pointwise_gemm"],
+            "note": "achieved = reference-algorithmic 2*MAC (SURVEY 8d) / time; achieved_executed = flops actually issued "
+                    "(per-node premultiply of per_point_pn.layers.0 and split concatenations execute fewer)"},
         "index_max_kernel": {
             "bound": "hbm", "achieved": idx_bytes / (fam_ms["di2p_index_max_values"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "ms_per_step": fam_ms["di2p_index_max_values"], "launches_per_step": launches["di2p_index_max_values"]},
-        "solve_kernel(fp64 VALU, not hbm/mfma bound)": {
-            "ms_per_step": fam_ms["di2p_solve_batched_f32"], "mean_iters": float(iters.mean()), "max_iters": float(iters.max()),
-            "points_per_sweep": n_active, "sweeps_lower_bound": solver_sweeps},
-        "pointwise_gemm_kernel(+point_head)": {"ms_per_step": fam_ms["di2p_pointwise_gemm"], "launches_per_step": launches["di2p_pointwise_gemm"]},
+            "unit": "GB/s", "ms_per_step": fam_ms["di2p_index_max_values"], "launches_per_step": launches["di2p_index_max_values"],
+            "note": "in-pipeline durations (both calls: C=32 and C=64), not a cache-warm microbenchmark"},
         "knn_nodes_kernel": {"ms_per_step": fam_ms["di2p_knn_nodes"], "launches_per_step": launches["di2p_knn_nodes"]},
     }
+    if sweeps is not None:
+        roofs["solve_kernel"]["mean_sweeps"] = float(sweeps.float().mean())
+        roofs["solve_kernel"]["max_sweeps"] = float(sweeps.max())
     for r in roofs.values():
         if "achieved" in r:
             r["frac"] = r["achieved"] / r["peak"]
-    dom = roofs["conv2d_kernel(implicit-GEMM fp32 MFMA)"]
-    # HBM traffic per convolution call from the committed PMC passes of the same kernels on the same shapes (separate
-    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH x2 for the 16-byte/lane loads as MI355X_MICROARCH.md prescribes;
-    # profiles/r01_pmc_traffic.json); None if the file is absent
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-            pmc = json.load(fh)
-        if B == 32 and (H, W) == (160, 512):
-            traffic = pmc["conv2d_resnet34_B32_160x512"]["hbm_bytes_per_call_corrected"]
-            roofs["index_max_kernel"]["traffic_C64"] = pmc["index_max_C64_B32_N20480_K128"]["hbm_bytes_corrected"]
-            roofs["index_max_kernel"]["algorithmic_C64"] = pmc["index_max_C64_B32_N20480_K128"]["algorithmic_bytes"]
-    except (OSError, KeyError, ValueError):
-        pass
-    roofline = {"kernel": "conv2d_kernel", "bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"],
-                "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
-                "algorithmic_flop_per_launch": conv_flops / 36.0,
-                "compulsory_bytes_per_launch": (conv_bytes_per_frame(H, W) * B + 85.1e6) / 36.0,
-                "note": "algorithmic 2*MAC of the 36 ResNet-34 convolution calls of one step / their summed HIP-event time "
-                        "(events on the launch stream, serial pass of %d steps directly after the timed region)" % prof_steps}
+    # HBM traffic per launch from the committed PMC passes of the same kernels on the same shapes (separate rocprofv3
+    # --pmc FETCH_SIZE / WRITE_SIZE runs, corrected as MI355X_MICROARCH.md prescribes); None if absent
+    pmc = {}
+    for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", fn)) as fh:
+                pmc = json.load(fh)
+            break
+        except (OSError, ValueError):
+            pass
+    if B == 32 and (H, W) == (160, 512):
+        roofs["conv2d_kernel"]["traffic"] = pmc.get("conv2d_resnet34_B32_160x512", {}).get("hbm_bytes_per_call_corrected")
+        roofs["index_max_kernel"]["traffic_C64"] = pmc.get("index_max_C64_B32_N20480_K128", {}).get("hbm_bytes_corrected")
+        roofs["solve_kernel"]["traffic"] = pmc.get("solve_kernel_F32_R60_N20480", {}).get("hbm_bytes_corrected")
+    # the line's roofline object = the TIME-DOMINANT kernel family of the step
+    dom_name = max((n for n in roofs if "frac" in roofs[n]), key=lambda n: roofs[n]["ms_per_step"])
+    dom = roofs[dom_name]
+    roofline = {"kernel": dom_name, "bound": "mfma" if dom["bound"] == "mfma" else ("hbm" if dom["bound"] == "hbm" else "valu-fp64"),
+                "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
+                "traffic": dom.get("traffic"), "ms_per_step": dom["ms_per_step"],
+                "algorithmic_per_launch": dom.get("algorithmic_flop_per_launch"),
+                "note": "time-dominant kernel family of the step; HIP events on the launch stream, serial pass of %d steps "
+                        "directly after the timed region; every family's roofline is under `kernels`" % prof_steps}
 
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not hyp and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(batch, sd, opt, H, W, R)
 
+    collective = None
+    if hyp and world > 1:
+        collective = measure_collective(dist, backend, dev, B, R, world)
     if rank == 0:
         line = {
             "metric": "frames/sec (img+pc infer + 60-restart GN pose) KITTI 20k-pt, 1/2/4/8 GPU",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if hyp else "weak", "vs_baseline": None,
             "dtype": "f32 network (fp32-input MFMA) + f64 solver",
             "data": "synthetic frames, random-init closed-form weights; solver labels = GT frustum labels with 5% flips (SURVEY 8d)",
-            "config": {"workload": "BASELINE configs[1]: KITTI 20480-pt / 160x512, batch %d per GPU, coarse classification "
-                                   "+ %d-restart 2D GN/LM solver, max_iter 500" % (B, R),
-                       "frames_per_gpu_per_step": B, "points": N, "image": [H, W], "restarts": R, "parallelism": "dp%d" % world,
-                       "streams": n_streams, "priority_streams": bool(prio)},
-            "roofline": roofline, "kernels": roofs, "cpu_baseline": cpu_baseline,
+            "config": {"workload": ("BASELINE configs[4]: Oxford-shaped %d-pt / %dx%d, %d frames per step on every rank, coarse classification "
+                                    "+ %d 2D GN/LM hypotheses per frame sharded over the ranks, all_gather + argmin" % (N, H, W, B, R)) if hyp else
+                                   ("BASELINE configs[1]: KITTI 20480-pt / 160x512, batch %d per GPU, coarse classification "
+                                    "+ %d-restart 2D GN/LM solver, max_iter 500" % (B, R)),
+                       "mode": args.mode, "frames_per_gpu_per_step": B, "points": N, "image": [H, W], "restarts": R,
+                       "parallelism": ("hyp%d" if hyp else "dp%d") % world, "streams": n_streams,
+                       "weights_broadcast_bytes": bcast_bytes},
+            "value_with_h2d": (frames / dt_h2d) if dt_h2d else None,
+            "ms_per_step_with_h2d": (dt_h2d / args.steps * 1e3) if dt_h2d else None,
+            "roofline": roofline, "kernels": roofs, "cpu_baseline": cpu_baseline, "collective": collective,
             "pose_check": pose_check(out, batch),
         }
         print(json.dumps(line))
@@ -277,9 +410,29 @@ def main():
         dist.destroy_process_group()
 
 
+def measure_collective(dist, backend, dev, F, R, world):
+    """Latency of the config-5 all_gather alone (payload R/world x 5 doubles per frame per rank), 50 calls."""
+    import torch
+    width = -(-R // world)
+    buf = torch.zeros((F, width, 5), dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    outs = [torch.empty_like(buf) for _ in range(world)]
+    for _ in range(5):
+        dist.all_gather(outs, buf)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    n = 50
+    for _ in range(n):
+        dist.all_gather(outs, buf)
+    torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / n * 1e6
+    return {"op": "all_gather", "backend": "rccl" if backend == "nccl" else backend, "bytes_per_rank": buf.numel() * 8,
+            "latency_us": us}
+
+
 def pose_check(out, batch):
     """Sanity (not parity): the network has random weights, so its labels are meaningless; report only that the
-    solver ran to completion on them."""
+    solver ran to completion on the synthetic labels."""
     from deepi2p_amd.registration import get_P_diff
     P = out["P"].cpu().numpy()
     errs = [get_P_diff(P[i], batch["P_gt"][i]) for i in range(P.shape[0])]
@@ -291,6 +444,8 @@ def pose_check(out, batch):
 
 def run_cpu_baseline(batch, sd, opt, H, W, R):
     """The oracle ("port" of the reference's CPU path) timed on this box's host cores on a bounded sample."""
+    import numpy as np
+    import torch
     from oracle import frustum_lm as flm
     from oracle import network_torch as nt
     cores = os.cpu_count() or 1
@@ -301,9 +456,8 @@ def run_cpu_baseline(batch, sd, opt, H, W, R):
     with torch.no_grad():
         nt.keypoint_detector(sd, opt, *[t[k][:1] for k in ("pc", "intensity", "sn", "node_a", "node_b", "img")])   # warm-up
         t0 = time.perf_counter()
-        logits = nt.keypoint_detector(sd, opt, t["pc"], t["intensity"], t["sn"], t["node_a"], t["node_b"], t["img"])
+        nt.keypoint_detector(sd, opt, t["pc"], t["intensity"], t["sn"], t["node_a"], t["node_b"], t["img"])
         t_net = (time.perf_counter() - t0) / nb
-    labels = logits.argmax(1).numpy().astype(np.int32)
     pc = batch["pc"][0].astype(np.float64)
     lab = batch["labels"][0]          # same synthetic solver labels as the GPU leg
     _, y0, pcf, labf = flm.get_initial_guess(pc, lab)

@@ -27,7 +27,7 @@ class SrcT(ctypes.Structure):
 class EpilogueT(ctypes.Structure):
     _fields_ = [("scale", c_void_p), ("shift", c_void_p), ("batch_bias", c_void_p), ("relu", c_int),
                 ("group_max", c_int), ("g_table", c_void_p * 2), ("g_idx", c_void_p * 2), ("g_w", c_void_p * 2),
-                ("g_nodes", c_int * 2), ("g_k", c_int), ("transpose_out", c_int)]
+                ("g_nodes", c_int * 2), ("g_k", c_int * 2), ("transpose_out", c_int)]
 
 
 SRC_DENSE, SRC_GATHER, SRC_GROUP = 0, 1, 2
@@ -46,6 +46,7 @@ _SIGS = {
     "di2p_pointwise_gemm": [ctypes.POINTER(SrcT), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                             ctypes.POINTER(EpilogueT), c_void_p],
     "di2p_batch_gemv": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
+    "di2p_batch_gemv2": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "di2p_attention_pool": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "di2p_point_head": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                         c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
@@ -70,7 +71,7 @@ _SIGS = {
     "di2p_pack_pc_label": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
 }
 EXPORTS = sorted(list(_SIGS) + ["di2p_last_error", "di2p_version", "di2p_solve_workspace_bytes", "di2p_solver_set_profile_buffer", "di2p_pnp_workspace_bytes",
-                 "di2p_conv2d_workspace_bytes"])
+                 "di2p_conv2d_workspace_bytes", "di2p_set_option", "di2p_get_option"])
 
 
 def load():
@@ -94,6 +95,10 @@ def load():
         lib.di2p_pnp_workspace_bytes.argtypes = [c_int, c_int, c_int]
         lib.di2p_conv2d_workspace_bytes.restype = c_ll
         lib.di2p_conv2d_workspace_bytes.argtypes = [c_int] * 10
+        lib.di2p_set_option.restype = c_int
+        lib.di2p_set_option.argtypes = [ctypes.c_char_p, c_ll]
+        lib.di2p_get_option.restype = c_ll
+        lib.di2p_get_option.argtypes = [ctypes.c_char_p]
         lib.di2p_solver_set_profile_buffer.restype = None
         lib.di2p_solver_set_profile_buffer.argtypes = [c_void_p]
         _lib = lib
@@ -104,6 +109,8 @@ def load():
 # recorded on the stream the kernel is launched on (torch's current stream).
 TIMED = None
 TIMED_TAG = None
+# Optional executed-work counters (bench.py): {kernel name: multiply-accumulates issued}, filled by ops.* when not None.
+WORK = None
 
 
 def call(name, *args):
@@ -118,6 +125,30 @@ def call(name, *args):
         TIMED[name].append((e0, e1, TIMED_TAG))
     if rc != 0:
         raise DeepI2PHipError("%s failed (%d): %s" % (name, rc, lib.di2p_last_error().decode()))
+
+
+def set_option(name, value):
+    """Set a cached library knob ("conv_nosplit", "pw_novec", "solver_nocull", ...; include/deepi2p_hip.h)."""
+    if load().di2p_set_option(name.encode(), int(value)) != 0:
+        raise DeepI2PHipError("unknown option " + name)
+
+
+def get_option(name):
+    return int(load().di2p_get_option(name.encode()))
+
+
+class option:
+    """``with _lib.option("solver_nocull", 1): ...`` -- temporarily override a knob (tests compare code paths)."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = get_option(self.name)
+        set_option(self.name, self.value)
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
 
 
 def ptr(t):

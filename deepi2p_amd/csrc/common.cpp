@@ -1,6 +1,10 @@
 #include "common.h"
 
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
 
 static thread_local char g_err[512] = "ok";
 
@@ -12,4 +16,43 @@ void di2p_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* di2p_last_error(void) { return g_err; }
-extern "C" int di2p_version(void) { return 1; }
+extern "C" int di2p_version(void) { return 2; }
+
+namespace {
+struct OptDef { const char* name; const char* env; long long def; };
+const OptDef kOpts[DI2P_OPT_COUNT] = {
+    {"conv_nosplit", "DI2P_CONV_NOSPLIT", 0},        {"conv_split_blocks", "DI2P_CONV_SPLIT_BLOCKS", 32},
+    {"conv_novec", "DI2P_CONV_NOVEC", 0},            {"conv_cfg", "DI2P_CONV_CFG", -1},
+    {"pw_novec", "DI2P_PW_NOVEC", 0},                {"solver_cfg", "DI2P_SOLVER_CFG", 43},
+    {"solver_nocull", "DI2P_SOLVER_NOCULL", 0},      {"solver_tier_sweeps", "DI2P_SOLVER_TIER_SWEEPS", 0},
+};
+long long g_opt[DI2P_OPT_COUNT];
+std::once_flag g_opt_once;
+void opts_init() {
+    for (int i = 0; i < DI2P_OPT_COUNT; ++i) {
+        const char* e = getenv(kOpts[i].env);
+        g_opt[i] = e ? atoll(e) : kOpts[i].def;
+    }
+}
+}  // namespace
+
+long long di2p_opt(int id) {
+    std::call_once(g_opt_once, opts_init);
+    return g_opt[id];
+}
+
+// name = lower-case knob name ("conv_nosplit", "solver_nocull", ...).  Returns 0, or -1 for an unknown name.
+extern "C" int di2p_set_option(const char* name, long long value) {
+    std::call_once(g_opt_once, opts_init);
+    for (int i = 0; i < DI2P_OPT_COUNT; ++i)
+        if (name && strcmp(name, kOpts[i].name) == 0) { g_opt[i] = value; return 0; }
+    di2p_set_error("di2p_set_option: unknown option");
+    return -1;
+}
+
+extern "C" long long di2p_get_option(const char* name) {
+    std::call_once(g_opt_once, opts_init);
+    for (int i = 0; i < DI2P_OPT_COUNT; ++i)
+        if (name && strcmp(name, kOpts[i].name) == 0) return g_opt[i];
+    return -1;
+}

@@ -29,3 +29,18 @@ void di2p_set_error(const char* fmt, ...);
     } while (0)
 
 static inline int di2p_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Tuning / test knobs.  Read ONCE from the environment (DI2P_<NAME>) when the library is first used and cached: no
+// getenv() on the launch path.  Tests and tools flip them at run time through di2p_set_option().
+enum Di2pOption {
+    DI2P_OPT_CONV_NOSPLIT = 0,      // 1: never split K in the convolutions
+    DI2P_OPT_CONV_SPLIT_BLOCKS,     // per-frame workgroup count below which K is split (default 32)
+    DI2P_OPT_CONV_NOVEC,            // 1: scalar stager for the convolutions
+    DI2P_OPT_CONV_CFG,              // >= 0: force a convolution tile configuration (experiments)
+    DI2P_OPT_PW_NOVEC,              // 1: scalar stager for the pointwise GEMMs
+    DI2P_OPT_SOLVER_CFG,            // <waves per hypothesis><min waves per SIMD>, default 43
+    DI2P_OPT_SOLVER_NOCULL,         // 1: classify every cluster per point (bit-identical by construction)
+    DI2P_OPT_SOLVER_TIER_SWEEPS,    // sweeps after which a hypothesis is handed to the wide (16-wave) tail kernel; 0 = never
+    DI2P_OPT_COUNT
+};
+long long di2p_opt(int id);

@@ -457,15 +457,13 @@ namespace {
 // (ResNet stage 4 at 160x512: 320 workgroups for 256 CUs) latency-bound; K-slices along the filter taps give the chip
 // >= 3 workgroups per CU.  Partials are combined in slice order by a separate pass (deterministic, no atomics).
 int conv_splits(int Cin, int Cout, int KH, int KW, int OW, long long opix, int tap_major) {
-    const char* e = getenv("DI2P_CONV_NOSPLIT");     // read per call: tests compare both paths
-    if ((e && atoi(e)) || !tap_major || Cin % 32 != 0 || OW % 4 != 0 || Cout % 4 != 0 || Cout < 128) return 1;
+    if (di2p_opt(DI2P_OPT_CONV_NOSPLIT) || !tap_major || Cin % 32 != 0 || OW % 4 != 0 || Cout % 4 != 0 || Cout < 128) return 1;
     // The decision depends on the PER-FRAME shape only, never on the batch size: a frame's result must not change with
     // the batch it is computed in (data-parallel shards reproduce the unsharded run bit for bit).  The limit is the
     // number of 64x64 workgroups one frame contributes below which a 32-frame batch leaves CUs idle.
     const long long per_frame = di2p_cdiv(opix, 64) * (long long)di2p_cdiv(Cout, 64);
     const int T = Cin * KH * KW / 32;
-    const char* t = getenv("DI2P_CONV_SPLIT_BLOCKS");   // tuning knob (per-frame workgroups), default 32
-    const long long limit = t ? atoll(t) : 32;
+    const long long limit = di2p_opt(DI2P_OPT_CONV_SPLIT_BLOCKS);   // tuning knob (per-frame workgroups), default 32
     if (per_frame >= limit || T < 24) return 1;
     return per_frame * 2 >= limit * 3 / 2 ? 2 : 3;
 }
@@ -487,8 +485,7 @@ int conv2d_impl(const float* x, const float* Wt, const float* scale, const float
 #define DI2P_CONV(CFG) launch_conv<CFG>(x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, Ntot, relu, tap_major, st)
     // tile choice: K-step 32 when a tap holds whole 32-channel groups (halves barriers, doubles the prefetch
     // distance); the largest tile that still yields >= ~2 workgroups per CU.  DI2P_CONV_CFG overrides (experiments).
-    static int force = -2;
-    if (force == -2) { const char* e = getenv("DI2P_CONV_CFG"); force = e ? atoi(e) : -1; }
+    const int force = (int)di2p_opt(DI2P_OPT_CONV_CFG);
     const bool k32 = tap_major && Cin % 32 == 0;
     const long long nb64x128 = (long long)di2p_cdiv(Ntot, 128) * di2p_cdiv(Cout, 64);
     const long long nb128x128 = (long long)di2p_cdiv(Ntot, 128) * di2p_cdiv(Cout, 128);
@@ -502,7 +499,7 @@ int conv2d_impl(const float* x, const float* Wt, const float* scale, const float
     const bool use32 = k32 && (force < 0 || force >= 10);
     // the 7x7/2 stem (weights in their own order): row-decoding vector stager
     if (!tap_major && KH == 7 && KW == 7 && stride == 2 && OW % 4 == 0 && Cout % 4 == 0 && ((uintptr_t)Wt & 15) == 0 &&
-        getenv("DI2P_CONV_NOVEC") == nullptr) {
+        !di2p_opt(DI2P_OPT_CONV_NOVEC)) {
         using CfgS = TileCfg<2, 2, 1, 2, 32>;      // 64 x 128, B_PASSES = 4 (one mask per pass)
         const dim3 grid(di2p_cdiv(Ntot, CfgS::BN), di2p_cdiv(Cout, CfgS::BM));
         hipLaunchKernelGGL(conv2d_stem_kernel<CfgS>, grid, dim3(CfgS::THREADS), CfgS::LDS_FLOATS * sizeof(float), st, x, Wt, scale, shift,
@@ -510,8 +507,7 @@ int conv2d_impl(const float* x, const float* Wt, const float* scale, const float
         DI2P_RETURN_LAUNCH();
     }
     // vector stager: tap-major weights, 32-channel taps, whole 4-pixel groups per output row, 16-byte aligned weights
-    static int novec = -1;
-    if (novec < 0) { const char* e = getenv("DI2P_CONV_NOVEC"); novec = e ? atoi(e) : 0; }
+    const bool novec = di2p_opt(DI2P_OPT_CONV_NOVEC) != 0;
     const bool vec = !novec && use32 && OW % 4 == 0 && Cout % 4 == 0 && ((uintptr_t)Wt & 15) == 0 &&
                      ((stride == 1 && pad <= 1 && KW <= 2 * pad + 1 && W >= 4) || stride == 2);
     if (vec && force < 0) choice = Cout <= 64 ? 1 : 0;   // measured: 64x64 tiles (more, smaller workgroups) win for Cout >= 128

@@ -122,7 +122,7 @@ struct EpiDev {
     const int* g_idx[2];
     const float* g_w[2];
     int g_nodes[2];
-    int g_k;
+    int g_k[2];      // neighbours per column of each gathered table (<= DI2P_MAX_GK)
     int relu;
     int group_max;
     int transpose_out;
@@ -153,18 +153,21 @@ struct EpiPointwise {
         for (int t = 0; t < 2; ++t)
             if (e.g_table[t]) {
                 const float* gt = e.g_table[t] + (long long)b * e.g_nodes[t] * M;
+                const int gk = e.g_k[t];
+                auto add_neighbour = [&](int j) {
+                    const int gi = e.g_idx[t][((long long)b * N + nc) * gk + j];
+                    const float gw = e.g_w[t] ? e.g_w[t][((long long)b * N + nc) * gk + j] : 1.0f;
+                    const float* gp = gt + (long long)gi * M;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 q = *reinterpret_cast<const float4*>(gp + min(mrow0 + 8 * g, M - 4));
+                        v[4 * g + 0] += gw * q.x; v[4 * g + 1] += gw * q.y; v[4 * g + 2] += gw * q.z; v[4 * g + 3] += gw * q.w;
+                    }
+                };
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (j < e.g_k) {
-                        const int gi = e.g_idx[t][((long long)b * N + nc) * e.g_k + j];
-                        const float gw = e.g_w[t] ? e.g_w[t][((long long)b * N + nc) * e.g_k + j] : 1.0f;
-                        const float* gp = gt + (long long)gi * M;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const float4 q = *reinterpret_cast<const float4*>(gp + min(mrow0 + 8 * g, M - 4));
-                            v[4 * g + 0] += gw * q.x; v[4 * g + 1] += gw * q.y; v[4 * g + 2] += gw * q.z; v[4 * g + 3] += gw * q.w;
-                        }
-                    }
+                    if (j < gk) add_neighbour(j);
+                for (int j = 4; j < gk; ++j) add_neighbour(j);       // k > 4 (the reference accepts any k): same order, rolled
             }
         if (e.scale) {
 #pragma unroll
@@ -190,7 +193,10 @@ struct EpiPointwise {
                 const int m = mrow0 + (r & 3) + 8 * (r >> 2);
                 const bool ok = col_ok && m < M;
                 float mx = ok ? v[r] : -__builtin_inff();
-                for (int o = 1; o < e.group_max; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                for (int o = 1; o < e.group_max; o <<= 1) {      // torch.max semantics: NaN propagates
+                    const float ot = __shfl_xor(mx, o);
+                    mx = (mx != mx || ot != ot) ? __builtin_nanf("") : fmaxf(mx, ot);
+                }
                 if (ok && (n % e.group_max) == 0) Y[((long long)b * M + m) * (N / e.group_max) + n / e.group_max] = mx;
             }
         } else if (e.transpose_out) {        // Y[b][n][m]: one float4 per row group (M % 4 == 0)
@@ -336,17 +342,12 @@ __global__ __launch_bounds__(Cfg::THREADS) void attention_pool_kernel(const floa
     mfma_gemm_block<Cfg>(lds, la, lb, ep, HW, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
 }
 
-// out[b][m] = sum_k Wt[k0+k][m] * v[b][k].  One block = 64 output channels x 4 k-slices (one wave per slice: its v[b][k]
-// reads are wave-uniform, its Wt reads 256 contiguous bytes); 4 independent accumulators per lane keep the dependent
-// FMA chain at Kv/16, the slices are combined through LDS.
-__global__ __launch_bounds__(256) void batch_gemv_kernel(const float* __restrict__ Wt, int M, int k0, const float* __restrict__ v,
-                                                         int Kv, float* __restrict__ out) {
-    __shared__ float part[4][64];
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int m = blockIdx.x * 64 + lane;
-    const int mc = min(m, M - 1);
-    const float* vb = v + (long long)b * Kv;
+// out[b][m] = sum_k Wt[k0+k][m] * v[b][k]  (+ the same for a second (k1, v1) pair).  One block = 64 output channels x 4
+// k-slices (one wave per slice: its v[b][k] reads are wave-uniform, its Wt reads 256 contiguous bytes); 4 independent
+// accumulators per lane keep the dependent FMA chain at Kv/16, the slices are combined through LDS.  With two pairs the
+// result is (gemv0) + (gemv1), each summed exactly as a single-pair call would: node_b_pn's two broadcast inputs
+// (networks_united.py:152-155) become ONE launch instead of two launches and an elementwise add.
+__device__ __forceinline__ float gemv_slice(const float* __restrict__ Wt, int M, int mc, int k0, const float* __restrict__ vb, int Kv, int slice) {
     const int per = (Kv + 3) / 4;
     const int kb = slice * per, ke = min(kb + per, Kv);
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
@@ -358,9 +359,25 @@ __global__ __launch_bounds__(256) void batch_gemv_kernel(const float* __restrict
         a3 += Wt[(long long)(k0 + k + 3) * M + mc] * vb[k + 3];
     }
     for (; k < ke; ++k) a0 += Wt[(long long)(k0 + k) * M + mc] * vb[k];
-    part[slice][lane] = (a0 + a1) + (a2 + a3);
+    return (a0 + a1) + (a2 + a3);
+}
+
+__global__ __launch_bounds__(256) void batch_gemv_kernel(const float* __restrict__ Wt, int M, int k0, const float* __restrict__ v,
+                                                         int Kv, int k1, const float* __restrict__ v1, int Kv1,
+                                                         float* __restrict__ out) {
+    __shared__ float part[2][4][64];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int m = blockIdx.x * 64 + lane;
+    const int mc = min(m, M - 1);
+    part[0][slice][lane] = gemv_slice(Wt, M, mc, k0, v + (long long)b * Kv, Kv, slice);
+    if (v1) part[1][slice][lane] = gemv_slice(Wt, M, mc, k1, v1 + (long long)b * Kv1, Kv1, slice);
     __syncthreads();
-    if (slice == 0 && m < M) out[(long long)b * M + m] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (slice == 0 && m < M) {
+        float r = (part[0][0][lane] + part[0][1][lane]) + (part[0][2][lane] + part[0][3][lane]);
+        if (v1) r += (part[1][0][lane] + part[1][1][lane]) + (part[1][2][lane] + part[1][3][lane]);
+        out[(long long)b * M + m] = r;
+    }
 }
 
 template <class Cfg>
@@ -415,9 +432,12 @@ extern "C" int di2p_pointwise_gemm(const di2p_src_t* srcs, int n_src, const floa
         e.scale = epi->scale; e.shift = epi->shift; e.batch_bias = epi->batch_bias; e.relu = epi->relu;
         e.group_max = epi->group_max > 1 ? epi->group_max : 1;
         for (int t = 0; t < 2; ++t) { e.g_table[t] = epi->g_table[t]; e.g_idx[t] = epi->g_idx[t]; e.g_w[t] = epi->g_w[t]; e.g_nodes[t] = epi->g_nodes[t]; }
-        e.g_k = epi->g_k;
         e.transpose_out = epi->transpose_out;
-        DI2P_CHECK_ARG(e.g_k >= 0 && e.g_k <= 4, "g_k must be <= 4");
+        for (int t = 0; t < 2; ++t) {
+            e.g_k[t] = e.g_table[t] ? epi->g_k[t] : 0;
+            DI2P_CHECK_ARG(e.g_k[t] >= 0 && e.g_k[t] <= DI2P_MAX_GK, "g_k must be in [0, DI2P_MAX_GK]");
+            DI2P_CHECK_ARG(!e.g_table[t] || (e.g_idx[t] && e.g_k[t] >= 1 && e.g_nodes[t] >= 1), "gathered table without index / k / nodes");
+        }
         DI2P_CHECK_ARG(!(e.g_table[0] || e.g_table[1]) || (M % 4 == 0 && M >= 4), "gathered tables need M % 4 == 0");
         DI2P_CHECK_ARG(!e.transpose_out || (M % 4 == 0 && e.group_max == 1), "transpose_out needs M % 4 == 0 and no group_max");
     }
@@ -430,7 +450,7 @@ extern "C" int di2p_pointwise_gemm(const di2p_src_t* srcs, int n_src, const floa
     // addressable get one 16-byte load per row, gathered / group sources four dword loads
     // (narrow layers, M <= 64, are HBM/latency-bound and measured 25-35 % faster on the scalar stager below, whose K-step 16
     //  skips the rows k >= K instead of re-reading clamped ones)
-    const bool vec = M > 64 && N % 4 == 0 && N >= 4 && M % 4 == 0 && aligned16(Wt) && getenv("DI2P_PW_NOVEC") == nullptr;
+    const bool vec = M > 64 && N % 4 == 0 && N >= 4 && M % 4 == 0 && aligned16(Wt) && !di2p_opt(DI2P_OPT_PW_NOVEC);
     bool dense = true;
     for (int i = 0; i < n_src; ++i)
         dense = dense && srcs[i].mode == DI2P_SRC_DENSE && srcs[i].row_stride % 4 == 0 && srcs[i].batch_stride % 4 == 0 && aligned16(srcs[i].ptr);
@@ -477,8 +497,11 @@ extern "C" int di2p_point_head(const di2p_src_t* srcs, int n_src, const float* W
     e.group_max = 1;
     e.scale = epi0->scale; e.shift = epi0->shift; e.batch_bias = epi0->batch_bias; e.relu = epi0->relu;
     for (int t = 0; t < 2; ++t) { e.g_table[t] = epi0->g_table[t]; e.g_idx[t] = epi0->g_idx[t]; e.g_w[t] = epi0->g_w[t]; e.g_nodes[t] = epi0->g_nodes[t]; }
-    e.g_k = epi0->g_k;
-    DI2P_CHECK_ARG(e.g_k >= 0 && e.g_k <= 4, "g_k must be <= 4");
+    for (int t = 0; t < 2; ++t) {
+        e.g_k[t] = e.g_table[t] ? epi0->g_k[t] : 0;
+        DI2P_CHECK_ARG(e.g_k[t] >= 0 && e.g_k[t] <= DI2P_MAX_GK, "g_k must be in [0, DI2P_MAX_GK]");
+        DI2P_CHECK_ARG(!e.g_table[t] || (e.g_idx[t] && e.g_k[t] >= 1 && e.g_nodes[t] >= 1), "gathered table without index / k / nodes");
+    }
     HeadTail tl{W1t, scale1, shift1, W2t, scale2, shift2, relu1, relu2, P};
     const size_t lds = (HeadCfg::LDS_FLOATS + HEAD_M * HEAD_BN) * sizeof(float);
     // > 64 KB of dynamic LDS needs the opt-in (per device; the call is cheap, so it is simply made every time)
@@ -490,7 +513,16 @@ extern "C" int di2p_point_head(const di2p_src_t* srcs, int n_src, const float* W
 extern "C" int di2p_batch_gemv(const float* Wt, int M, int k0, const float* v, int Kv, float* out, int B, void* stream) {
     DI2P_CHECK_ARG(Wt && v && out && M >= 1 && Kv >= 1 && k0 >= 0 && B >= 0, "bad args");
     if (B == 0) return 0;
-    hipLaunchKernelGGL(batch_gemv_kernel, dim3(di2p_cdiv(M, 64), B), dim3(256), 0, (hipStream_t)stream, Wt, M, k0, v, Kv, out);
+    hipLaunchKernelGGL(batch_gemv_kernel, dim3(di2p_cdiv(M, 64), B), dim3(256), 0, (hipStream_t)stream, Wt, M, k0, v, Kv, 0,
+                       (const float*)nullptr, 0, out);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_batch_gemv2(const float* Wt, int M, int k0, const float* v0, int Kv0, int k1, const float* v1, int Kv1,
+                                float* out, int B, void* stream) {
+    DI2P_CHECK_ARG(Wt && v0 && v1 && out && M >= 1 && Kv0 >= 1 && Kv1 >= 1 && k0 >= 0 && k1 >= 0 && B >= 0, "bad args");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(batch_gemv_kernel, dim3(di2p_cdiv(M, 64), B), dim3(256), 0, (hipStream_t)stream, Wt, M, k0, v0, Kv0, k1, v1, Kv1, out);
     DI2P_RETURN_LAUNCH();
 }
 

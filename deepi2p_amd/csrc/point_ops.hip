@@ -163,10 +163,14 @@ __global__ __launch_bounds__(256) void argmax_channels_kernel(const float* __res
     int bi = 0;
     for (int c = 1; c < C; ++c) {
         const float v = s[(long long)c * N + n];
-        if (v > best) { best = v; bi = c; }
+        // torch.argmax semantics: NaN ranks above everything and the FIRST NaN / first maximum wins
+        if (best == best && (v != v || v > best)) { best = v; bi = c; }
     }
     out[(long long)b * N + n] = bi;
 }
+
+// torch.max semantics: NaN propagates (fmaxf would silently drop it and hide a faulty activation)
+__device__ __forceinline__ float nanmax(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); }
 
 // max over the last axis of [rows][N].  A row is handled by G = min(64, pow2 >= N) consecutive lanes, so short rows
 // (the K = 16 neighbour axis of the kNN fusion) pack 64/G rows into a wavefront and stay coalesced.
@@ -178,9 +182,9 @@ __global__ __launch_bounds__(256) void channel_max_kernel(const float* __restric
     float m = -__builtin_inff();
     if (row < rows) {
         const float* r = x + row * N;
-        for (int n = n0; n < N; n += G) m = fmaxf(m, r[n]);
+        for (int n = n0; n < N; n += G) m = nanmax(m, r[n]);
     }
-    for (int o = G >> 1; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    for (int o = G >> 1; o > 0; o >>= 1) m = nanmax(m, __shfl_xor(m, o));
     if (row < rows && n0 == 0) y[row] = m;
 }
 

@@ -1062,9 +1062,7 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
     hipLaunchKernelGGL(prepare_kernel<PT>, dim3(F), dim3(1024), 0, st, points, labels, N, ws.P, ws.NCMAX, keys, packed, boxes, counts);
     // DI2P_SOLVER_CFG=<waves per hypothesis><min waves/SIMD>, e.g. 43 (default); DI2P_SOLVER_NOCULL=1 classifies every
     // cluster per point (the sums are bit-identical by construction: tests compare the two)
-    static int cfg = -1, nocull = -1;
-    if (cfg < 0) { const char* e = getenv("DI2P_SOLVER_CFG"); cfg = e ? atoi(e) : 43; }
-    { const char* e = getenv("DI2P_SOLVER_NOCULL"); nocull = e ? atoi(e) : 0; }
+    const int cfg = (int)di2p_opt(DI2P_OPT_SOLVER_CFG), nocull = (int)di2p_opt(DI2P_OPT_SOLVER_NOCULL);
     const dim3 grid(R * F);
 #define DI2P_LAUNCH_SOLVE(NPV, MW, WP) hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP>), grid, dim3(WP * 64), 0, st, packed, boxes, ws.NCMAX, nocull, counts, K, init_y, init_T, yaw0, H, W, b, max_iter, F, R, N, params, cost, iters, sweeps, g_prof)
     if (is_2d) {

@@ -109,6 +109,17 @@ class _PackedModule(nn.Module):
     def _sd(self):
         return {k: v for k, v in self.state_dict().items()}
 
+    def prepack(self):
+        """Derive the kernel operands of this module and its sub-modules NOW, on the current stream, and wait for them:
+        afterwards forward() may be issued from any stream (or captured in a graph) without an ordering hazard on the
+        lazily packed weights."""
+        for m in self.modules():
+            if isinstance(m, _PackedModule) and hasattr(m, "_pack"):
+                m._pack()
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
+        return self
+
 
 def _fold(sd, conv_key, norm_key, tap_major=False):
     """(Wt [K,M], scale [M]|None, shift [M]) for conv(+bias) followed by optional BN(eval).
@@ -191,6 +202,7 @@ class PCEncoder(_PackedModule):
         cache = self.__dict__.setdefault("_gidx_cache", {})
         if key not in cache:
             cache[key] = (torch.arange(Mb * K, dtype=torch.int32, device=device) // K).unsqueeze(0).expand(B, -1).contiguous()
+            torch.cuda.current_stream().synchronize()     # created once per batch shape: visible to every stream from here on
         return cache[key]
 
     def forward_device(self, pc, intensity, sn, node_a, node_b):
@@ -344,7 +356,7 @@ class KeypointDetector(_PackedModule):
         w_s32 = ops.attention_pool(s32f, score_b)
         # node_b_pn (:152-155)
         Wt, sc, sh, act = p["node_b_pn"][0]
-        bias = ops.batch_gemv(Wt, 256, gf) + ops.batch_gemv(Wt, 1280, ig)
+        bias = ops.batch_gemv2(Wt, 256, gf, 1280, ig)
         h = ops.pointwise_gemm([Src(node_b_features), Src(w_s32)], p["node_b_pn_dense_Wt"], Wt.shape[1], Mb,
                                scale=sc, shift=sh, relu=act, batch_bias=bias)
         up_b = _run_pn(h, p["node_b_pn"][1:])

@@ -13,6 +13,7 @@ from . import _lib
 from ._lib import EpilogueT, SrcT, call, ptr, require_cuda, stream
 
 _f32, _i32, _f64 = torch.float32, torch.int32, torch.float64
+MAX_GK = 16          # DI2P_MAX_GK (include/deepi2p_hip.h)
 
 
 def _chk(t, dtype, name):
@@ -28,6 +29,10 @@ def index_max(data, index, K, return_values=False, mask=None):
     _chk(index, _i32, "index")
     B, C, N = data.shape
     K = int(K)
+    if tuple(index.shape) != (B, N):
+        raise RuntimeError("index must be i32[B, N] for data f32[B, C, N]")
+    if mask is not None and tuple(mask.shape) != (B, K):
+        raise RuntimeError("mask must be f32[B, K]")
     idx = torch.empty((B, C, K), dtype=_i32, device=data.device)
     ws = torch.empty((B * C * K,), dtype=torch.int64, device=data.device)
     if return_values:
@@ -126,43 +131,6 @@ class Src:
         self.t, self.mode, self.gidx, self.group = t, mode, gidx, group
 
 
-def pointwise_gemm(srcs, Wt, M, N, scale=None, shift=None, batch_bias=None, relu=False, group_max=1, gathered=None,
-                   transpose_out=False):
-    """Y[b] = epi(Wt^T @ concat(srcs)[b]).  srcs: list of Src; Wt f32[K,M].  gathered: optional list of up
-    to two (table f32[B,nodes,M] node-major, idx i32[B,N,k], w f32[B,N,k]).  transpose_out: Y is f32[B,N,M]."""
-    B = srcs[0].t.shape[0]
-    K = Wt.shape[0]
-    arr = (SrcT * len(srcs))()
-    keep = []
-    for i, s in enumerate(srcs):
-        arr[i].ptr = ptr(s.t)
-        arr[i].gidx = ptr(s.gidx)
-        arr[i].batch_stride = s.t.stride(0)
-        arr[i].row_stride = s.t.stride(1)
-        arr[i].channels = s.t.shape[1]
-        arr[i].mode = s.mode
-        arr[i].group = s.group
-        keep.append(s)
-    e = EpilogueT()
-    e.scale, e.shift, e.batch_bias = ptr(scale), ptr(shift), ptr(batch_bias)
-    e.relu, e.group_max = int(bool(relu)), int(group_max)
-    e.g_k = 0
-    if gathered:
-        for t, (tab, gi, gw) in enumerate(gathered):
-            require_cuda(tab, gi, gw)
-            if gi.dtype != _i32 or not gi.is_contiguous() or not tab.is_contiguous():
-                raise RuntimeError("gathered tables must be contiguous, indices int32 contiguous")
-            e.g_table[t], e.g_idx[t], e.g_w[t] = ptr(tab), ptr(gi), ptr(gw)
-            assert tab.shape[2] == M
-            e.g_nodes[t] = tab.shape[1]
-            e.g_k = gi.shape[2]
-    e.transpose_out = int(bool(transpose_out))
-    Nout = N // group_max if group_max > 1 else N
-    Y = torch.empty((B, Nout, M) if transpose_out else (B, M, Nout), dtype=_f32, device=Wt.device)
-    call("di2p_pointwise_gemm", arr, len(srcs), ptr(Wt), ptr(Y), B, M, K, N, ctypes.byref(e), stream())
-    return Y
-
-
 def _fill_srcs(srcs):
     arr = (SrcT * len(srcs))()
     for i, s in enumerate(srcs):
@@ -176,6 +144,54 @@ def _fill_srcs(srcs):
     return arr
 
 
+def _fill_gathered(e, gathered, B, M, N):
+    """Up to two gathered tables (table f32[B,nodes,M] node-major, idx i32[B,N,k_t], w f32[B,N,k_t] | None); each
+    table carries its OWN k (opt.k_interp_point_a and k_interp_point_b may differ)."""
+    e.g_k[0] = e.g_k[1] = 0
+    if not gathered:
+        return
+    if len(gathered) > 2:
+        raise RuntimeError("at most two gathered tables")
+    for t, (tab, gi, gw) in enumerate(gathered):
+        require_cuda(tab, gi, gw)
+        _chk(tab, _f32, "gathered table")
+        _chk(gi, _i32, "gathered index")
+        if tab.dim() != 3 or tab.shape[0] != B or tab.shape[2] != M:
+            raise RuntimeError("gathered table must be f32[B, nodes, M]")
+        if gi.dim() != 3 or gi.shape[0] != B or gi.shape[1] != N:
+            raise RuntimeError("gathered index must be i32[B, N, k]")
+        k = gi.shape[2]
+        if not 1 <= k <= MAX_GK:
+            raise RuntimeError("gathered k must be in [1, %d]" % MAX_GK)
+        if gw is not None:
+            _chk(gw, _f32, "gathered weights")
+            if gw.shape != gi.shape:
+                raise RuntimeError("gathered weights must have the index's shape")
+        e.g_table[t], e.g_idx[t], e.g_w[t] = ptr(tab), ptr(gi), ptr(gw)
+        e.g_nodes[t] = tab.shape[1]
+        e.g_k[t] = k
+
+
+def pointwise_gemm(srcs, Wt, M, N, scale=None, shift=None, batch_bias=None, relu=False, group_max=1, gathered=None,
+                   transpose_out=False):
+    """Y[b] = epi(Wt^T @ concat(srcs)[b]).  srcs: list of Src; Wt f32[K,M].  gathered: optional list of up
+    to two (table f32[B,nodes,M] node-major, idx i32[B,N,k], w f32[B,N,k]).  transpose_out: Y is f32[B,N,M]."""
+    B = srcs[0].t.shape[0]
+    K = Wt.shape[0]
+    arr = _fill_srcs(srcs)
+    e = EpilogueT()
+    e.scale, e.shift, e.batch_bias = ptr(scale), ptr(shift), ptr(batch_bias)
+    e.relu, e.group_max = int(bool(relu)), int(group_max)
+    _fill_gathered(e, gathered, B, M, N)
+    e.transpose_out = int(bool(transpose_out))
+    Nout = N // group_max if group_max > 1 else N
+    Y = torch.empty((B, Nout, M) if transpose_out else (B, M, Nout), dtype=_f32, device=Wt.device)
+    if _lib.WORK is not None:
+        _lib.WORK["di2p_pointwise_gemm"] = _lib.WORK.get("di2p_pointwise_gemm", 0) + B * M * K * N
+    call("di2p_pointwise_gemm", arr, len(srcs), ptr(Wt), ptr(Y), B, M, K, N, ctypes.byref(e), stream())
+    return Y
+
+
 def point_head(srcs, layer0, layer1, layer2, N, batch_bias=None, gathered=None):
     """Fused three-layer per-point head (di2p_point_head): layers are (Wt[K,M], scale, shift, relu) tuples with hidden
     width 128 and at most 4 outputs; layer0's Wt holds only the rows of the dense `srcs`.  -> f32[B, P, N]."""
@@ -187,15 +203,11 @@ def point_head(srcs, layer0, layer1, layer2, N, batch_bias=None, gathered=None):
     require_cuda(Wt0, Wt1, Wt2, sc0, sh0, sc1, sh1, sc2, sh2, batch_bias)
     e = EpilogueT()
     e.scale, e.shift, e.batch_bias = ptr(sc0), ptr(sh0), ptr(batch_bias)
-    e.relu, e.group_max, e.g_k, e.transpose_out = int(bool(act0)), 1, 0, 0
-    if gathered:
-        for t, (tab, gi, gw) in enumerate(gathered):
-            require_cuda(tab, gi, gw)
-            assert tab.shape[2] == M and gi.dtype == _i32
-            e.g_table[t], e.g_idx[t], e.g_w[t] = ptr(tab), ptr(gi), ptr(gw)
-            e.g_nodes[t] = tab.shape[1]
-            e.g_k = gi.shape[2]
+    e.relu, e.group_max, e.transpose_out = int(bool(act0)), 1, 0
+    _fill_gathered(e, gathered, B, M, N)
     out = torch.empty((B, P, N), dtype=_f32, device=Wt0.device)
+    if _lib.WORK is not None:
+        _lib.WORK["di2p_point_head"] = _lib.WORK.get("di2p_point_head", 0) + B * N * (Wt0.shape[0] * M + M * M + M * P)
     call("di2p_point_head", _fill_srcs(srcs), len(srcs), ptr(Wt0), Wt0.shape[0], ctypes.byref(e), ptr(Wt1), ptr(sc1), ptr(sh1),
          int(bool(act1)), ptr(Wt2), ptr(sc2), ptr(sh2), int(bool(act2)), ptr(out), B, M, P, N, stream())
     return out
@@ -208,6 +220,16 @@ def batch_gemv(Wt, k0, v):
     M = Wt.shape[1]
     out = torch.empty((B, M), dtype=_f32, device=Wt.device)
     call("di2p_batch_gemv", ptr(Wt), M, int(k0), ptr(v), Kv, ptr(out), B, stream())
+    return out
+
+
+def batch_gemv2(Wt, k0, v0, k1, v1):
+    """out[b,m] = sum_k Wt[k0+k, m] v0[b,k] + sum_k Wt[k1+k, m] v1[b,k]  (one launch)."""
+    require_cuda(Wt, v0, v1)
+    B = v0.shape[0]
+    M = Wt.shape[1]
+    out = torch.empty((B, M), dtype=_f32, device=Wt.device)
+    call("di2p_batch_gemv2", ptr(Wt), M, int(k0), ptr(v0), v0.shape[1], int(k1), ptr(v1), v1.shape[1], ptr(out), B, stream())
     return out
 
 

@@ -154,7 +154,8 @@ class RegistrationPipeline:
         ops.call("di2p_f32_to_f64", ops.ptr(pc_f32), ops.ptr(pts64), F * 3 * N, ops.stream())
         yaw0, lab_front, has_inside = ops.initial_guess(pts64, labels_i32)
         noise, Ts = restarts
+        sweeps = torch.empty(noise.shape, dtype=torch.int32, device=pc_f32.device)
         params, cost, iters = ops.solve_batched(pc_f32, lab_front, K_f64, noise, Ts, self.H, self.W, self.lb, self.ub,
-                                                self.max_iter, self.is_2d, yaw0=yaw0)
+                                                self.max_iter, self.is_2d, yaw0=yaw0, sweeps=sweeps)
         best, P, bc = ops.select_best(params, cost, self.is_2d, has_inside=has_inside)
-        return dict(P=P, cost=bc, best=best, yaw0=yaw0, costs=cost, iters=iters, params=params, labels_front=lab_front)
+        return dict(P=P, cost=bc, best=best, yaw0=yaw0, costs=cost, iters=iters, sweeps=sweeps, params=params, labels_front=lab_front)

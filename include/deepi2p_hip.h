@@ -23,6 +23,11 @@ extern "C" {
 
 const char* di2p_last_error(void);
 int di2p_version(void);
+/* Tuning / test knobs, cached in the library (initialised once from the environment variable DI2P_<NAME>): "conv_nosplit",
+ * "conv_split_blocks", "conv_novec", "conv_cfg", "pw_novec", "solver_cfg", "solver_nocull", "solver_tier_sweeps".
+ * set: 0, or -1 for an unknown name; get: the value, or -1 for an unknown name. */
+int di2p_set_option(const char* name, long long value);
+long long di2p_get_option(const char* name);
 
 /* ---------------------------------------------------------------------------------------------
  * index_max  -- replaces models/index_max_ext: index_max.cpp:141-148 (forward_cuda_shared_mem),
@@ -94,6 +99,7 @@ int di2p_argmax_channels(const float* scores, int32_t* out, int B, int C, int N,
  * transposed to [K,M] (packed once at load time).  group_max > 1 takes the max over each run of
  * `group_max` consecutive columns (torch.max(dim=3) of layers_pc.py:811,816). */
 #define DI2P_MAX_SRC 3
+#define DI2P_MAX_GK 16      /* = the k limit of di2p_knn_nodes */
 enum { DI2P_SRC_DENSE = 0,   /* X[b,c,n]      = ptr[b*batch_stride + c*row_stride + n]            */
        DI2P_SRC_GATHER = 1,  /* X[b,c,n]      = ptr[b*batch_stride + c*row_stride + gidx[b,n]]    */
        DI2P_SRC_GROUP = 2    /* X[b,c,n]      = ptr[b*batch_stride + c*row_stride + n / group]    */ };
@@ -116,10 +122,11 @@ typedef struct {
     int group_max;             /* 1 = none */
     /* optional gathered add (per_point_pn layer 0 with W*interp == interp(W*nodes)):            */
     const float* g_table[2];   /* each f32[B,g_nodes,M] (node-major, M % 4 == 0; what transpose_out writes) or NULL */
-    const int32_t* g_idx[2];   /* i32[B,N,g_k] */
-    const float* g_w[2];       /* f32[B,N,g_k], or NULL for unit weights (plain gather) */
+    const int32_t* g_idx[2];   /* i32[B,N,g_k[t]] */
+    const float* g_w[2];       /* f32[B,N,g_k[t]], or NULL for unit weights (plain gather) */
     int g_nodes[2];
-    int g_k;
+    int g_k[2];                /* neighbours per column of each table, 1..DI2P_MAX_GK (the two tables may differ:
+                                  opt.k_interp_point_a / k_interp_point_b, networks_united.py:158-165,188-191) */
     int transpose_out;         /* 1: Y is written f32[B,N,M] (needs M % 4 == 0, group_max == 1) */
 } di2p_epilogue_t;
 
@@ -139,6 +146,10 @@ int di2p_point_head(const di2p_src_t* srcs_host, int n_src, const float* W0t, in
                     float* out, int B, int M, int P, int N, void* stream);
 
 int di2p_batch_gemv(const float* Wt, int M, int k0, const float* v, int Kv, float* out, int B, void* stream);
+/* Two broadcast inputs in one launch: Y[b,m] = (sum_k Wt[k0+k,m] v0[b,k]) + (sum_k Wt[k1+k,m] v1[b,k]), each sum formed
+ * exactly as di2p_batch_gemv forms it (node_b_pn: global PC feature + global image feature, networks_united.py:152-155). */
+int di2p_batch_gemv2(const float* Wt, int M, int k0, const float* v0, int Kv0, int k1, const float* v1, int Kv1,
+                     float* out, int B, void* stream);
 
 /* Batched attention contraction of networks_united.py:147-150,170-174:
  * out[b,c,m] = (1/HW) * sum_hw feat[b,c,hw] * score[b,hw,m]. */

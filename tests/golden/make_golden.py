@@ -12,6 +12,12 @@ where /root/reference exists):   python tests/golden/make_golden.py
                          get_inside_img_mask and data/augmentation.py angles2rotation_matrix: the function
                          DEFINITIONS are extracted from the reference files with ``ast`` and exec'd here
                          (the modules themselves need open3d/cv2/TkAgg); only inputs/outputs are stored.
+  network_fullsize_golden.npz   the imported reference at the BASELINE config-2/3 size (B=1, N=20480, 160x512), coarse-only
+                         and coarse+fine models, on the seeded synthetic frame deepi2p_amd.synthetic.make_batch(41, 1)
+                         (regenerated on the GPU box; its SHA-256 is stored to detect generator drift): every 40th point's
+                         logits, ALL argmax labels (coarse bit-packed, fine uint8), per-output percentiles / sums, and
+                         percentiles of the encoder stages (SURVEY.md 8c fixture policy: "one full-size KITTI-shape run
+                         reduced to checksums/percentiles")
 Fixtures hold data only (inputs + expected outputs), never reference source.
 """
 import ast
@@ -94,6 +100,68 @@ def make_network(fine, fname):
     print(fname, "coarse absmax", float(np.abs(out["coarse"]).max()))
 
 
+FULLSIZE_SEED, FULLSIZE_STRIDE = 41, 40
+PCTS = np.array([0, 1, 5, 25, 50, 75, 95, 99, 100], dtype=np.float64)
+
+
+def stats(a):
+    """[percentiles..., mean, abs-mean, abs-max] of a tensor/array (float64)."""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    return np.concatenate((np.percentile(a, PCTS), [a.mean(), np.abs(a).mean(), np.abs(a).max()]))
+
+
+def fullsize_inputs():
+    import hashlib
+    from deepi2p_amd import synthetic
+    b = synthetic.make_batch(FULLSIZE_SEED, 1)
+    names = ("pc", "intensity", "sn", "node_a", "node_b", "img")
+    h = hashlib.sha256()
+    for k in names:
+        h.update(np.ascontiguousarray(b[k]).tobytes())
+    return b, names, h.hexdigest()
+
+
+def make_fullsize():
+    b, names, digest = fullsize_inputs()
+    N, H, W = b["pc"].shape[2], b["img"].shape[2], b["img"].shape[3]
+    t = [torch.from_numpy(b[k]) for k in names]
+    out = {"input_sha256": np.array(digest), "meta": np.array([1, N, H, W, FULLSIZE_SEED, FULLSIZE_STRIDE], dtype=np.int32)}
+    for fine in (False, True):
+        tag = "fine_model" if fine else "coarse_model"
+        opt = rn.make_opt(N, H, W, fine, B=1)
+        det = rn.load_reference_detector(opt)
+        det.load_state_dict(nt.synthetic_state_dict(nt.OptLike(N, H, W, fine)))
+        with torch.no_grad():
+            enc = det.pc_encoder(*t[:5])
+            s16, s32, glob = det.img_encoder(t[5])
+            res = det(*t)
+        coarse = (res[0] if fine else res).numpy()
+        out[tag + "_coarse_sub"] = coarse[:, :, ::FULLSIZE_STRIDE].copy()
+        out[tag + "_coarse_labels"] = np.packbits(coarse.argmax(1).astype(np.uint8), axis=1)
+        out[tag + "_coarse_stats"] = stats(coarse)
+        out[tag + "_coarse_absmax"] = np.float64(np.abs(coarse).max())
+        # margin between the two coarse logits: label flips are only meaningful where it exceeds the tolerance
+        out[tag + "_coarse_margin"] = np.abs(coarse[:, 0] - coarse[:, 1]).astype(np.float32)
+        if fine:
+            f = res[1].numpy()
+            out[tag + "_fine_sub"] = f[:, :, ::FULLSIZE_STRIDE].copy()
+            out[tag + "_fine_labels"] = f.argmax(1).astype(np.uint8)
+            out[tag + "_fine_stats"] = stats(f)
+            out[tag + "_fine_absmax"] = np.float64(np.abs(f).max())
+            srt = np.sort(f, axis=1)
+            out[tag + "_fine_margin"] = (srt[:, -1] - srt[:, -2]).astype(np.float32)
+        if not fine:   # encoder stages are identical for both models
+            for name, v in (("first_pn_out", enc[3]), ("second_pn_out", enc[4]), ("node_a_features", enc[5]),
+                            ("node_b_features", enc[6]), ("global_feature", enc[7]), ("s16", s16), ("s32", s32), ("img_global", glob)):
+                out["stage_" + name + "_stats"] = stats(v.numpy())
+            out["stage_global_feature"] = enc[7].numpy()
+            out["stage_img_global"] = glob.numpy()
+            out["stage_node_b_features_sub"] = enc[6].numpy()[:, ::8, ::4].copy()
+        print("fullsize", tag, "coarse absmax", float(np.abs(coarse).max()))
+    np.savez_compressed(os.path.join(HERE, "network_fullsize_golden.npz"), **out)
+    print("network_fullsize_golden.npz written")
+
+
 def _extract_functions(path, names):
     src = open(path).read()
     tree = ast.parse(src)
@@ -169,10 +237,15 @@ def make_prep():
 
 
 if __name__ == "__main__":
+    only = sys.argv[1] if len(sys.argv) > 1 else None
     assert rn.available(), "needs /root/reference and oracle/_ref (make -C oracle ref)"
     torch.set_num_threads(8)
+    if only == "fullsize":
+        make_fullsize()
+        sys.exit(0)
     make_index_max()
     make_network(True, "network_golden.npz")
     make_network(False, "network_coarse_golden.npz")
     make_lsq_driver()
     make_prep()
+    make_fullsize()

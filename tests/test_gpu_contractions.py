@@ -5,6 +5,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from deepi2p_amd import _lib
+
 pytestmark = pytest.mark.gpu
 
 
@@ -30,8 +32,7 @@ def test_pointwise_gemm_dense(dev, B, M, K, N):
 def test_pointwise_gemm_dense_vector_path(dev, B, chans, M, N):
     """16-byte staged path (all sources dense, N % 4 == 0, M % 4 == 0): ragged K, M and N against torch and against the
     scalar stager."""
-    import os
-    from deepi2p_amd import ops
+    from deepi2p_amd import _lib, ops
     g = torch.Generator().manual_seed(11 + N)
     xs = [torch.randn(B, c, N, generator=g) for c in chans]
     K = sum(chans)
@@ -44,11 +45,8 @@ def test_pointwise_gemm_dense_vector_path(dev, B, chans, M, N):
     y = ops.pointwise_gemm(srcs, Wt, M, N, **args).cpu()
     ref = torch.relu((torch.einsum("mk,bkn->bmn", W, torch.cat(xs, 1)) + bias.unsqueeze(2)) * scale.view(1, M, 1) + shift.view(1, M, 1))
     assert (y - ref).abs().max() <= _tol(ref, K)
-    os.environ["DI2P_PW_NOVEC"] = "1"
-    try:
+    with _lib.option("pw_novec", 1):
         y0 = ops.pointwise_gemm(srcs, Wt, M, N, **args).cpu()
-    finally:
-        del os.environ["DI2P_PW_NOVEC"]
     assert (y - y0).abs().max() <= _tol(ref, K)
     yt = ops.pointwise_gemm(srcs, Wt, M, N, transpose_out=True, **args).cpu()
     assert torch.equal(yt.transpose(1, 2), y)
@@ -84,13 +82,9 @@ def test_pointwise_gemm_concat_gather_group_bias(dev):
                       grpsrc.repeat_interleave(grp, dim=2), bvec.unsqueeze(2).expand(B, 40, N)), dim=1)
     ref = torch.einsum("mk,bkn->bmn", W, full)
     assert (y - ref).abs().max() <= _tol(ref, K)
-    import os
-    os.environ["DI2P_PW_NOVEC"] = "1"           # scalar stager: same operands element by element
-    try:
+    with _lib.option("pw_novec", 1):            # scalar stager: same operands element by element
         y0 = ops.pointwise_gemm([ops.Src(a.to(dev)), ops.Src(tab.to(dev), _lib.SRC_GATHER, gidx=gi.to(dev)),
                                  ops.Src(grpsrc.to(dev), _lib.SRC_GROUP, group=grp)], Wt_dense, M, N, batch_bias=bias).cpu()
-    finally:
-        del os.environ["DI2P_PW_NOVEC"]
     assert (y - y0).abs().max() <= _tol(ref, K)
     # fused max over groups of 16 consecutive columns (torch.max(dim=3) of layers_pc.py:811,816)
     ym = ops.pointwise_gemm([ops.Src(full.to(dev))], Wt, M, N, relu=True, group_max=grp).cpu()
@@ -161,12 +155,8 @@ def test_conv2d(dev, B, Cin, H, W, Cout, k, s, p):
         Wtap = w.permute(2, 3, 1, 0).reshape(-1, Cout).contiguous().to(dev)
         y3 = ops.conv2d(x.to(dev), Wtap, scale.to(dev), shift.to(dev), k, k, s, p, True, residual=res.to(dev), tap_major=True).cpu()
         assert (y3 - ref).abs().max() <= _tol(ref0, Cin * k * k)
-        import os
-        os.environ["DI2P_CONV_NOSPLIT"] = "1"
-        try:
+        with _lib.option("conv_nosplit", 1):
             y4 = ops.conv2d(x.to(dev), Wtap, scale.to(dev), shift.to(dev), k, k, s, p, True, residual=res.to(dev), tap_major=True).cpu()
-        finally:
-            del os.environ["DI2P_CONV_NOSPLIT"]
         assert (y4 - y3).abs().max() <= _tol(ref0, Cin * k * k)
         y5 = ops.conv2d(x.to(dev), Wtap, scale.to(dev), shift.to(dev), k, k, s, p, True, residual=res.to(dev), tap_major=True).cpu()
         assert torch.equal(y5, y3)                                    # run-to-run identical (ordered split-K reduce, no atomics)

@@ -120,11 +120,9 @@ def test_cluster_culling_is_exact(dev, is_2d, use_f32):
         params, cost, iters = ops.solve_batched(*args, sweeps=sweeps)
         return params.cpu().numpy(), cost.cpu().numpy(), iters.cpu().numpy(), sweeps.cpu().numpy()
     a = run()
-    os.environ["DI2P_SOLVER_NOCULL"] = "1"
-    try:
+    from deepi2p_amd import _lib
+    with _lib.option("solver_nocull", 1):
         b = run()
-    finally:
-        del os.environ["DI2P_SOLVER_NOCULL"]
     for u, v in zip(a, b):
         assert u.tobytes() == v.tobytes()        # bit-identical, NaN-safe
     assert np.isfinite(a[1]).sum() >= R - 4      # the planted on-plane points may fail hypotheses 0/1 only

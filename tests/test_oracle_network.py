@@ -77,3 +77,24 @@ def test_oracle_network_vs_live_reference():
         o = nt.keypoint_detector(sd, opt, *args)
     assert float((r[0] - o[0]).abs().max()) <= 1e-4 * float(r[0].abs().max())
     assert float((r[1] - o[1]).abs().max()) <= 1e-4 * float(r[1].abs().max())
+
+
+@pytest.mark.parametrize("fine", [False, True])
+def test_oracle_network_vs_reference_fullsize_golden(golden, fine):
+    """Oracle pin at the BASELINE config-2/3 size (N=20480, 160x512): sub-sampled logits, statistics and all argmax labels
+    of the imported reference (tests/golden/network_fullsize_golden.npz)."""
+    from tests import fullsize_golden as fg
+    g = golden("network_fullsize_golden.npz")
+    b, N, H, W, stride = fg.inputs(g)
+    torch.set_num_threads(8)
+    opt = nt.OptLike(N, H, W, fine)
+    sd = nt.synthetic_state_dict(opt)
+    t = [torch.from_numpy(b[k]) for k in fg.NAMES]
+    with torch.no_grad():
+        c, f, inter = nt.keypoint_detector(sd, opt, *t, return_intermediates=True)
+    fg.check_logits(g, "fine_model" if fine else "coarse_model", c.numpy(), f.numpy() if fine else None, 1e-4, 1e-4)
+    if not fine:
+        for name in ("first_pn_out", "second_pn_out", "node_a_features", "node_b_features", "global_feature", "s16", "s32", "img_global"):
+            ref = g["stage_%s_stats" % name]
+            assert np.abs(fg.stats(inter[name].numpy()) - ref).max() <= 1e-4 * ref[-1] + 1e-7, name
+        assert np.abs(inter["global_feature"].numpy() - g["stage_global_feature"]).max() <= 1e-4 * np.abs(g["stage_global_feature"]).max()

@@ -25,9 +25,9 @@ for name, lab_np in (("noisy-gt", np.stack([f["labels"] for f in frames])),):
             out = ops.solve_batched(pc, lab_front, K, restarts[0], restarts[1], H, W, pipe.lb, pipe.ub, 500, True, yaw0=yaw0, sweeps=sweeps)
             torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
         return best, out
-    os.environ["DI2P_SOLVER_NOCULL"] = "1"
-    dt_nocull, _ = timed()
-    del os.environ["DI2P_SOLVER_NOCULL"]
+    from deepi2p_amd import _lib
+    with _lib.option("solver_nocull", 1):
+        dt_nocull, _ = timed()
     dt, (params, cost, iters) = timed()
     print("per-point classification of every cluster (DI2P_SOLVER_NOCULL=1): %.2f ms ; with the cluster test: %.2f ms" % (dt_nocull * 1e3, dt * 1e3))
     kept = (lab_front >= 0).sum(1).float().mean().item()

@@ -3,7 +3,7 @@ counts, intrinsics and hypotheses the outputs with and without DI2P_SOLVER_NOCUL
 import os, sys, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from deepi2p_amd import ops, synthetic
+from deepi2p_amd import _lib, ops, synthetic
 
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(int(os.environ.get("SEED", 0)))
@@ -31,9 +31,8 @@ for it in range(cases):
         p, c, i = ops.solve_batched(*args, sweeps=sw)
         return [t.cpu().numpy().tobytes() for t in (p, c, i, sw)]
     a = run()
-    os.environ["DI2P_SOLVER_NOCULL"] = "1"
-    b = run()
-    del os.environ["DI2P_SOLVER_NOCULL"]
+    with _lib.option("solver_nocull", 1):
+        b = run()
     if a != b:
         bad += 1
         print("MISMATCH", dict(N=N, H=H, W=W, is_2d=is_2d, f32=f32))
