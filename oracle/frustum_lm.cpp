@@ -23,10 +23,21 @@
 // PARITY UNPINNED: Ceres/Eigen are absent from the reference tree and from this image, the
 // reference holds no golden vector for this path (evaluation/test_frustum_solver.py has a
 // stale signature and no asserts), so iterate-level equality with Ceres cannot be checked.
-// Deliberate simplifications vs Ceres (solution-level equivalent): the linear solve is a
-// Cholesky factorisation of the 4x4/6x6 normal equations instead of DENSE_QR of the stacked
-// Jacobian; the Armijo search interpolates quadratically (Ceres default: cubic, which needs a
-// gradient per trial point).  What pins this oracle instead (tests/test_oracle_solver.py):
+// The Armijo search follows Ceres' defaults (line_search.cc ArmijoLineSearch::DoSearch, polynomial.cc):
+// line_search_interpolation_type = CUBIC, i.e. every trial point is evaluated WITH its gradient, the
+// next step minimises the polynomial that interpolates value + directional derivative at step 0, at
+// the current trial and (from the third trial on) at the previous trial -- a cubic, then a quintic --
+// over [1e-3, 0.6] x current step (MinimizePolynomial: interval midpoint, both ends, critical points),
+// an invalid trial (non-finite cost or Jacobian) halves the step, at most 20 trials, minimum step 1e-9.
+// Remaining deviations from Ceres, all equal in exact arithmetic:
+//   * linear solve: Cholesky of the 4x4/6x6 normal equations instead of DENSE_QR of the stacked Jacobian;
+//   * interpolating polynomial: fitted in the normalised variable u = step / current step with the two
+//     constraints at step 0 eliminated analytically (Ceres: FullPivLU of the raw Vandermonde system);
+//   * its minimiser: real critical points isolated by bracketing (Ceres: real parts of the eigenvalues of
+//     the companion matrix of the derivative; real parts of complex roots can never win the strict
+//     comparison of MinimizePolynomial because the minimum over a closed interval is attained at an end
+//     point or a real critical point, which are all candidates).
+// What pins this oracle instead (tests/test_oracle_solver.py):
 // residual known-answers from an independent numpy evaluation, dual-number Jacobians vs central
 // finite differences, cost == 1/2 sum log(1+|r|^2), synthetic recover-the-pose runs, and a
 // solution-level cross-check against scipy.optimize.least_squares on the corrected residuals.
@@ -188,6 +199,124 @@ bool chol_solve(const double* M, const double* rhs, double* y) {
     return true;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Ceres polynomial.cc / line_search.cc restated (see header for the three exact-arithmetic-equal deviations).
+struct Sample { double x, value, gradient; bool value_ok, grad_ok; };
+
+inline double poly_eval(const double* c, int deg, double u) {     // c[0] + c[1] u + ... (Horner)
+    double v = c[deg];
+    for (int i = deg - 1; i >= 0; --i) v = v * u + c[i];
+    return v;
+}
+
+// root of the monotone piece of q on [a,b] with q(a), q(b) of opposite sign: safeguarded Newton / bisection
+inline double bracket_root(const double* q, int deg, double a, double b, double qa, double qb) {
+    double dq[6];
+    for (int i = 1; i <= deg; ++i) dq[i - 1] = i * q[i];
+    double x = 0.5 * (a + b);
+    for (int it = 0; it < 200; ++it) {
+        const double qx = poly_eval(q, deg, x);
+        if (qx == 0.0) return x;
+        if ((qx < 0.0) == (qa < 0.0)) { a = x; qa = qx; } else { b = x; qb = qx; }
+        const double d = poly_eval(dq, deg - 1, x);
+        double xn = x - qx / d;
+        if (!(xn > a && xn < b)) xn = 0.5 * (a + b);
+        if (xn == x || b - a <= 4e-16 * std::fabs(x)) return xn;
+        x = xn;
+    }
+    return x;
+}
+
+// all real roots of q (degree <= 4, ascending coefficients) inside [a,b], ascending, via the roots of q'
+inline int real_roots_in(const double* q, int deg, double a, double b, double* roots) {
+    while (deg > 0 && q[deg] == 0.0) --deg;                          // RemoveLeadingZeros
+    if (deg == 0) return 0;
+    if (deg == 1) { const double r = -q[0] / q[1]; if (r >= a && r <= b) { roots[0] = r; return 1; } return 0; }
+    double dq[5], crit[4];
+    for (int i = 1; i <= deg; ++i) dq[i - 1] = i * q[i];
+    const int nc = real_roots_in(dq, deg - 1, a, b, crit);
+    double knots[6];
+    int nk = 0;
+    knots[nk++] = a;
+    for (int i = 0; i < nc; ++i) knots[nk++] = crit[i];
+    knots[nk++] = b;
+    int n = 0;
+    for (int i = 0; i + 1 < nk; ++i) {
+        const double l = knots[i], r = knots[i + 1];
+        const double ql = poly_eval(q, deg, l), qr = poly_eval(q, deg, r);
+        if (ql == 0.0) { if (n == 0 || roots[n - 1] != l) roots[n++] = l; }
+        if (ql != 0.0 && qr != 0.0 && (ql < 0.0) != (qr < 0.0)) roots[n++] = bracket_root(q, deg, l, r, ql, qr);
+        if (i + 2 == nk && qr == 0.0) roots[n++] = r;
+    }
+    return n;
+}
+
+// LineSearch::InterpolatingPolynomialMinimizingStepSize for CUBIC: lowerbound = (0, f0, g0) always valid.
+inline double interpolating_step(double f0, double g0, const Sample& cur, const Sample& prev, double min_step, double max_step) {
+    if (!cur.value_ok) return std::min(std::max(cur.x * 0.5, min_step), max_step);
+    // polynomial p(u) = f0 + g0 xc u + u^2 r(u), u = x / xc; r has one coefficient per remaining constraint
+    const double xc = cur.x, G0 = g0 * xc;
+    double M[4][5];
+    int m = 0;
+    auto row_value = [&](double u, double val) {       // u^2 r(u) = val - f0 - G0 u
+        double pw = u * u;
+        for (int j = 0; j < 4; ++j) { M[m][j] = pw; pw *= u; }
+        M[m][4] = val - f0 - G0 * u; ++m;
+    };
+    auto row_grad = [&](double u, double gu) {         // d/du [u^2 r(u)] = gu - G0,  column j: (j+2) u^(j+1)
+        double pw = u;
+        for (int j = 0; j < 4; ++j) { M[m][j] = (j + 2) * pw; pw *= u; }
+        M[m][4] = gu - G0; ++m;
+    };
+    row_value(1.0, cur.value);
+    if (cur.grad_ok) row_grad(1.0, cur.gradient * xc);
+    if (prev.value_ok) {
+        const double up = prev.x / xc;
+        row_value(up, prev.value);
+        if (prev.grad_ok) row_grad(up, prev.gradient * xc);
+    }
+    // m x m solve, Gaussian elimination with partial pivoting (columns 0..m-1 are the unknowns r_0..r_{m-1})
+    double rc[4] = {0, 0, 0, 0};
+    bool singular = false;
+    for (int c = 0; c < m; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < m; ++r) if (std::fabs(M[r][c]) > std::fabs(M[piv][c])) piv = r;
+        if (M[piv][c] == 0.0) { singular = true; break; }
+        if (piv != c) for (int j = 0; j < 5; ++j) std::swap(M[piv][j], M[c][j]);
+        for (int r = c + 1; r < m; ++r) {
+            const double f = M[r][c] / M[c][c];
+            for (int j = c; j < m; ++j) M[r][j] -= f * M[c][j];
+            M[r][4] -= f * M[c][4];
+        }
+    }
+    if (!singular)
+        for (int c = m - 1; c >= 0; --c) {
+            double v = M[c][4];
+            for (int j = c + 1; j < m; ++j) v -= M[c][j] * rc[j];
+            rc[c] = v / M[c][c];
+        }
+    double p[6] = {f0, G0, 0, 0, 0, 0};
+    const int deg = m + 1;
+    for (int j = 0; j < m; ++j) p[j + 2] = rc[j];
+    for (int j = 0; j <= deg; ++j) if (!std::isfinite(p[j])) return std::min(std::max(cur.x * 0.5, min_step), max_step);
+    // MinimizePolynomial over u in [umin, umax]
+    const double umin = min_step / xc, umax = max_step / xc;
+    double best_u = 0.5 * (umin + umax), best_v = poly_eval(p, deg, best_u);
+    const double vmin = poly_eval(p, deg, umin);
+    if (vmin < best_v) { best_v = vmin; best_u = umin; }
+    const double vmax = poly_eval(p, deg, umax);
+    if (vmax < best_v) { best_v = vmax; best_u = umax; }
+    double dp[5], roots[4];
+    for (int i = 1; i <= deg; ++i) dp[i - 1] = i * p[i];
+    const int nr = real_roots_in(dp, deg - 1, umin, umax, roots);
+    for (int i = 0; i < nr; ++i) {
+        const double v = poly_eval(p, deg, roots[i]);
+        if (v < best_v) { best_v = v; best_u = roots[i]; }
+    }
+    return best_u * xc;
+}
+
 enum Term { T_MAX_ITER = 0, T_GRADIENT = 1, T_PARAMETER = 2, T_FUNCTION = 3, T_RADIUS = 4, T_INVALID = 5, T_EVAL_FAIL = 6 };
 
 template <int NP>
@@ -242,30 +371,37 @@ void minimize(const Problem<NP>& P, double* x, int max_iter, int* iters_out, int
         invalid_run = 0;
         double delta[NP];
         for (int a = 0; a < NP; ++a) delta[a] = ds[a] * S[a];
-        // --- projected Armijo line search (bounded problem), quadratic interpolation
+        // --- projected Armijo line search (bounded problem), Ceres defaults: CUBIC interpolation, so every trial is
+        //     evaluated with its gradient (TrustRegionMinimizer::DoLineSearch -> ArmijoLineSearch::DoSearch)
         {
             double gd = 0.0, dmax = 0.0;
             for (int a = 0; a < NP; ++a) { gd += g[a] * delta[a]; dmax = std::max(dmax, std::fabs(delta[a])); }
-            double t = 1.0, ft = 0.0; bool okv; int ls_it = 0; bool success = false;
-            auto f_at = [&](double tt, double* out) { double d2[NP], xc[NP]; for (int a = 0; a < NP; ++a) d2[a] = tt * delta[a]; P.plus(x, d2, xc); ++n_eval; return P.eval(xc, out, nullptr, nullptr, nullptr); };
-            okv = f_at(t, &ft);
+            auto sample_at = [&](double tt) {
+                Sample sm{tt, 0.0, 0.0, false, false};
+                double d2[NP], xc2[NP], gt[NP], At[NP * NP];
+                for (int a = 0; a < NP; ++a) d2[a] = tt * delta[a];
+                P.plus(x, d2, xc2);
+                ++n_eval;
+                if (!P.eval(xc2, &sm.value, gt, At, nullptr)) return sm;     // non-finite cost OR Jacobian: invalid sample
+                sm.value_ok = true;
+                double gdir = 0.0;
+                for (int a = 0; a < NP; ++a) gdir += delta[a] * gt[a];
+                sm.gradient = gdir;
+                sm.grad_ok = std::isfinite(gdir);
+                return sm;
+            };
+            Sample prev{0.0, 0.0, 0.0, false, false};
+            Sample cur = sample_at(1.0);
+            int ls_it = 0; bool success = false;
             for (;;) {
-                if (okv && ft <= cost + 1e-4 * gd * t) { success = true; break; }
+                if (cur.value_ok && cur.value <= cost + 1e-4 * gd * cur.x) { success = true; break; }
                 if (++ls_it >= 20) break;
-                const double lo = 1e-3 * t, hi = 0.6 * t;
-                double tn;
-                if (!okv) tn = std::min(std::max(0.5 * t, lo), hi);
-                else {
-                    const double a2 = (ft - cost - gd * t) / (t * t);          // q(s) = cost + gd s + a2 s^2
-                    auto qv = [&](double s) { return cost + gd * s + a2 * s * s; };
-                    tn = qv(lo) <= qv(hi) ? lo : hi;
-                    if (a2 > 0.0) { const double sc = -gd / (2.0 * a2); if (sc > lo && sc < hi && qv(sc) < qv(tn)) tn = sc; }
-                }
+                const double tn = interpolating_step(cost, gd, cur, prev, 1e-3 * cur.x, 0.6 * cur.x);
                 if (tn * dmax < 1e-9) break;
-                t = tn;
-                okv = f_at(t, &ft);
+                prev = cur;
+                cur = sample_at(tn);
             }
-            if (success && t != 1.0) for (int a = 0; a < NP; ++a) delta[a] *= t;
+            if (success && cur.x != 1.0) for (int a = 0; a < NP; ++a) delta[a] *= cur.x;
         }
         double xc[NP], cand_cost;
         P.plus(x, delta, xc);
