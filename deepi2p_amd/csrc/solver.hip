@@ -320,9 +320,11 @@ struct LogProd {
     __device__ __forceinline__ double log_value() const { return log(m) + (double)e * 0.69314718055994530942; }
 };
 
-// WITH_J == false: cost only (line-search trials beyond the first, 92 % of which are rejected): the residual rows, s and
-// the cost product are computed by the SAME operations in the same order, so the cost is bit-identical to a full sweep's.
-template <int NP, typename PT, int LAB, bool WITH_J>
+// MODE 2: cost, gradient J^T r and normal equations J^T J; MODE 1: cost and gradient only (line-search trials beyond the
+// first: Ceres' CUBIC interpolation needs the directional derivative at every trial, 92 % of them are rejected, the accepted
+// ones are confirmed by a MODE-2 sweep); MODE 0: cost only.  The residual rows, s, the cost product and the gradient terms
+// are computed by the SAME operations in the same order in every mode, so shared outputs are bit-identical across modes.
+template <int NP, typename PT, int LAB, int MODE>
 __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& rot, const double* x, const Cam& k, LogProd& cost,
                                             double* lg, double* lA, bool& bad) {
     constexpr int TOFF = NP == 4 ? 1 : 3;
@@ -358,7 +360,7 @@ __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& ro
     if (!isfinite(s)) bad = true;
     const double s1 = 1.0 + s;
     cost.mul(s1);                                // rho(s) = log(1+s), accumulated as a product
-    if (!WITH_J) return;
+    if (MODE == 0) return;
     const double rho1 = fast_rcp(s1);
     const double ax = k.fx * iz, bx = -k.fx * p0 * iz * iz;   // dpix_x = ax*dp0 + bx*dp2
     const double ay = k.fy * iz, by = -k.fy * p1 * iz * iz;   // dpix_y = ay*dp1 + by*dp2
@@ -392,9 +394,11 @@ __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& ro
 #pragma unroll
         for (int a = 0; a < NP; ++a) {
             lg[a] += wr * J[a];
-            const double wa = rho1 * J[a];
+            if (MODE == 2) {
+                const double wa = rho1 * J[a];
 #pragma unroll
-            for (int b = 0; b <= a; ++b) lA[a * (a + 1) / 2 + b] += wa * J[b];
+                for (int b = 0; b <= a; ++b) lA[a * (a + 1) / 2 + b] += wa * J[b];
+            }
         }
     }
 }
@@ -465,7 +469,7 @@ __device__ __forceinline__ int cluster_status(const Box& bx, const Rot<NP>& rot,
 // Active ids go to the per-wave LDS queue and are evaluated densely (phase B) 64 at a time.  The queue sequence is the
 // same as if every cluster had been classified per point, so the sums are bit-identical to the unculled sweep
 // (nocull != 0 forces status 1 everywhere: tests compare the two).
-template <int NP, typename PT, int WPH, int LAB, bool WITH_J>
+template <int NP, typename PT, int WPH, int LAB, int MODE>
 __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs, int cnt, const Box* __restrict__ boxes, int nc,
                                                const Cam& k, const Planes& pl, const double* x, const Rot<NP>& rot, int nocull,
                                                int* queue, LogProd& cost, double* lg, double* lA, bool& bad, int* n_active) {
@@ -494,7 +498,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
             n_active[0] += qn > 64 ? 64 : qn;
             qn = qn > 64 ? qn - 64 : 0;
             __builtin_amdgcn_wave_barrier();
-            if (n >= 0) eval_active<NP, PT, LAB, WITH_J>(recs[n], rot, x, k, cost, lg, lA, bad);
+            if (n >= 0) eval_active<NP, PT, LAB, MODE>(recs[n], rot, x, k, cost, lg, lA, bad);
         }
     };
     // exact classification of one record (the reference's pixel-form conditions)
@@ -542,7 +546,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
 // Leaves the WPH wave partials {cost, g[NP], A[tri], bad} in sh.red[wave][*]; the caller combines them after a
 // barrier.  Records are sorted by label (prepare_kernel): the label-1 block and the label-0 block are swept by two
 // specialised loops.
-template <int NP, typename PT, int WPH, bool WITH_J>
+template <int NP, typename PT, int WPH, int MODE>
 __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Box* __restrict__ boxes, int cnt1, int cnt0, int nc1,
                                      int nc0, const Cam& k, const Planes& pl, const double* x, int nocull, SweepShared<NP, WPH>& sh, int* n_active) {
     constexpr int NV = Tri<NP>::N + NP + 2;
@@ -558,23 +562,29 @@ __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Bo
 #pragma unroll
     for (int i = 0; i < Tri<NP>::N; ++i) lA[i] = 0.0;
     bool bad = false;
-    sweep_clusters<NP, PT, WPH, 1, WITH_J>(recs, cnt1, boxes, nc1, k, pl, x, rot, nocull, queue, cost, lg, lA, bad, n_active);
-    sweep_clusters<NP, PT, WPH, 0, WITH_J>(recs + cnt1, cnt0, boxes + nc1, nc0, k, pl, x, rot, nocull, queue, cost, lg, lA, bad, n_active);
+    sweep_clusters<NP, PT, WPH, 1, MODE>(recs, cnt1, boxes, nc1, k, pl, x, rot, nocull, queue, cost, lg, lA, bad, n_active);
+    sweep_clusters<NP, PT, WPH, 0, MODE>(recs + cnt1, cnt0, boxes + nc1, nc0, k, pl, x, rot, nocull, queue, cost, lg, lA, bad, n_active);
 
     // a non-finite Jacobian entry (evaluation failure in the reference) makes a sum non-finite: tested once per sweep
-    if (WITH_J) {
+    if (MODE >= 1) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) if (!isfinite(lg[i])) bad = true;
+    }
+    if (MODE == 2) {
 #pragma unroll
         for (int i = 0; i < Tri<NP>::N; ++i) if (!isfinite(lA[i])) bad = true;
     }
     double* mine = sh.red[wave];
     double v = wave_sum(0.5 * cost.log_value());
     if (lane == 0) mine[0] = v;
+    if (MODE >= 1) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) { v = wave_sum(lg[i]); if (lane == 0) mine[1 + i] = v; }
+        for (int i = 0; i < NP; ++i) { v = wave_sum(lg[i]); if (lane == 0) mine[1 + i] = v; }
+    }
+    if (MODE == 2) {
 #pragma unroll
-    for (int i = 0; i < Tri<NP>::N; ++i) { v = wave_sum(lA[i]); if (lane == 0) mine[1 + NP + i] = v; }
+        for (int i = 0; i < Tri<NP>::N; ++i) { v = wave_sum(lA[i]); if (lane == 0) mine[1 + NP + i] = v; }
+    }
     if (lane == 0) mine[NV - 1] = (__any(bad) != 0) ? 1.0 : 0.0;
 }
 
@@ -634,6 +644,171 @@ __device__ __forceinline__ double grad_max_norm(const double* x, const double* g
     return m;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Ceres' ArmijoLineSearch with CUBIC interpolation (line_search.cc, polynomial.cc), same statement as the oracle's:
+// the next step minimises, over [1e-3, 0.6] x current step, the polynomial interpolating value + directional derivative at
+// step 0, at the current trial and (when valid) at the previous trial.  Fitted in u = step / current step with the two
+// constraints at 0 eliminated; minimiser = best of {interval midpoint, ends, real critical points} (MinimizePolynomial).
+// Runs on ONE lane between sweeps: loops are unrolled over compile-time indices so that everything stays in registers.
+template <int DEG> __device__ __forceinline__ double poly_eval(const double* c, double u) {
+    double v = c[DEG];
+#pragma unroll
+    for (int i = DEG - 1; i >= 0; --i) v = fma(v, u, c[i]);
+    return v;
+}
+
+template <int DEG>
+__device__ double bracket_root(const double* q, double a, double b, double qa) {
+    double dq[DEG];
+#pragma unroll
+    for (int i = 1; i <= DEG; ++i) dq[i - 1] = i * q[i];
+    double x = 0.5 * (a + b);
+    for (int it = 0; it < 200; ++it) {
+        const double qx = poly_eval<DEG>(q, x);
+        if (qx == 0.0) return x;
+        if ((qx < 0.0) == (qa < 0.0)) { a = x; qa = qx; } else { b = x; }
+        const double d = poly_eval<DEG - 1>(dq, x);
+        double xn = x - qx / d;
+        if (!(xn > a && xn < b)) xn = 0.5 * (a + b);
+        if (xn == x || b - a <= 4e-16 * fabs(x)) return xn;
+        x = xn;
+    }
+    return x;
+}
+
+// Real roots of q (degree <= DEG, ascending coefficients) inside [a,b): bracket i lies between the (i-1)-th and i-th
+// critical point of q (roots of q', found the same way one degree down), q is monotone on it, so it holds at most one
+// root -> slot i of (has, val).  Slots are ascending; everything is indexed at compile time (no scratch arrays).
+template <int DEG> struct RealRoots {
+    __device__ static void run(const double* q, double a, double b, bool* has, double* val) {
+        if (q[DEG] == 0.0) {                                   // RemoveLeadingZeros (polynomial.cc)
+            RealRoots<DEG - 1>::run(q, a, b, has, val);
+            has[DEG - 1] = false;
+            return;
+        }
+        double dq[DEG], vc[DEG - 1];
+        bool hc[DEG - 1];
+#pragma unroll
+        for (int i = 1; i <= DEG; ++i) dq[i - 1] = i * q[i];
+        RealRoots<DEG - 1>::run(dq, a, b, hc, vc);
+        double l = a, ql = poly_eval<DEG>(q, a);
+#pragma unroll
+        for (int i = 0; i < DEG; ++i) {
+            has[i] = false;
+            const bool last = i == DEG - 1;
+            if (last || hc[last ? 0 : i]) {
+                const double r = last ? b : vc[last ? 0 : i];
+                const double qr = poly_eval<DEG>(q, r);
+                if (ql == 0.0) { has[i] = true; val[i] = l; }
+                else if (qr != 0.0 && (ql < 0.0) != (qr < 0.0)) { has[i] = true; val[i] = bracket_root<DEG>(q, l, r, ql); }
+                l = r; ql = qr;
+            }
+        }
+    }
+};
+template <> struct RealRoots<1> {
+    __device__ static void run(const double* q, double a, double b, bool* has, double* val) {
+        has[0] = false;
+        if (q[1] == 0.0) return;
+        const double r = -q[0] / q[1];
+        if (r >= a && r <= b) { has[0] = true; val[0] = r; }
+    }
+};
+
+// MinimizePolynomial (polynomial.cc): interval midpoint first, then both ends, then the critical points, strict "<"
+__device__ double poly_min_on(const double* p, double umin, double umax) {     // p: degree <= 5, ascending
+    double best_u = 0.5 * (umin + umax), best_v = poly_eval<5>(p, best_u);
+    const double vmin = poly_eval<5>(p, umin);
+    if (vmin < best_v) { best_v = vmin; best_u = umin; }
+    const double vmax = poly_eval<5>(p, umax);
+    if (vmax < best_v) { best_v = vmax; best_u = umax; }
+    double dp[5], val[4];
+    bool has[4];
+#pragma unroll
+    for (int i = 1; i <= 5; ++i) dp[i - 1] = i * p[i];
+    RealRoots<4>::run(dp, umin, umax, has, val);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (has[i]) {
+            const double v = poly_eval<5>(p, val[i]);
+            if (v < best_v) { best_v = v; best_u = val[i]; }
+        }
+    return best_u;
+}
+
+struct LsSample { double x, value, gradient; bool value_ok, grad_ok; };
+
+// LineSearch::InterpolatingPolynomialMinimizingStepSize, CUBIC: p(u) = f0 + g0 xc u + u^2 (r0 + r1 u + r2 u^2 + r3 u^3) with one
+// coefficient per valid constraint {cur value, cur gradient, prev value, prev gradient}; missing constraints pin the
+// highest coefficients to zero (unit rows), so the 4x4 elimination below always runs on compile-time indices.
+__device__ double interpolating_step(double f0, double g0, const LsSample& cur, const LsSample& prev, double min_step, double max_step) {
+    const double bis = fmin(fmax(cur.x * 0.5, min_step), max_step);
+    if (!cur.value_ok) return bis;
+    const double xc = cur.x, G0 = g0 * xc;
+    const double up = prev.value_ok ? prev.x / xc : 2.0;
+    const bool valid[4] = {true, cur.grad_ok, prev.value_ok, prev.value_ok && prev.grad_ok};
+    const int m = 1 + (valid[1] ? 1 : 0) + (valid[2] ? 1 : 0) + (valid[3] ? 1 : 0);
+    double A[4][5];
+    {
+        const double us[4] = {1.0, 1.0, up, up};
+        const double rhs[4] = {cur.value - f0 - G0, cur.gradient * xc - G0, prev.value - f0 - G0 * up, prev.gradient * xc - G0};
+        int pad = m;                                           // next coefficient pinned to zero
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool is_grad = (i & 1) != 0;
+            double pw = is_grad ? us[i] : us[i] * us[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double e = is_grad ? (j + 2) * pw : pw;
+                A[i][j] = valid[i] ? (j < m ? e : 0.0) : (j == pad ? 1.0 : 0.0);
+                pw *= us[i];
+            }
+            A[i][4] = valid[i] ? rhs[i] : 0.0;
+            if (!valid[i]) ++pad;
+        }
+    }
+    // Gaussian elimination with partial pivoting
+    bool singular = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        double pv = fabs(A[c][c]);
+#pragma unroll
+        for (int i = c + 1; i < 4; ++i) if (fabs(A[i][c]) > pv) { pv = fabs(A[i][c]); piv = i; }
+        if (pv == 0.0) singular = true;
+#pragma unroll
+        for (int i = c + 1; i < 4; ++i)
+            if (i == piv) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) { const double t = A[i][j]; A[i][j] = A[c][j]; A[c][j] = t; }
+            }
+        const double inv = singular ? 0.0 : 1.0 / A[c][c];
+#pragma unroll
+        for (int i = c + 1; i < 4; ++i) {
+            const double f = A[i][c] * inv;
+#pragma unroll
+            for (int j = c; j < 5; ++j) A[i][j] -= f * A[c][j];
+        }
+    }
+    double r[4] = {0.0, 0.0, 0.0, 0.0};
+    if (!singular) {
+#pragma unroll
+        for (int c = 3; c >= 0; --c) {
+            double v = A[c][4];
+#pragma unroll
+            for (int j = c + 1; j < 4; ++j) v -= A[c][j] * r[j];
+            r[c] = v / A[c][c];
+        }
+    }
+    const double p[6] = {f0, G0, r[0], m > 1 ? r[1] : 0.0, m > 2 ? r[2] : 0.0, m > 3 ? r[3] : 0.0};
+    bool fin = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) if (!isfinite(p[j])) fin = false;
+    if (!fin) return bis;
+    return poly_min_on(p, min_step / xc, max_step / xc) * xc;
+}
+
 struct Bounds { double lb[3], ub[3]; };
 
 // Levenberg-Marquardt state of one hypothesis.  Lives ONCE per workgroup in LDS; thread 0 advances it between
@@ -645,7 +820,10 @@ struct LMState {
     double lb[NP], ub[NP];
     double cost, gmax, radius, decrease, gd, dmax, t, f1, model_change;
     int iter, nsweep, invalid_run, ls_it, phase, reuse_diag, ok1, done, max_iter;
-    int want_j;        // the NEXT sweep needs the normal equations (0: cost only)
+    int want_j;        // what the NEXT sweep must produce: 2 = cost + gradient + normal equations, 1 = cost + gradient
+    double g1[NP], A1[Tri<NP>::N];     // sums of the FIRST trial point (t = 1): the candidate when the line search fails
+    double prev_t, prev_f, prev_g;     // previous line-search sample (step, cost, directional derivative)
+    int prev_vok, prev_gok;
     int n_ls_extra, n_ls_late_accept, n_resweep;      // diagnostics: line-search trials beyond the first, accepted ones among them, re-sweeps
 };
 
@@ -691,7 +869,7 @@ __device__ void lm_begin_iteration(LMState<NP>& st) {
         }
         st.gd = gd; st.dmax = dmax; st.t = 1.0; st.ls_it = 0;
         plus_proj<NP>(st.x, st.delta, 1.0, st.lb, st.ub, st.xe);
-        st.phase = PH_TRIAL; st.want_j = 1;
+        st.phase = PH_TRIAL; st.want_j = 2; st.prev_vok = 0; st.prev_gok = 0;
         return;   // needs a sweep at xe
     }
 }
@@ -733,53 +911,50 @@ __device__ void lm_after_sweep(LMState<NP>& st, bool ok, double fe, const double
         lm_begin_iteration<NP>(st);
         return;
     }
-    if (st.phase == PH_RESWEEP) {   // normal equations of the unscaled first trial, whose cost was kept in f1
-        ++st.n_resweep;
-        lm_finish_iteration<NP>(st, st.f1, ge, Ae);
-        return;
-    }
-    // PH_TRIAL: projected Armijo search along delta.  The first trial (t = 1) is swept WITH its normal equations (it is
-    // accepted most of the time, so an accepted step costs one sweep); later trials are swept cost-only, and the rare
-    // one that satisfies Armijo is confirmed by a full sweep at the same point (PH_CONFIRM) before it is used.
+    // PH_TRIAL: projected Armijo search along delta (Ceres ArmijoLineSearch, CUBIC interpolation).  The first trial (t = 1)
+    // is swept WITH its normal equations (it is accepted most of the time, so an accepted step costs one sweep) and its
+    // sums are kept: it is also the candidate when the search fails.  Later trials are swept for cost + gradient only
+    // (the interpolation needs the directional derivative); the rare one that satisfies Armijo is confirmed by a full
+    // sweep at the same point (PH_CONFIRM) before it is used.
     if (st.phase == PH_CONFIRM) {
         st.phase = PH_TRIAL;
-        if (ok) { ++st.n_ls_late_accept; lm_finish_iteration<NP>(st, fe, ge, Ae); return; }
-        // non-finite Jacobian: this trial is an evaluation failure, exactly as if it had been swept in full right away
+        ++st.n_ls_late_accept;
+        lm_finish_iteration<NP>(st, ok ? fe : DBL_MAX, ge, Ae);     // same point, same sums: ok is what the trial sweep saw
+        return;
+    }
+    if (st.ls_it == 0) {
+        st.f1 = ok ? fe : DBL_MAX; st.ok1 = ok;
+        for (int a = 0; a < NP; ++a) st.g1[a] = ge[a];
+        for (int i = 0; i < Tri<NP>::N; ++i) st.A1[i] = Ae[i];
     } else {
-        if (st.ls_it == 0) { st.f1 = ok ? fe : DBL_MAX; st.ok1 = ok; } else ++st.n_ls_extra;
-        if (ok && fe <= st.cost + 1e-4 * st.gd * st.t) {
-            if (st.ls_it > 0) { st.phase = PH_CONFIRM; st.want_j = 1; return; }      // same xe again, with J
-            lm_finish_iteration<NP>(st, fe, ge, Ae);
-            return;
-        }
+        ++st.n_ls_extra;
+    }
+    if (ok && fe <= st.cost + 1e-4 * st.gd * st.t) {
+        if (st.ls_it > 0) { st.phase = PH_CONFIRM; st.want_j = 2; return; }      // same xe again, with the normal equations
+        lm_finish_iteration<NP>(st, fe, ge, Ae);
+        return;
     }
     bool give_up = ++st.ls_it >= 20;
     double tn = 0.0;
     if (!give_up) {
-        const double t = st.t, lo = 1e-3 * t, hi = 0.6 * t;
-        if (!ok) {
-            tn = fmin(fmax(0.5 * t, lo), hi);
-        } else {
-            const double a2 = (fe - st.cost - st.gd * t) / (t * t);
-            const double qlo = st.cost + st.gd * lo + a2 * lo * lo, qhi = st.cost + st.gd * hi + a2 * hi * hi;
-            tn = qlo <= qhi ? lo : hi;
-            if (a2 > 0.0) {
-                const double sc = -st.gd / (2.0 * a2);
-                const double qsc = st.cost + st.gd * sc + a2 * sc * sc;
-                const double qtn = qlo <= qhi ? qlo : qhi;
-                if (sc > lo && sc < hi && qsc < qtn) tn = sc;
-            }
+        LsSample cur{st.t, fe, 0.0, ok, false}, prev{st.prev_t, st.prev_f, st.prev_g, st.prev_vok != 0, st.prev_gok != 0};
+        if (ok) {
+            double gdir = 0.0;
+            for (int a = 0; a < NP; ++a) gdir += st.delta[a] * ge[a];
+            cur.gradient = gdir;
+            cur.grad_ok = isfinite(gdir);
         }
+        tn = interpolating_step(st.cost, st.gd, cur, prev, 1e-3 * st.t, 0.6 * st.t);
         if (tn * st.dmax < 1e-9) give_up = true;
+        st.prev_t = cur.x; st.prev_f = cur.value; st.prev_g = cur.gradient; st.prev_vok = cur.value_ok; st.prev_gok = cur.grad_ok;
     }
-    if (give_up) {   // delta stays unscaled: the candidate is the first trial point
+    if (give_up) {   // delta stays unscaled: the candidate is the first trial point, whose sums were kept
         plus_proj<NP>(st.x, st.delta, 1.0, st.lb, st.ub, st.xe);
-        if (st.ls_it > 1 || st.t != 1.0) { st.phase = PH_RESWEEP; st.want_j = 1; return; }   // sums on hand belong to another point
-        lm_finish_iteration<NP>(st, st.f1, ge, Ae);
+        lm_finish_iteration<NP>(st, st.f1, st.g1, st.A1);
         return;
     }
     st.t = tn;
-    st.want_j = 0;
+    st.want_j = 1;
     plus_proj<NP>(st.x, st.delta, tn, st.lb, st.ub, st.xe);
 }
 
@@ -818,7 +993,7 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
         for (int i = 0; i < NP; ++i) { st.x[i] = fmin(fmax(st.x[i], st.lb[i]), st.ub[i]); st.xe[i] = st.x[i]; }
         st.radius = 1e4; st.decrease = 2.0; st.reuse_diag = 0; st.invalid_run = 0; st.iter = 0; st.nsweep = 0;
         st.phase = PH_INIT; st.done = 0; st.max_iter = max_iter; st.cost = 0.0; st.gmax = 0.0;
-        st.n_ls_extra = 0; st.n_ls_late_accept = 0; st.n_resweep = 0; st.want_j = 1;
+        st.n_ls_extra = 0; st.n_ls_late_accept = 0; st.n_resweep = 0; st.want_j = 2;
     }
     __syncthreads();
     long long c_sweep = 0, c_wait = 0, c_lm = 0;
@@ -828,8 +1003,8 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
 #pragma unroll
         for (int i = 0; i < NP; ++i) xe[i] = st.xe[i];
         const long long t0 = prof ? clock64() : 0;
-        if (st.want_j) sweep<NP, PT, WPH, true>(recs, boxes, cnt1, cnt0, nc1, nc0, k, pl, xe, nocull, sh, n_act);
-        else sweep<NP, PT, WPH, false>(recs, boxes, cnt1, cnt0, nc1, nc0, k, pl, xe, nocull, sh, n_act);
+        if (st.want_j == 2) sweep<NP, PT, WPH, 2>(recs, boxes, cnt1, cnt0, nc1, nc0, k, pl, xe, nocull, sh, n_act);
+        else sweep<NP, PT, WPH, 1>(recs, boxes, cnt1, cnt0, nc1, nc0, k, pl, xe, nocull, sh, n_act);
         const long long t1 = prof ? clock64() : 0;
         __syncthreads();
         const long long t2 = prof ? clock64() : 0;
