@@ -90,7 +90,7 @@ def load():
         lib.di2p_last_error.restype = ctypes.c_char_p
         lib.di2p_version.restype = c_int
         lib.di2p_solve_workspace_bytes.restype = c_ll
-        lib.di2p_solve_workspace_bytes.argtypes = [c_int, c_int]
+        lib.di2p_solve_workspace_bytes.argtypes = [c_int, c_int, c_int]
         lib.di2p_pnp_workspace_bytes.restype = c_ll
         lib.di2p_pnp_workspace_bytes.argtypes = [c_int, c_int, c_int]
         lib.di2p_conv2d_workspace_bytes.restype = c_ll

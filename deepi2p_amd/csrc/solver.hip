@@ -268,11 +268,12 @@ __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ po
 //   reduction: xor-butterfly inside each wave, then the 4 wave partials are combined through LDS in a FIXED
 //     order by every thread, so all 256 threads hold bit-identical sums and the LM control flow that
 //     follows is workgroup-uniform.
-constexpr int QCAP = 128;        // per-wave queue capacity (<= 63 carried + 64 pushed per cluster)
+constexpr int QCAP = 512;        // per-wave queue capacity (ids); phase B drains it when fewer than 4 clusters' worth of room is left
 
 template <int NP, int WPH>   // WPH = waves per hypothesis (workgroup = WPH*64 threads)
 struct SweepShared {
     double red[WPH][Tri<NP>::N + NP + 2];
+    double comb[Tri<NP>::N + NP + 2];      // the WPH partials combined in a fixed order (lane i of wave 0 sums value i)
     int queue[WPH][QCAP];
 };
 
@@ -461,6 +462,71 @@ __device__ __forceinline__ int cluster_status(const Box& bx, const Rot<NP>& rot,
     return 1;
 }
 
+
+// fp32 PRE-FILTER of the per-point classification (phase A).  The exact test costs ~55 fp64 instructions per 64 points
+// (rotation, reciprocal, projection, pixel-form comparisons); most points it is run on are nowhere near a frustum plane.
+// Here the five plane functions f_i(p) = n_i . (R x + t) are evaluated in fp32 and compared with a margin
+//   m_i = 4e-6 * |n_i|_1 * (|x|_1 + |t|_1),
+// >= 8x the worst-case fp32 evaluation error (inputs rounded to fp32, <= 5 roundings per coordinate, <= 3 per plane:
+// <= 8 * 2^-24 * |n_i|_1 * (|x|_1 + |t|_1)).  A point whose five |f_i| all exceed their margins has, in exact arithmetic,
+// pixel coordinates at least 3e-6 * fx away from 0 / W-1 / H-1 and |p2| > 3e-6 * |p|, five orders of magnitude above the
+// rounding of the fp64 pixel-form test: its classification is the exact test's and none of dx, dy, p2 is zero or non-finite.
+// If ANY lane of a cluster is not certified, the whole cluster takes the exact fp64 path, so the active set -- and every
+// sum -- is bit-identical with and without the pre-filter (DI2P_SOLVER_NOPREFILTER=1; tests compare).
+struct Pre32 {
+    float R[9], t[3], T1;
+    float fx, cx, wcx, fy, cy, hcy;
+    float mL, mR, mT, mB, mZ;
+};
+template <int NP>
+__device__ __forceinline__ void make_pre32(const Rot<NP>& rot, double tx, double ty, double tz, const Cam& k, Pre32& q) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) q.R[i] = (float)rot.R[i];
+    q.t[0] = (float)tx; q.t[1] = (float)ty; q.t[2] = (float)tz;
+    q.T1 = (fabsf(q.t[0]) + fabsf(q.t[1]) + fabsf(q.t[2])) * 1.000001f;
+    q.fx = (float)k.fx; q.cx = (float)k.cx; q.wcx = (float)(k.W1 - k.cx);
+    q.fy = (float)k.fy; q.cy = (float)k.cy; q.hcy = (float)(k.H1 - k.cy);
+    const float rel = 4e-6f;
+    q.mL = rel * (fabsf(q.fx) + fabsf(q.cx)); q.mR = rel * (fabsf(q.fx) + fabsf(q.wcx));
+    q.mT = rel * (fabsf(q.fy) + fabsf(q.cy)); q.mB = rel * (fabsf(q.fy) + fabsf(q.hcy));
+    q.mZ = rel;
+    // wave-uniform by construction: keep the whole table in SGPRs (it is live across the cluster loop)
+    float* f = reinterpret_cast<float*>(&q);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(Pre32) / sizeof(float)); ++i) f[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, f[i])));
+}
+// -> act (valid only when !uncertain).  NaN / inf anywhere fails every comparison -> uncertain.
+template <int NP, int LAB>
+__device__ __forceinline__ void prefilter32(const Pre32& q, float X, float Y, float Z, bool& act, bool& uncertain) {
+    const float S = (fabsf(X) + fabsf(Y)) + (fabsf(Z) + q.T1);
+    float p0, p1, p2;
+    if (NP == 4) {
+        p0 = fmaf(q.R[0], X, fmaf(q.R[2], Z, q.t[0])); p1 = Y + q.t[1]; p2 = fmaf(q.R[6], X, fmaf(q.R[8], Z, q.t[2]));
+    } else {
+        p0 = fmaf(q.R[0], X, fmaf(q.R[1], Y, fmaf(q.R[2], Z, q.t[0])));
+        p1 = fmaf(q.R[3], X, fmaf(q.R[4], Y, fmaf(q.R[5], Z, q.t[1])));
+        p2 = fmaf(q.R[6], X, fmaf(q.R[7], Y, fmaf(q.R[8], Z, q.t[2])));
+    }
+    const float fL = fmaf(q.fx, p0, q.cx * p2), fR = fmaf(-q.fx, p0, q.wcx * p2);
+    const float fT = fmaf(q.fy, p1, q.cy * p2), fB = fmaf(-q.fy, p1, q.hcy * p2);
+    // all five certified positive  <=>  min_i (f_i - m_i S) > 0
+    const float lo = fminf(fminf(fminf(fmaf(-q.mL, S, fL), fmaf(-q.mR, S, fR)), fminf(fmaf(-q.mT, S, fT), fmaf(-q.mB, S, fB))), fmaf(-q.mZ, S, p2));
+    const bool inside = lo > 0.0f;
+    if (LAB == 1) {
+        // some plane certified negative  <=>  min_i (f_i + m_i S) < 0  -> active whatever the other planes say
+        const float hi = fminf(fminf(fminf(fmaf(q.mL, S, fL), fmaf(q.mR, S, fR)), fminf(fmaf(q.mT, S, fT), fmaf(q.mB, S, fB))), fmaf(q.mZ, S, p2));
+        const bool outside = hi < 0.0f;
+        act = outside;
+        uncertain = !(inside || outside);
+    } else {
+        // label 0 needs EVERY plane certified (an exact zero on any of them is an evaluation failure in the reference)
+        const float cm = fminf(fminf(fminf(fmaf(-q.mL, S, fabsf(fL)), fmaf(-q.mR, S, fabsf(fR))), fminf(fmaf(-q.mT, S, fabsf(fT)), fmaf(-q.mB, S, fabsf(fB)))),
+                               fmaf(-q.mZ, S, fabsf(p2)));
+        act = inside;
+        uncertain = !(cm > 0.0f);
+    }
+}
+
 // One label-uniform block of records [recs, recs+cnt) = nc clusters of CL records.  Cluster c belongs to wave
 // c % WPH (neighbouring clusters -- which tend to share their status -- spread over the waves).  Per round a lane
 // tests one cluster; the wave then walks the flagged ones:
@@ -480,26 +546,30 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
     const double hw = k.W1 * 0.5, hh = k.H1 * 0.5;
     int qn = 0;  // wave-uniform
     auto load_rec = [&](int c) {
-        // unconditional load from a clamped index (a load inside a branch is waited for on the spot); lanes past
-        // the end of the block are marked by lab = -1
-        const int n = c * CL + lane;
-        Rec<PT> r = recs[min(n, cnt - 1)];
-        if (n >= cnt) r.lab = -1;
-        return r;
+        // unconditional load from a clamped index (a load inside a branch is waited for on the spot)
+        return recs[min(max(c, 0) * CL + lane, cnt - 1)];
     };
+    // Phase B over the queued ids: full rounds of 64 from the FRONT of the queue (position p of the wave's active sequence is
+    // always evaluated by lane p % 64, so the per-lane sums do not depend on when the queue is drained); the records of the next
+    // round are gathered while the current round is evaluated.  flush: also the last, partial round.
     auto drain = [&](bool flush) {
-        while (qn >= 64 || (flush && qn > 0)) {
-            // LDS ops of one wave retire in order; only the compiler must not reorder them
-            __builtin_amdgcn_wave_barrier();
-            const int n = lane < qn ? queue[lane] : -1;
-            const int carry = (lane + 64 < qn) ? queue[lane + 64] : 0;
-            __builtin_amdgcn_wave_barrier();
-            if (lane + 64 < qn) queue[lane] = carry;
-            n_active[0] += qn > 64 ? 64 : qn;
-            qn = qn > 64 ? qn - 64 : 0;
-            __builtin_amdgcn_wave_barrier();
-            if (n >= 0) eval_active<NP, PT, LAB, MODE>(recs[n], rot, x, k, cost, lg, lA, bad);
+        const int total = flush ? qn : (qn & ~63);
+        __builtin_amdgcn_wave_barrier();          // LDS ops of one wave retire in order; only the compiler must not reorder them
+        int n_cur = queue[lane];
+        Rec<PT> r_cur = recs[min(max(n_cur, 0), cnt - 1)];
+        for (int pos = 0; pos < total; pos += 64) {
+            const int n_nxt = queue[min(pos + 64 + lane, QCAP - 1)];
+            const Rec<PT> r_nxt = recs[min(max(n_nxt, 0), cnt - 1)];          // unconditional, clamped (the last one is wasted)
+            if (pos + lane < total) eval_active<NP, PT, LAB, MODE>(r_cur, rot, x, k, cost, lg, lA, bad);
+            n_active[0] += min(64, total - pos);
+            n_cur = n_nxt; r_cur = r_nxt;
         }
+        const int rem = qn - total;               // < 64 ids stay queued (0 after a flush)
+        const int carry = queue[min(total + lane, QCAP - 1)];
+        __builtin_amdgcn_wave_barrier();
+        if (lane < rem) queue[lane] = carry;
+        __builtin_amdgcn_wave_barrier();
+        qn = rem;
     };
     // exact classification of one record (the reference's pixel-form conditions)
     auto exact_active = [&](const Rec<PT>& rec, bool valid) {
@@ -514,30 +584,60 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
         if (valid && (!(fabs(chk) > 0.0) || !(fabs(chk) < __builtin_inf()))) bad = true;
         return valid && dx > 0.0 && dy > 0.0 && p2 > 0.0;
     };
+    const bool use_pre = (nocull & 2) == 0;
+    nocull &= 1;
+    Pre32 pre;
+    make_pre32<NP>(rot, tx, ty, tz, k, pre);
+    // phase A of one flagged cluster: classify its 64 records (status 1) or take them all (status 2), append the active ids
+    auto classify = [&](int c, bool isA, const Rec<PT>& rec) {
+        const bool valid = c * CL + lane < cnt;                                     // padding lanes of a partial cluster
+        bool act = valid;
+        if (isA) {
+            bool unc = true;
+            if (use_pre) {
+                prefilter32<NP, LAB>(pre, (float)rec.x, (float)rec.y, (float)rec.z, act, unc);
+                act = act && valid;
+                unc = unc && valid;
+            }
+            if (__any(unc)) act = exact_active(rec, valid);      // wave-uniform: some lane is not certified -> exact test for the cluster
+        }
+        const unsigned long long bal = __ballot(act);
+        if (act) queue[qn + __popcll(bal & lt)] = c * CL + lane;
+        qn += __popcll(bal);
+    };
     const int mine = (nc - wave + WPH - 1) / WPH;        // clusters wave, wave+WPH, ... < nc
     for (int j0 = 0; j0 < mine; j0 += 64) {
         const int j = j0 + lane;
         int status = 0;
         if (j < mine) status = nocull ? 1 : cluster_status<NP, LAB>(boxes[j * WPH + wave], rot, tx, ty, tz, k, pl);
         const unsigned long long mA = __ballot(status == 1), mB = __ballot(status == 2);
-        unsigned long long m = mA | mB;
         n_active[1] += __popcll(mA); n_active[2] += __popcll(mB); n_active[3] += min(mine - j0, 64);
-        Rec<PT> nxt;
-        if (m) nxt = load_rec((j0 + (int)__builtin_ctzll(m)) * WPH + wave);
-        while (m) {
-            const int bit = (int)__builtin_ctzll(m);
-            const int c = (j0 + bit) * WPH + wave;
-            const bool isA = (mA >> bit) & 1ull;
-            m &= m - 1;
-            const Rec<PT> rec = nxt;
-            if (m) nxt = load_rec((j0 + (int)__builtin_ctzll(m)) * WPH + wave);     // next flagged cluster in flight
-            const bool valid = (int)rec.lab >= 0;                                   // padding lanes of a partial cluster
-            bool act = valid;
-            if (isA) act = exact_active(rec, valid);
-            const unsigned long long bal = __ballot(act);
-            if (act) queue[qn + __popcll(bal & lt)] = c * CL + lane;
-            qn += __popcll(bal);
-            drain(false);
+        // The flagged clusters are walked in index order with PF records in flight (a cluster's 64 records are one 16-byte load
+        // per lane; the L2 latency is several times the ~40 instructions a cluster costs).  Slot i of the ring holds the
+        // (bit index, record) of a cluster; exhausted slots carry bit = -1 (and a harmless clamped load).
+        unsigned long long mp = mA | mB;                 // clusters not yet requested
+        auto next_bit = [&]() { int b = -1; if (mp) { b = (int)__builtin_ctzll(mp); mp &= mp - 1; } return b; };
+        constexpr int PF = 4;
+        int bits[PF];
+        Rec<PT> ring[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) { bits[u] = next_bit(); ring[u] = load_rec((j0 + bits[u]) * WPH + wave); }
+        while (bits[0] >= 0) {
+            while (bits[0] >= 0 && qn <= QCAP - PF * 64) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    if (bits[u] >= 0) {          // wave-uniform
+                        const Rec<PT> rec = ring[u];
+                        const int bit = bits[u];
+                        bits[u] = next_bit();
+                        ring[u] = load_rec((j0 + bits[u]) * WPH + wave);
+                        classify((j0 + bit) * WPH + wave, (mA >> bit) & 1ull, rec);
+                    }
+                }
+                // slots are consumed in order 0..PF-1 and refilled in the same order, so after a full pass slot 0 again holds the
+                // oldest cluster; a pass that met an exhausted slot leaves only exhausted slots behind it
+            }
+            if (bits[0] >= 0) drain(false);      // queue nearly full: evaluate the full rounds, keep the remainder queued
         }
     }
     drain(true);
@@ -659,7 +759,7 @@ template <int DEG> __device__ __forceinline__ double poly_eval(const double* c, 
 }
 
 template <int DEG>
-__device__ double bracket_root(const double* q, double a, double b, double qa) {
+__device__ __forceinline__ double bracket_root(const double* q, double a, double b, double qa) {
     double dq[DEG];
 #pragma unroll
     for (int i = 1; i <= DEG; ++i) dq[i - 1] = i * q[i];
@@ -681,7 +781,7 @@ __device__ double bracket_root(const double* q, double a, double b, double qa) {
 // critical point of q (roots of q', found the same way one degree down), q is monotone on it, so it holds at most one
 // root -> slot i of (has, val).  Slots are ascending; everything is indexed at compile time (no scratch arrays).
 template <int DEG> struct RealRoots {
-    __device__ static void run(const double* q, double a, double b, bool* has, double* val) {
+    __device__ __forceinline__ static void run(const double* q, double a, double b, bool* has, double* val) {
         if (q[DEG] == 0.0) {                                   // RemoveLeadingZeros (polynomial.cc)
             RealRoots<DEG - 1>::run(q, a, b, has, val);
             has[DEG - 1] = false;
@@ -708,7 +808,7 @@ template <int DEG> struct RealRoots {
     }
 };
 template <> struct RealRoots<1> {
-    __device__ static void run(const double* q, double a, double b, bool* has, double* val) {
+    __device__ __forceinline__ static void run(const double* q, double a, double b, bool* has, double* val) {
         has[0] = false;
         if (q[1] == 0.0) return;
         const double r = -q[0] / q[1];
@@ -717,7 +817,7 @@ template <> struct RealRoots<1> {
 };
 
 // MinimizePolynomial (polynomial.cc): interval midpoint first, then both ends, then the critical points, strict "<"
-__device__ double poly_min_on(const double* p, double umin, double umax) {     // p: degree <= 5, ascending
+__device__ __forceinline__ double poly_min_on(const double* p, double umin, double umax) {     // p: degree <= 5, ascending
     double best_u = 0.5 * (umin + umax), best_v = poly_eval<5>(p, best_u);
     const double vmin = poly_eval<5>(p, umin);
     if (vmin < best_v) { best_v = vmin; best_u = umin; }
@@ -742,7 +842,7 @@ struct LsSample { double x, value, gradient; bool value_ok, grad_ok; };
 // LineSearch::InterpolatingPolynomialMinimizingStepSize, CUBIC: p(u) = f0 + g0 xc u + u^2 (r0 + r1 u + r2 u^2 + r3 u^3) with one
 // coefficient per valid constraint {cur value, cur gradient, prev value, prev gradient}; missing constraints pin the
 // highest coefficients to zero (unit rows), so the 4x4 elimination below always runs on compile-time indices.
-__device__ double interpolating_step(double f0, double g0, const LsSample& cur, const LsSample& prev, double min_step, double max_step) {
+__device__ __forceinline__ double interpolating_step(double f0, double g0, const LsSample& cur, const LsSample& prev, double min_step, double max_step) {
     const double bis = fmin(fmax(cur.x * 0.5, min_step), max_step);
     if (!cur.value_ok) return bis;
     const double xc = cur.x, G0 = g0 * xc;
@@ -813,7 +913,7 @@ struct Bounds { double lb[3], ub[3]; };
 
 // Levenberg-Marquardt state of one hypothesis.  Lives ONCE per workgroup in LDS; thread 0 advances it between
 // sweeps (a few hundred scalar flops), so the sweep's register budget is not shared with it.
-enum { PH_INIT = 0, PH_TRIAL = 1, PH_RESWEEP = 2, PH_CONFIRM = 3 };
+enum { PH_INIT = 0, PH_TRIAL = 1 };
 template <int NP>
 struct LMState {
     double x[NP], g[NP], A[Tri<NP>::N], S[NP], diag[NP], delta[NP], xe[NP];
@@ -828,27 +928,34 @@ struct LMState {
 };
 
 template <int NP>
-__device__ void lm_begin_iteration(LMState<NP>& st) {
+__device__ __forceinline__ void lm_begin_iteration(LMState<NP>& st) {
     constexpr int NT = Tri<NP>::N;
     const double kMinDiag = 1e-6, kMaxDiag = 1e32, kMinRadius = 1e-32, kGradTol = 1e-10;
     for (;;) {
         if (st.iter >= st.max_iter || st.gmax <= kGradTol || st.radius <= kMinRadius) { st.done = 1; return; }
         ++st.iter;
         double As[NT], gs[NP], M[NT], rhs[NP], ds[NP];
+#pragma unroll
         for (int a = 0; a < NP; ++a) {
             gs[a] = st.S[a] * st.g[a];
+#pragma unroll
             for (int b = 0; b <= a; ++b) As[a * (a + 1) / 2 + b] = st.S[a] * st.A[a * (a + 1) / 2 + b] * st.S[b];
         }
         if (!st.reuse_diag)
+#pragma unroll
             for (int a = 0; a < NP; ++a) st.diag[a] = fmin(fmax(As[a * (a + 1) / 2 + a], kMinDiag), kMaxDiag);
+#pragma unroll
         for (int i = 0; i < NT; ++i) M[i] = As[i];
+#pragma unroll
         for (int a = 0; a < NP; ++a) { M[a * (a + 1) / 2 + a] += st.diag[a] / st.radius; rhs[a] = -gs[a]; }
         bool valid = chol_solve<NP>(M, rhs, ds);
         double model_change = 0.0;
         if (valid) {
             double q = 0.0, l = 0.0;
+#pragma unroll
             for (int a = 0; a < NP; ++a) {
                 l += ds[a] * gs[a];
+#pragma unroll
                 for (int b = 0; b < NP; ++b) q += ds[a] * As[tri<NP>(a, b)] * ds[b];
             }
             model_change = -(l + 0.5 * q);
@@ -862,6 +969,7 @@ __device__ void lm_begin_iteration(LMState<NP>& st) {
         st.invalid_run = 0;
         st.model_change = model_change;
         double gd = 0.0, dmax = 0.0;
+#pragma unroll
         for (int a = 0; a < NP; ++a) {
             st.delta[a] = ds[a] * st.S[a];
             gd += st.g[a] * st.delta[a];
@@ -876,16 +984,19 @@ __device__ void lm_begin_iteration(LMState<NP>& st) {
 
 // candidate (xe, cand_cost, ge, Ae) against the current iterate: tolerance tests, accept / reject
 template <int NP>
-__device__ void lm_finish_iteration(LMState<NP>& st, double cand_cost, const double* ge, const double* Ae) {
+__device__ __forceinline__ void lm_finish_iteration(LMState<NP>& st, double cand_cost, const double* ge, const double* Ae) {
     const double kMaxRadius = 1e16, kMinRelDec = 1e-3, kFuncTol = 1e-6, kParamTol = 1e-8;
     double step_norm = 0.0, x_norm = 0.0;
+#pragma unroll
     for (int a = 0; a < NP; ++a) { step_norm += (st.x[a] - st.xe[a]) * (st.x[a] - st.xe[a]); x_norm += st.x[a] * st.x[a]; }
     step_norm = sqrt(step_norm); x_norm = sqrt(x_norm);
     if (step_norm <= kParamTol * (x_norm + kParamTol)) { st.done = 1; return; }
     if (fabs(st.cost - cand_cost) <= kFuncTol * st.cost) { st.done = 1; return; }
     const double rel = (st.cost - cand_cost) / st.model_change;
     if (rel > kMinRelDec) {
+#pragma unroll
         for (int a = 0; a < NP; ++a) { st.x[a] = st.xe[a]; st.g[a] = ge[a]; }
+#pragma unroll
         for (int i = 0; i < Tri<NP>::N; ++i) st.A[i] = Ae[i];
         st.cost = cand_cost;
         st.gmax = grad_max_norm<NP>(st.x, st.g, st.lb, st.ub);
@@ -900,38 +1011,35 @@ __device__ void lm_finish_iteration(LMState<NP>& st, double cand_cost, const dou
 
 // Called by thread 0 after every sweep with the combined sums of the point just evaluated (st.xe).
 template <int NP>
-__device__ void lm_after_sweep(LMState<NP>& st, bool ok, double fe, const double* ge, const double* Ae) {
+__device__ __forceinline__ void lm_after_sweep(LMState<NP>& st, bool ok, double fe, const double* ge, const double* Ae) {
     ++st.nsweep;
     if (st.phase == PH_INIT) {
         st.cost = fe;
         if (!ok) { st.done = 1; return; }
+#pragma unroll
         for (int a = 0; a < NP; ++a) { st.g[a] = ge[a]; st.S[a] = 1.0 / (1.0 + sqrt(Ae[a * (a + 1) / 2 + a])); }
+#pragma unroll
         for (int i = 0; i < Tri<NP>::N; ++i) st.A[i] = Ae[i];
         st.gmax = grad_max_norm<NP>(st.x, st.g, st.lb, st.ub);
         lm_begin_iteration<NP>(st);
         return;
     }
-    // PH_TRIAL: projected Armijo search along delta (Ceres ArmijoLineSearch, CUBIC interpolation).  The first trial (t = 1)
-    // is swept WITH its normal equations (it is accepted most of the time, so an accepted step costs one sweep) and its
-    // sums are kept: it is also the candidate when the search fails.  Later trials are swept for cost + gradient only
-    // (the interpolation needs the directional derivative); the rare one that satisfies Armijo is confirmed by a full
-    // sweep at the same point (PH_CONFIRM) before it is used.
-    if (st.phase == PH_CONFIRM) {
-        st.phase = PH_TRIAL;
-        ++st.n_ls_late_accept;
-        lm_finish_iteration<NP>(st, ok ? fe : DBL_MAX, ge, Ae);     // same point, same sums: ok is what the trial sweep saw
-        return;
-    }
+    // PH_TRIAL: projected Armijo search along delta (Ceres ArmijoLineSearch, CUBIC interpolation: every trial needs its
+    // gradient).  Every sweep also carries the normal equations (10 more fma per Jacobian row, ~3 % of a sweep), so whichever
+    // trial satisfies Armijo is used at once; the sums of the first trial (t = 1) are kept: it is the candidate when the
+    // search fails.
     if (st.ls_it == 0) {
         st.f1 = ok ? fe : DBL_MAX; st.ok1 = ok;
+#pragma unroll
         for (int a = 0; a < NP; ++a) st.g1[a] = ge[a];
+#pragma unroll
         for (int i = 0; i < Tri<NP>::N; ++i) st.A1[i] = Ae[i];
     } else {
         ++st.n_ls_extra;
     }
     if (ok && fe <= st.cost + 1e-4 * st.gd * st.t) {
-        if (st.ls_it > 0) { st.phase = PH_CONFIRM; st.want_j = 2; return; }      // same xe again, with the normal equations
-        lm_finish_iteration<NP>(st, fe, ge, Ae);
+        if (st.ls_it > 0) ++st.n_ls_late_accept;
+        lm_finish_iteration<NP>(st, fe, ge, Ae);       // every sweep carries its normal equations: an accepted trial needs no second sweep
         return;
     }
     bool give_up = ++st.ls_it >= 20;
@@ -940,6 +1048,7 @@ __device__ void lm_after_sweep(LMState<NP>& st, bool ok, double fe, const double
         LsSample cur{st.t, fe, 0.0, ok, false}, prev{st.prev_t, st.prev_f, st.prev_g, st.prev_vok != 0, st.prev_gok != 0};
         if (ok) {
             double gdir = 0.0;
+#pragma unroll
             for (int a = 0; a < NP; ++a) gdir += st.delta[a] * ge[a];
             cur.gradient = gdir;
             cur.grad_ok = isfinite(gdir);
@@ -954,7 +1063,6 @@ __device__ void lm_after_sweep(LMState<NP>& st, bool ok, double fe, const double
         return;
     }
     st.t = tn;
-    st.want_j = 1;
     plus_proj<NP>(st.x, st.delta, tn, st.lb, st.ub, st.xe);
 }
 
@@ -965,7 +1073,9 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
                                                        const double* __restrict__ init_T, const double* __restrict__ yaw0,
                                                        double H, double W, Bounds bnd, int max_iter, int F, int R, int N,
                                                        double* __restrict__ params_out, double* __restrict__ cost_out,
-                                                       int* __restrict__ iters_out, int* __restrict__ sweeps_out, long long* __restrict__ prof) {
+                                                       int* __restrict__ iters_out, int* __restrict__ sweeps_out, long long* __restrict__ prof,
+                                                       unsigned long long* __restrict__ state_buf, int* __restrict__ pending,
+                                                       int budget, int resume) {
     constexpr int TOFF = NP == 4 ? 1 : 3;
     constexpr int NT = Tri<NP>::N;
     constexpr int NV = NT + NP + 2;
@@ -983,8 +1093,15 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
     const Planes pl{sqrt(k.fx * k.fx + k.cx * k.cx), sqrt(k.fx * k.fx + (k.W1 - k.cx) * (k.W1 - k.cx)),
                     sqrt(k.fy * k.fy + k.cy * k.cy), sqrt(k.fy * k.fy + (k.H1 - k.cy) * (k.H1 - k.cy))};
     const long long hr = (long long)f * R + r;
-
-    if (threadIdx.x == 0) {
+    constexpr int ST_WORDS = (int)(sizeof(LMState<NP>) / 8);
+    static_assert(sizeof(LMState<NP>) % 8 == 0, "LMState is copied as 8-byte words");
+    // Two-tier launch (see launch_solve): the first launch stops a hypothesis after `budget` sweeps and parks its LM state;
+    // the second launch (more waves per hypothesis) resumes the parked ones and leaves the finished ones alone.
+    if (resume) {
+        if (pending[hr] == 0) return;            // finished in the first tier (workgroup-uniform)
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(&st);
+        for (int i = threadIdx.x; i < ST_WORDS; i += WPH * 64) dst[i] = state_buf[hr * ST_WORDS + i];
+    } else if (threadIdx.x == 0) {
         for (int i = 0; i < NP; ++i) { st.lb[i] = -DBL_MAX; st.ub[i] = DBL_MAX; }
         for (int i = 0; i < 3; ++i) { st.lb[TOFF + i] = bnd.lb[i]; st.ub[TOFF + i] = bnd.ub[i]; }
         const double y0 = init_y[hr] + (yaw0 ? yaw0[f] : 0.0);
@@ -996,39 +1113,51 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
         st.n_ls_extra = 0; st.n_ls_late_accept = 0; st.n_resweep = 0; st.want_j = 2;
     }
     __syncthreads();
-    long long c_sweep = 0, c_wait = 0, c_lm = 0;
+    long long c_sweep = 0, c_wait = 0, c_lm = 0, c_comb = 0;
     int n_act[4] = {0, 0, 0, 0};   // wave 0: phase-B evaluations, clusters classified per point / all active / tested
     for (;;) {
         double xe[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) xe[i] = st.xe[i];
         const long long t0 = prof ? clock64() : 0;
-        if (st.want_j == 2) sweep<NP, PT, WPH, 2>(recs, boxes, cnt1, cnt0, nc1, nc0, k, pl, xe, nocull, sh, n_act);
-        else sweep<NP, PT, WPH, 1>(recs, boxes, cnt1, cnt0, nc1, nc0, k, pl, xe, nocull, sh, n_act);
+        sweep<NP, PT, WPH, 2>(recs, boxes, cnt1, cnt0, nc1, nc0, k, pl, xe, nocull, sh, n_act);
         const long long t1 = prof ? clock64() : 0;
         __syncthreads();
         const long long t2 = prof ? clock64() : 0;
+        if (threadIdx.x < NV) {                 // fixed-order combination of the wave partials, one value per lane
+            double t = sh.red[0][threadIdx.x];
+#pragma unroll
+            for (int w = 1; w < WPH; ++w) t += sh.red[w][threadIdx.x];
+            sh.comb[threadIdx.x] = t;
+        }
+        __builtin_amdgcn_wave_barrier();        // same wave: its LDS operations retire in order
+        const long long t2b = prof ? clock64() : 0;
         if (threadIdx.x == 0) {
-            double v[NV];
-            for (int i = 0; i < NV; ++i) {      // fixed-order combination of the wave partials
-                double t = sh.red[0][i];
-                for (int w = 1; w < WPH; ++w) t += sh.red[w][i];
-                v[i] = t;
-            }
-            const bool ok = v[NV - 1] == 0.0 && isfinite(v[0]);
-            lm_after_sweep<NP>(st, ok, v[0], v + 1, v + 1 + NP);
+            const bool ok = sh.comb[NV - 1] == 0.0 && isfinite(sh.comb[0]);
+            lm_after_sweep<NP>(st, ok, sh.comb[0], sh.comb + 1, sh.comb + 1 + NP);
         }
         const long long t3 = prof ? clock64() : 0;
+        c_comb += t2b - t2;
         __syncthreads();
         c_sweep += t1 - t0; c_wait += t2 - t1; c_lm += t3 - t2;
         if (st.done) break;
+        if (budget > 0 && st.nsweep >= budget) break;       // parked for the wide tier (workgroup-uniform: st is in LDS)
+    }
+    if (pending) {
+        if (threadIdx.x == 0) pending[hr] = st.done ? 0 : 1;
+        if (!st.done) {
+            const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&st);
+            for (int i = threadIdx.x; i < ST_WORDS; i += WPH * 64) state_buf[hr * ST_WORDS + i] = src[i];
+        }
     }
     if (prof && threadIdx.x == 0) {   // diagnostics: shader-clock cycles of wave 0 per phase, phase-B evaluations of wave 0
+        if (resume) { c_sweep += prof[hr * 8 + 0]; c_wait += prof[hr * 8 + 1]; c_lm += prof[hr * 8 + 2]; c_comb += prof[hr * 8 + 6];
+                      n_act[0] += (int)prof[hr * 8 + 3]; n_act[1] += (int)prof[hr * 8 + 4]; n_act[2] += (int)prof[hr * 8 + 5]; }
         prof[hr * 8 + 0] = c_sweep; prof[hr * 8 + 1] = c_wait; prof[hr * 8 + 2] = c_lm; prof[hr * 8 + 3] = n_act[0];
-        prof[hr * 8 + 4] = n_act[1]; prof[hr * 8 + 5] = n_act[2]; prof[hr * 8 + 6] = n_act[3];
+        prof[hr * 8 + 4] = n_act[1]; prof[hr * 8 + 5] = n_act[2]; prof[hr * 8 + 6] = c_comb;
         prof[hr * 8 + 7] = (long long)st.n_ls_extra | ((long long)st.n_ls_late_accept << 20) | ((long long)st.n_resweep << 40);
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && st.done) {
         for (int i = 0; i < NP; ++i) params_out[hr * NP + i] = st.x[i];
         cost_out[hr] = st.cost;
         iters_out[hr] = st.iter;
@@ -1207,8 +1336,9 @@ __global__ __launch_bounds__(256) void residuals_kernel(const double* __restrict
 
 static long long* g_prof = nullptr;   // diagnostics hook, see di2p_solver_set_profile_buffer
 
-struct SolveWs { int P, NCMAX; size_t off_recs, off_boxes, off_keys, bytes; };
-static SolveWs solve_ws_layout(int F, int N) {
+constexpr size_t kStateBytes = sizeof(LMState<6>) > sizeof(LMState<4>) ? sizeof(LMState<6>) : sizeof(LMState<4>);
+struct SolveWs { int P, NCMAX; size_t off_recs, off_boxes, off_keys, off_pending, off_state, bytes; };
+static SolveWs solve_ws_layout(int F, int R, int N) {
     SolveWs w;
     w.P = 64;
     while (w.P < N) w.P <<= 1;
@@ -1217,7 +1347,9 @@ static SolveWs solve_ws_layout(int F, int N) {
     w.off_recs = up((size_t)F * 4 * sizeof(int));
     w.off_boxes = up(w.off_recs + (size_t)F * N * 32);
     w.off_keys = up(w.off_boxes + (size_t)F * w.NCMAX * sizeof(Box));
-    w.bytes = up(w.off_keys + (size_t)F * w.P * 8) + 256;
+    w.off_pending = up(w.off_keys + (size_t)F * w.P * 8);
+    w.off_state = up(w.off_pending + (size_t)F * R * sizeof(int));
+    w.bytes = up(w.off_state + (size_t)F * R * kStateBytes) + 256;
     return w;
 }
 
@@ -1227,8 +1359,8 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
                  int R, int N, double* params, double* cost, int* iters, int* sweeps, void* workspace, hipStream_t st) {
     Bounds b;
     for (int i = 0; i < 3; ++i) { b.lb[i] = lb[i]; b.ub[i] = ub[i]; }
-    // workspace: counts i32[F][4] | records Rec[F][N] | cluster boxes [F][NCMAX] | sort keys u64[F][P]
-    const SolveWs ws = solve_ws_layout(F, N);
+    // workspace: counts i32[F][4] | records Rec[F][N] | cluster boxes [F][NCMAX] | sort keys u64[F][P] | pending i32[F][R] | parked LM states [F][R]
+    const SolveWs ws = solve_ws_layout(F, R, N);
     char* base = (char*)workspace;
     int* counts = (int*)base;
     Rec<PT>* packed = (Rec<PT>*)(base + ws.off_recs);
@@ -1237,20 +1369,32 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
     hipLaunchKernelGGL(prepare_kernel<PT>, dim3(F), dim3(1024), 0, st, points, labels, N, ws.P, ws.NCMAX, keys, packed, boxes, counts);
     // DI2P_SOLVER_CFG=<waves per hypothesis><min waves/SIMD>, e.g. 43 (default); DI2P_SOLVER_NOCULL=1 classifies every
     // cluster per point (the sums are bit-identical by construction: tests compare the two)
-    const int cfg = (int)di2p_opt(DI2P_OPT_SOLVER_CFG), nocull = (int)di2p_opt(DI2P_OPT_SOLVER_NOCULL);
+    const int cfg = (int)di2p_opt(DI2P_OPT_SOLVER_CFG);
+    const int nocull = (di2p_opt(DI2P_OPT_SOLVER_NOCULL) ? 1 : 0) | (di2p_opt(DI2P_OPT_SOLVER_NOPREFILTER) ? 2 : 0);   // bit 0: no cluster test, bit 1: no fp32 pre-filter
     const dim3 grid(R * F);
-#define DI2P_LAUNCH_SOLVE(NPV, MW, WP) hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP>), grid, dim3(WP * 64), 0, st, packed, boxes, ws.NCMAX, nocull, counts, K, init_y, init_T, yaw0, H, W, b, max_iter, F, R, N, params, cost, iters, sweeps, g_prof)
+    // Two tiers against the tail: the sweep counts of the hypotheses are heavy-tailed (median 48, 10 % above 140, max > 200 on the
+    // config-2 workload) and a hypothesis is a sequential chain of sweeps, so a lone launch ends with a few long chains on an
+    // otherwise idle chip.  Tier 1 (4 waves per hypothesis, 3 workgroups per CU: throughput) parks every hypothesis that needs
+    // more than `tier` sweeps; tier 2 resumes the parked ones with 12 waves each (one workgroup per CU: latency).  Which tier a
+    // hypothesis ends in depends on its own sweep count only, so results do not depend on the batch.  tier = 0: single launch.
+    int* pending = (int*)(base + ws.off_pending);
+    unsigned long long* state = (unsigned long long*)(base + ws.off_state);
+    const int tier = (int)di2p_opt(DI2P_OPT_SOLVER_TIER_SWEEPS);
+#define DI2P_LAUNCH_SOLVE(NPV, MW, WP, PEND, BUDGET, RESUME) hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP>), grid, dim3(WP * 64), 0, st, packed, boxes, ws.NCMAX, nocull, counts, K, init_y, init_T, yaw0, H, W, b, max_iter, F, R, N, params, cost, iters, sweeps, g_prof, state, PEND, BUDGET, RESUME)
+    int* pend1 = tier > 0 ? pending : nullptr;
     if (is_2d) {
         switch (cfg) {
-            case 42: DI2P_LAUNCH_SOLVE(4, 2, 4); break;
-            case 44: DI2P_LAUNCH_SOLVE(4, 4, 4); break;
-            case 23: DI2P_LAUNCH_SOLVE(4, 3, 2); break;
-            case 24: DI2P_LAUNCH_SOLVE(4, 4, 2); break;
-            case 82: DI2P_LAUNCH_SOLVE(4, 2, 8); break;
-            default: DI2P_LAUNCH_SOLVE(4, 3, 4); break;
+            case 42: DI2P_LAUNCH_SOLVE(4, 2, 4, pend1, tier, 0); break;
+            case 82: DI2P_LAUNCH_SOLVE(4, 2, 8, pend1, tier, 0); break;
+            default: DI2P_LAUNCH_SOLVE(4, 3, 4, pend1, tier, 0); break;
+        }
+        if (tier > 0) {
+            if (cfg % 100 / 10 == 8 && cfg >= 100) DI2P_LAUNCH_SOLVE(4, 2, 8, pending, 0, 1);      // cfg 18x: 8-wave tail (experiments)
+            else DI2P_LAUNCH_SOLVE(4, 3, 12, pending, 0, 1);
         }
     } else {
-        DI2P_LAUNCH_SOLVE(6, 2, 4);
+        DI2P_LAUNCH_SOLVE(6, 2, 4, pend1, tier, 0);
+        if (tier > 0) DI2P_LAUNCH_SOLVE(6, 2, 8, pending, 0, 1);
     }
 #undef DI2P_LAUNCH_SOLVE
     return 0;
@@ -1308,9 +1452,9 @@ extern "C" int di2p_solver_residuals(const double* points, const int32_t* labels
     DI2P_RETURN_LAUNCH();
 }
 
-extern "C" long long di2p_solve_workspace_bytes(int F, int N) {
-    if (F < 0 || N < 0) return 0;
-    return (long long)solve_ws_layout(F, N).bytes;
+extern "C" long long di2p_solve_workspace_bytes(int F, int R, int N) {
+    if (F < 0 || N < 0 || R < 0) return 0;
+    return (long long)solve_ws_layout(F, R, N).bytes;
 }
 
 // Diagnostics: when set to a device buffer of F*R*8 int64, every solve launch records per hypothesis the shader-clock

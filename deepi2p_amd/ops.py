@@ -312,7 +312,7 @@ def solve_batched(points, labels, K, init_y, init_T, H, W, lb, ub, max_iter, is_
     name = "di2p_solve_batched" if points.dtype == _f64 else "di2p_solve_batched_f32"
     if points.dtype not in (_f64, _f32):
         raise RuntimeError("points must be float64 or float32")
-    ws = torch.empty((_lib.load().di2p_solve_workspace_bytes(F, N),), dtype=torch.uint8, device=points.device)
+    ws = torch.empty((_lib.load().di2p_solve_workspace_bytes(F, R, N),), dtype=torch.uint8, device=points.device)
     call(name, ptr(points), ptr(labels), ptr(K), ptr(init_y), ptr(init_T), ptr(yaw0), float(H), float(W), _dbl3(lb),
          _dbl3(ub), int(max_iter), int(bool(is_2d)), F, R, N, ptr(params), ptr(cost), ptr(iters), ptr(sweeps), ptr(ws), stream())
     return params, cost, iters

@@ -24,7 +24,7 @@ extern "C" {
 const char* di2p_last_error(void);
 int di2p_version(void);
 /* Tuning / test knobs, cached in the library (initialised once from the environment variable DI2P_<NAME>): "conv_nosplit",
- * "conv_split_blocks", "conv_novec", "conv_cfg", "pw_novec", "solver_cfg", "solver_nocull", "solver_tier_sweeps".
+ * "conv_split_blocks", "conv_novec", "conv_cfg", "pw_novec", "solver_cfg", "solver_nocull", "solver_noprefilter", "solver_tier_sweeps".
  * set: 0, or -1 for an unknown name; get: the value, or -1 for an unknown name. */
 int di2p_set_option(const char* name, long long value);
 long long di2p_get_option(const char* name);
@@ -194,7 +194,8 @@ int di2p_channel_max(const float* x, float* y, int B, int C, int N, void* stream
  *   init_T f64[F,R,3], lb/ub f64[3] HOST arrays, is_2d: 4 params [ry,tx,ty,tz] else 6
  *   [angle-axis, t].  Outputs: params f64[F,R,np], cost f64[F,R], iters i32[F,R], sweeps i32[F,R] (optional).
  *   If yaw0 != NULL it is added to init_y per frame (restart noise drawn before yaw0 is known).
- *   workspace: di2p_solve_workspace_bytes(F, N) bytes of scratch (sorted point records, cluster boxes, sort keys).
+ *   workspace: di2p_solve_workspace_bytes(F, R, N) bytes of scratch (sorted point records, cluster boxes, sort keys,
+ *   parked Levenberg-Marquardt states of the two-tier launch).
  * di2p_select_best: argmin cost over R per frame (ties -> lowest r; frames with has_inside==0 get
  *   identity and cost 1e4, registration_lsq.py:329-332) -> best i32[F], P f64[F,4,4], cost f64[F].
  * di2p_solver_residuals: Problem::Evaluate of registration.cpp:150-155 at given params:
@@ -214,7 +215,7 @@ int di2p_solve_batched_f32(const float* points, const int32_t* labels, const dou
                            double H, double W, const double* lb_host, const double* ub_host,
                            int max_iter, int is_2d, int F, int R, int N,
                            double* params, double* cost, int32_t* iters, int32_t* sweeps /* may be NULL: #passes over the points */, void* workspace, void* stream);
-long long di2p_solve_workspace_bytes(int F, int N);
+long long di2p_solve_workspace_bytes(int F, int R, int N);
 /* diagnostics only: device buffer of F*R*8 int64 (or NULL) receiving per-hypothesis phase cycle counts and cluster statistics */
 void di2p_solver_set_profile_buffer(void* buf);
 int di2p_select_best(const double* params, const double* cost, const int32_t* has_inside, int is_2d,

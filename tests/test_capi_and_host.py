@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTS) == names
     l = _lib.load()
     assert l.di2p_version() >= 1 and l.di2p_last_error() == b"ok"
-    assert l.di2p_solve_workspace_bytes(32, 20480) >= 32 * 20480 * 32
+    assert l.di2p_solve_workspace_bytes(32, 60, 20480) >= 32 * 20480 * 32
 
 
 def test_argument_errors_are_reported_not_crashed():

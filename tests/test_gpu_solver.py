@@ -125,6 +125,14 @@ def test_cluster_culling_is_exact(dev, is_2d, use_f32):
         b = run()
     for u, v in zip(a, b):
         assert u.tobytes() == v.tobytes()        # bit-identical, NaN-safe
+    # the fp32 pre-filter of the per-point classification certifies or defers to the exact test: same bits without it,
+    # also with every cluster forced through the per-point path (the planted on-plane points must all be deferred)
+    with _lib.option("solver_noprefilter", 1):
+        c = run()
+        with _lib.option("solver_nocull", 1):
+            d = run()
+    for u, v, w in zip(a, c, d):
+        assert u.tobytes() == v.tobytes() == w.tobytes()
     assert np.isfinite(a[1]).sum() >= R - 4      # the planted on-plane points may fail hypotheses 0/1 only
 
 

@@ -42,13 +42,20 @@ for name, lab_np in (("noisy-gt", np.stack([f["labels"] for f in frames])),):
         tot = p[:, :3].sum(1)
         print("  per-sweep cycles (mean over hyps): sweep %.0f  barrier-wait %.0f  LM %.0f ; active evals/sweep (wave0) %.1f of %d records/wave"
               % ((p[:, 0] / sw).mean(), (p[:, 1] / sw).mean(), (p[:, 2] / sw).mean(), (p[:, 3] / sw).mean(), kept / 4))
-        print("  clusters per sweep (wave 0): tested %.1f  per-point %.1f  all-active %.1f" % ((p[:, 6] / sw).mean(), (p[:, 4] / sw).mean(), (p[:, 5] / sw).mean()))
+        print("  clusters per sweep (wave 0): per-point %.1f  all-active %.1f ; partial-combine cycles per sweep %.0f (part of LM)" % ((p[:, 4] / sw).mean(), (p[:, 5] / sw).mean(), (p[:, 6] / sw).mean()))
+        print("  sweeps per hypothesis: percentiles 50/75/90/95/99/100 = %s" % np.percentile(sw, [50, 75, 90, 95, 99, 100]).round(0).tolist())
         q = prof.cpu().numpy().reshape(-1, 8)[:, 7]
         print("  line search: extra trials %.1f / hyp, of which accepted %.1f, re-sweeps %.1f (iterations %.1f, sweeps %.1f)" % (
             (q & 0xfffff).mean(), ((q >> 20) & 0xfffff).mean(), (q >> 40).mean(), iters.float().mean().item(), sw.mean()))
         i = int(np.argmax(sw))
         print("  slowest hyp: sweeps %d cycles total %.3g (sweep %.3g wait %.3g lm %.3g) active/sweep %.1f" % (sw[i], tot[i], p[i, 0], p[i, 1], p[i, 2], p[i, 3] / sw[i]))
         print("  sum over hyps of block cycles %.3g ; max %.3g" % (tot.sum(), tot.max()))
+    for tier in [int(t) for t in os.environ.get("TIERS", "").split(",") if t]:
+        with _lib.option("solver_tier_sweeps", tier):
+            dtt, (p2, c2, i2) = timed()
+        same = torch.equal(c2, cost)
+        print("  two-tier launch, park after %d sweeps: %.2f ms (costs bit-identical to the single launch: %s; max rel diff %.2e)" % (
+            tier, dtt * 1e3, same, float(((c2 - cost).abs() / cost.abs().clamp(min=1e-30)).max())))
     print("%s CFG=%s: %.2f ms  iters mean %.1f max %d  sweeps mean %.1f max %d  kept pts %.0f  -> %.1f us/sweep/hyp-wave" % (
         name, os.environ.get("DI2P_SOLVER_CFG", "43"), dt * 1e3, iters.float().mean().item(), iters.max().item(),
         sweeps.float().mean().item(), sweeps.max().item(), kept, dt * 1e6 / max(sweeps.float().mean().item(), 1)))

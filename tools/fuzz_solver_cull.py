@@ -31,7 +31,7 @@ for it in range(cases):
         p, c, i = ops.solve_batched(*args, sweeps=sw)
         return [t.cpu().numpy().tobytes() for t in (p, c, i, sw)]
     a = run()
-    with _lib.option("solver_nocull", 1):
+    with _lib.option("solver_nocull", 1), _lib.option("solver_noprefilter", 1):
         b = run()
     if a != b:
         bad += 1
