@@ -105,7 +105,8 @@ template <> struct __attribute__((aligned(16))) Rec<double> { double x, y, z; lo
 // The solver's sweeps test each box against the five planes of the camera frustum of the current iterate and
 // classify the points of a cluster individually only when the box touches a plane (see sweep_clusters).
 constexpr int CL = 64;
-struct __attribute__((aligned(16))) Box { double cx, cy, cz, hx, hy, hz; };   // axis-aligned bounds of a cluster (centre, half extents)
+// axis-aligned bounds of a cluster (centre, half extents) in fp32, rounded OUTWARD: the fp32 box contains every point of the cluster
+struct __attribute__((aligned(16))) Box { float cx, cy, cz, hx, hy, hz, pad0, pad1; };
 
 __device__ __forceinline__ unsigned spread10(unsigned v) {
     v &= 0x3ffu;
@@ -245,11 +246,19 @@ __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ po
         const bool nan_any = __any(valid && !(x == x && y == y && z == z)) != 0;
         if (lane == 0) {
             Box bx;
-            bx.cx = 0.5 * (lo[0] + hi[0]); bx.cy = 0.5 * (lo[1] + hi[1]); bx.cz = 0.5 * (lo[2] + hi[2]);
-            const double grow = 1.0 + 1e-12;     // the rounded centre +- half extent must still contain lo and hi
-            bx.hx = nan_any ? __builtin_nan("") : 0.5 * (hi[0] - lo[0]) * grow + 1e-300;
-            bx.hy = 0.5 * (hi[1] - lo[1]) * grow + 1e-300;
-            bx.hz = 0.5 * (hi[2] - lo[2]) * grow + 1e-300;
+            float* bc = &bx.cx;
+            float* bh = &bx.hx;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double cd = 0.5 * (lo[a] + hi[a]);
+                const float cf = (float)cd;
+                // half extent measured from the ROUNDED centre, grown by 1e-6 (>> 2^-24): centre +- half extent contains lo and hi
+                const double hd = fmax(hi[a] - (double)cf, (double)cf - lo[a]);
+                bc[a] = cf;
+                bh[a] = (float)(hd * (1.0 + 1e-6)) + 1e-30f;
+            }
+            if (nan_any) bx.hx = __builtin_nanf("");
+            bx.pad0 = bx.pad1 = 0.0f;
             boxes[c] = bx;
         }
     }
@@ -410,55 +419,71 @@ __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& ro
 //   p2 > 0     <=> f_Z = p2 > 0.
 struct Planes { double nL, nR, nT, nB; };
 
-// Cluster test.  The axis-aligned box (centre c, half extents h) of a cluster, moved by the iterate (R, t), lies
-// strictly on one side of plane i iff |f_i(Rc + t)| > sum_j |(n_i^T R)_j| h_j + delta*|n_i|  (support function of the
-// rotated box).  If that holds for ALL five planes, every point of the cluster has the sign pattern of the centre,
-// none of dx, dy, p2 is zero or non-finite, and the per-point classification of phase A is known without evaluating it:
+// Cluster test, in fp32 with conservative margins.  The axis-aligned box (centre c, half extents h) of a cluster, moved by
+// the iterate (R, t), lies strictly on one side of plane i iff |f_i(Rc + t)| > sum_j |(n_i^T R)_j| h_j  (support function of
+// the rotated box).  The fp32 evaluation decides only when it clears that bound by
+//     1e-5 * support + 4e-6 * |n_i|_1 * (|c|_1 + |h|_1 + |t|_1)
+// (>= 8x the worst-case rounding of the fp32 evaluation, see the pre-filter below); anything closer is "undecided" and goes
+// to the per-point path, which is always right.  If ALL five planes are decided, every point of the cluster has the sign
+// pattern of the centre, none of dx, dy, p2 is zero or non-finite, and the per-point classification is known:
 //   label 1: inactive iff all five are positive, else every point is active;
 //   label 0: active   iff all five are positive, else every point is inactive (and cannot raise `bad`).
-// delta = 1e-9*(1+|p|) exceeds the rounding error of the per-point pixel test (~1e-13 of the same scale) by four
-// orders of magnitude, so the shortcut never disagrees with the exact test; NaN/inf anywhere fails every
-// comparison and falls back to the per-point path.
+// NaN/inf anywhere fails every comparison and falls back to the per-point path.
 // Returns 0: skip, 1: classify per point, 2: all active.
+struct BoxTest {           // per sweep: |n_i^T R|_j * (1 + 1e-5) and the margin factors (wave-uniform)
+    float R[9], t[3], T1;
+    float aL[3], aR[3], aT[3], aB[3], aZ[3];
+    float fx, cx, wcx, fy, cy, hcy, mL, mR, mT, mB, mZ;
+};
+template <int NP>
+__device__ __forceinline__ void make_box_test(const Rot<NP>& rot, double tx, double ty, double tz, const Cam& k, BoxTest& q) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) q.R[i] = (float)rot.R[i];
+    q.t[0] = (float)tx; q.t[1] = (float)ty; q.t[2] = (float)tz;
+    q.T1 = fabsf(q.t[0]) + fabsf(q.t[1]) + fabsf(q.t[2]);
+    q.fx = (float)k.fx; q.cx = (float)k.cx; q.wcx = (float)(k.W1 - k.cx);
+    q.fy = (float)k.fy; q.cy = (float)k.cy; q.hcy = (float)(k.H1 - k.cy);
+    const float g = 1.0f + 1e-5f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {      // (n^T R)_j = a R0j + b R1j + c R2j
+        q.aL[j] = fabsf(q.fx * q.R[j] + q.cx * q.R[6 + j]) * g;
+        q.aR[j] = fabsf(-q.fx * q.R[j] + q.wcx * q.R[6 + j]) * g;
+        q.aT[j] = fabsf(q.fy * q.R[3 + j] + q.cy * q.R[6 + j]) * g;
+        q.aB[j] = fabsf(-q.fy * q.R[3 + j] + q.hcy * q.R[6 + j]) * g;
+        q.aZ[j] = fabsf(q.R[6 + j]) * g;
+    }
+    const float rel = 4e-6f;
+    q.mL = rel * (fabsf(q.fx) + fabsf(q.cx)); q.mR = rel * (fabsf(q.fx) + fabsf(q.wcx));
+    q.mT = rel * (fabsf(q.fy) + fabsf(q.cy)); q.mB = rel * (fabsf(q.fy) + fabsf(q.hcy));
+    q.mZ = rel;
+}
 template <int NP, int LAB>
-__device__ __forceinline__ int cluster_status(const Box& bx, const Rot<NP>& rot, double tx, double ty, double tz, const Cam& k,
-                                              const Planes& pl) {
-    const double* R = rot.R;
-    double p0, p1, p2;
+__device__ __forceinline__ int cluster_status(const Box& bx, const BoxTest& q) {
+    const float S = ((fabsf(bx.cx) + fabsf(bx.cy)) + (fabsf(bx.cz) + q.T1)) + ((bx.hx + bx.hy) + bx.hz);
+    float p0, p1, p2;
     if (NP == 4) {
-        p0 = R[0] * bx.cx + R[2] * bx.cz + tx; p1 = bx.cy + ty; p2 = R[6] * bx.cx + R[8] * bx.cz + tz;
+        p0 = fmaf(q.R[0], bx.cx, fmaf(q.R[2], bx.cz, q.t[0])); p1 = bx.cy + q.t[1]; p2 = fmaf(q.R[6], bx.cx, fmaf(q.R[8], bx.cz, q.t[2]));
     } else {
-        p0 = R[0] * bx.cx + R[1] * bx.cy + R[2] * bx.cz + tx;
-        p1 = R[3] * bx.cx + R[4] * bx.cy + R[5] * bx.cz + ty;
-        p2 = R[6] * bx.cx + R[7] * bx.cy + R[8] * bx.cz + tz;
+        p0 = fmaf(q.R[0], bx.cx, fmaf(q.R[1], bx.cy, fmaf(q.R[2], bx.cz, q.t[0])));
+        p1 = fmaf(q.R[3], bx.cx, fmaf(q.R[4], bx.cy, fmaf(q.R[5], bx.cz, q.t[1])));
+        p2 = fmaf(q.R[6], bx.cx, fmaf(q.R[7], bx.cy, fmaf(q.R[8], bx.cz, q.t[2])));
     }
-    const double delta = 1e-9 * (1.0 + fabs(p0) + fabs(p1) + fabs(p2));
-    // plane normals n = a*e0 + b*e1 + c*e2 in camera coordinates -> world components (n^T R)_j = a R0j + b R1j + c R2j
-    auto support = [&](double a, double b, double c, double nrm) {
-        double sj;
-        if (NP == 4) {      // R = [[c,0,s],[0,1,0],[-s,0,c]]
-            sj = fabs(a * R[0] + c * R[6]) * bx.hx + fabs(b) * bx.hy + fabs(a * R[2] + c * R[8]) * bx.hz;
-        } else {
-            sj = fabs(a * R[0] + b * R[3] + c * R[6]) * bx.hx + fabs(a * R[1] + b * R[4] + c * R[7]) * bx.hy +
-                 fabs(a * R[2] + b * R[5] + c * R[8]) * bx.hz;
-        }
-        return sj + delta * nrm;
-    };
-    const double fL = k.fx * p0 + k.cx * p2, fR = -k.fx * p0 + (k.W1 - k.cx) * p2;
-    const double fT = k.fy * p1 + k.cy * p2, fB = -k.fy * p1 + (k.H1 - k.cy) * p2;
-    const double tL = support(k.fx, 0.0, k.cx, pl.nL), tR = support(-k.fx, 0.0, k.W1 - k.cx, pl.nR);
-    const double tT = support(0.0, k.fy, k.cy, pl.nT), tB = support(0.0, -k.fy, k.H1 - k.cy, pl.nB);
-    const double tZ = support(0.0, 0.0, 1.0, 1.0);
-    const bool pL = fL > tL, pR = fR > tR, pT = fT > tT, pB = fB > tB, pZ = p2 > tZ;
-    const bool cL = pL || fL < -tL, cR = pR || fR < -tR, cT = pT || fT < -tT, cB = pB || fB < -tB, cZ = pZ || p2 < -tZ;
-    if (cL && cR && cT && cB && cZ) {
-        const bool inside = pL && pR && pT && pB && pZ;
-        return (LAB == 1) ? (inside ? 0 : 2) : (inside ? 2 : 0);
-    }
-    // a certified negative plane already decides every point: not inside.  Label 1: all active.  Label-0 points of such a
-    // cluster may still sit exactly on one of the touched planes (dx, dy or p2 == 0 is an evaluation failure in the
+    const float fL = fmaf(q.fx, p0, q.cx * p2), fR = fmaf(-q.fx, p0, q.wcx * p2);
+    const float fT = fmaf(q.fy, p1, q.cy * p2), fB = fmaf(-q.fy, p1, q.hcy * p2);
+    auto bound = [&](const float* a, float m) { return fmaf(a[0], bx.hx, fmaf(a[1], bx.hy, fmaf(a[2], bx.hz, m * S))); };
+    const float tL = bound(q.aL, q.mL), tR = bound(q.aR, q.mR), tT = bound(q.aT, q.mT), tB = bound(q.aB, q.mB), tZ = bound(q.aZ, q.mZ);
+    // all five decided positive <=> min_i (f_i - t_i) > 0 ; all five decided <=> min_i (|f_i| - t_i) > 0
+    const float lo = fminf(fminf(fminf(fL - tL, fR - tR), fminf(fT - tT, fB - tB)), p2 - tZ);
+    const float cm = fminf(fminf(fminf(fabsf(fL) - tL, fabsf(fR) - tR), fminf(fabsf(fT) - tT, fabsf(fB) - tB)), fabsf(p2) - tZ);
+    const bool inside = lo > 0.0f;
+    if (cm > 0.0f) return (LAB == 1) ? (inside ? 0 : 2) : (inside ? 2 : 0);
+    // a decided-negative plane already decides every point: not inside.  Label 1: all active.  Label-0 points of such a
+    // cluster may still sit exactly on one of the undecided planes (dx, dy or p2 == 0 is an evaluation failure in the
     // reference), so label 0 keeps the per-point path.
-    if (LAB == 1 && ((cL && !pL) || (cR && !pR) || (cT && !pT) || (cB && !pB) || (cZ && !pZ))) return 2;
+    if (LAB == 1) {
+        const float hi = fminf(fminf(fminf(fL + tL, fR + tR), fminf(fT + tT, fB + tB)), p2 + tZ);
+        if (hi < 0.0f) return 2;
+    }
     return 1;
 }
 
@@ -588,6 +613,8 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
     nocull &= 1;
     Pre32 pre;
     make_pre32<NP>(rot, tx, ty, tz, k, pre);
+    BoxTest btest;
+    make_box_test<NP>(rot, tx, ty, tz, k, btest);
     // phase A of one flagged cluster: classify its 64 records (status 1) or take them all (status 2), append the active ids
     auto classify = [&](int c, bool isA, const Rec<PT>& rec) {
         const bool valid = c * CL + lane < cnt;                                     // padding lanes of a partial cluster
@@ -609,7 +636,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
     for (int j0 = 0; j0 < mine; j0 += 64) {
         const int j = j0 + lane;
         int status = 0;
-        if (j < mine) status = nocull ? 1 : cluster_status<NP, LAB>(boxes[j * WPH + wave], rot, tx, ty, tz, k, pl);
+        if (j < mine) status = nocull ? 1 : cluster_status<NP, LAB>(boxes[j * WPH + wave], btest);
         const unsigned long long mA = __ballot(status == 1), mB = __ballot(status == 2);
         n_active[1] += __popcll(mA); n_active[2] += __popcll(mB); n_active[3] += min(mine - j0, 64);
         // The flagged clusters are walked in index order with PF records in flight (a cluster's 64 records are one 16-byte load
@@ -675,7 +702,43 @@ __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Bo
         for (int i = 0; i < Tri<NP>::N; ++i) if (!isfinite(lA[i])) bad = true;
     }
     double* mine = sh.red[wave];
-    double v = wave_sum(0.5 * cost.log_value());
+    const bool anybad = __any(bad) != 0;        // evaluated by the whole wave (a ballot inside `if (lane == 0)` sees lane 0 only)
+    // Wave reduction of NV - 1 values per lane.  Butterfly with value halving: at step k a lane keeps the values whose index
+    // has bit k equal to its own lane bit k, sends the other half to lane ^ (1 << k) and adds what it receives, so the number
+    // of live values halves per step (16 -> 8 -> 4 -> 2 -> 1, then plain butterflies): ~2x(NV-1) exchanges instead of
+    // 6x(NV-1).  The pairing, hence the summation order, is fixed: deterministic and identical on every path.
+    double vals[16];
+    vals[0] = 0.5 * cost.log_value();
+#pragma unroll
+    for (int i = 0; i < NP; ++i) vals[1 + i] = lg[i];
+#pragma unroll
+    for (int i = 0; i < Tri<NP>::N; ++i) vals[1 + NP + i] = lA[i];
+    static_assert(1 + NP + Tri<NP>::N <= 16 || NP == 6, "value count");
+    if (NP == 4) {
+#pragma unroll
+        for (int i = 1 + NP + Tri<NP>::N; i < 16; ++i) vals[i] = 0.0;
+        int nlive = 16;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool up = (lane >> k) & 1;
+            nlive >>= 1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < nlive) {
+                    const double keep = up ? vals[2 * i + 1] : vals[2 * i];
+                    const double send = up ? vals[2 * i] : vals[2 * i + 1];
+                    vals[i] = keep + __shfl_xor(send, 1 << k);
+                }
+        }
+        double r = vals[0];
+        r += __shfl_xor(r, 16);
+        r += __shfl_xor(r, 32);
+        // step k consumed bit k of the value index together with lane bit k: lane l < 16 now holds the wave total of value l
+        if (lane < 1 + NP + Tri<NP>::N) mine[lane] = r;
+        if (lane == 0) mine[NV - 1] = anybad ? 1.0 : 0.0;
+        return;
+    }
+    double v = wave_sum(vals[0]);
     if (lane == 0) mine[0] = v;
     if (MODE >= 1) {
 #pragma unroll
@@ -685,7 +748,7 @@ __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Bo
 #pragma unroll
         for (int i = 0; i < Tri<NP>::N; ++i) { v = wave_sum(lA[i]); if (lane == 0) mine[1 + NP + i] = v; }
     }
-    if (lane == 0) mine[NV - 1] = (__any(bad) != 0) ? 1.0 : 0.0;
+    if (lane == 0) mine[NV - 1] = anybad ? 1.0 : 0.0;
 }
 
 template <int NP>
