@@ -821,32 +821,45 @@ template <int DEG> __device__ __forceinline__ double poly_eval(const double* c, 
     return v;
 }
 
+// ---- real critical points by the WHOLE wavefront (wave 0 runs this between sweeps; arguments are wave-uniform).
+// Same statement as the oracle's real_roots_in(): the roots of q inside [a,b] are isolated between consecutive roots of q'
+// (found the same way one degree down; degree 2 in closed form, as polynomial.cc's FindQuadraticPolynomialRoots), q is
+// monotone on each piece, so a sign change pins exactly one root.  The oracle solves a piece by scalar Newton/bisection
+// (~25 dependent fp64 divisions); here the 64 lanes sample the piece at 64 points, a ballot finds the sub-interval with the
+// sign change (three rounds: 63^3 = 2.5e5 x narrower), and three Newton steps with a reciprocal finish it to rounding.
 template <int DEG>
-__device__ __forceinline__ double bracket_root(const double* q, double a, double b, double qa) {
+__device__ __forceinline__ double wave_bracket_root(const double* q, double l, double r, double ql) {
+    const int lane = threadIdx.x & 63;
+    const bool lneg = ql < 0.0;
+#pragma unroll 1
+    for (int round = 0; round < 3; ++round) {
+        const double h = (r - l) * (1.0 / 63.0);
+        const double u = fma((double)lane, h, l);
+        const double v = poly_eval<DEG>(q, u);
+        const unsigned long long same = __ballot(v != 0.0 && (v < 0.0) == lneg);       // monotone piece: a prefix of lanes
+        const unsigned long long zero = __ballot(v == 0.0);
+        if (zero) return fma((double)__builtin_ctzll(zero), h, l);                       // a sample hit the root exactly
+        const int idx = same ? 63 - (int)__builtin_clzll(same) : 0;                      // last lane on the left side
+        l = fma((double)idx, h, l);
+        r = l + h;
+    }
     double dq[DEG];
 #pragma unroll
     for (int i = 1; i <= DEG; ++i) dq[i - 1] = i * q[i];
-    double x = 0.5 * (a + b);
-    for (int it = 0; it < 200; ++it) {
-        const double qx = poly_eval<DEG>(q, x);
-        if (qx == 0.0) return x;
-        if ((qx < 0.0) == (qa < 0.0)) { a = x; qa = qx; } else { b = x; }
-        const double d = poly_eval<DEG - 1>(dq, x);
-        double xn = x - qx / d;
-        if (!(xn > a && xn < b)) xn = 0.5 * (a + b);
-        if (xn == x || b - a <= 4e-16 * fabs(x)) return xn;
-        x = xn;
+    double x = 0.5 * (l + r);
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const double qx = poly_eval<DEG>(q, x), d = poly_eval<DEG - 1>(dq, x);
+        const double xn = fma(-qx, fast_rcp(d), x);
+        x = (xn >= l && xn <= r) ? xn : x;         // NaN / runaway steps keep the bracketed iterate
     }
     return x;
 }
 
-// Real roots of q (degree <= DEG, ascending coefficients) inside [a,b): bracket i lies between the (i-1)-th and i-th
-// critical point of q (roots of q', found the same way one degree down), q is monotone on it, so it holds at most one
-// root -> slot i of (has, val).  Slots are ascending; everything is indexed at compile time (no scratch arrays).
-template <int DEG> struct RealRoots {
+template <int DEG> struct WaveRoots {
     __device__ __forceinline__ static void run(const double* q, double a, double b, bool* has, double* val) {
         if (q[DEG] == 0.0) {                                   // RemoveLeadingZeros (polynomial.cc)
-            RealRoots<DEG - 1>::run(q, a, b, has, val);
+            WaveRoots<DEG - 1>::run(q, a, b, has, val);
             has[DEG - 1] = false;
             return;
         }
@@ -854,23 +867,43 @@ template <int DEG> struct RealRoots {
         bool hc[DEG - 1];
 #pragma unroll
         for (int i = 1; i <= DEG; ++i) dq[i - 1] = i * q[i];
-        RealRoots<DEG - 1>::run(dq, a, b, hc, vc);
+        WaveRoots<DEG - 1>::run(dq, a, b, hc, vc);
         double l = a, ql = poly_eval<DEG>(q, a);
 #pragma unroll
         for (int i = 0; i < DEG; ++i) {
             has[i] = false;
             const bool last = i == DEG - 1;
-            if (last || hc[last ? 0 : i]) {
+            if (last || hc[last ? 0 : i]) {                    // wave-uniform
                 const double r = last ? b : vc[last ? 0 : i];
                 const double qr = poly_eval<DEG>(q, r);
                 if (ql == 0.0) { has[i] = true; val[i] = l; }
-                else if (qr != 0.0 && (ql < 0.0) != (qr < 0.0)) { has[i] = true; val[i] = bracket_root<DEG>(q, l, r, ql); }
+                else if (qr != 0.0 && (ql < 0.0) != (qr < 0.0)) { has[i] = true; val[i] = wave_bracket_root<DEG>(q, l, r, ql); }
                 l = r; ql = qr;
             }
         }
     }
 };
-template <> struct RealRoots<1> {
+template <> struct WaveRoots<2> {      // closed form, the numerically stable pair of FindQuadraticPolynomialRoots; ascending, inside [a,b]
+    __device__ __forceinline__ static void run(const double* q, double a, double b, bool* has, double* val) {
+        has[0] = has[1] = false;
+        if (q[2] == 0.0) {
+            if (q[1] == 0.0) return;
+            const double r = -q[0] / q[1];
+            if (r >= a && r <= b) { has[0] = true; val[0] = r; }
+            return;
+        }
+        const double D = q[1] * q[1] - 4.0 * q[2] * q[0];
+        if (!(D >= 0.0)) return;
+        const double sD = sqrt(D);
+        const double t = q[1] >= 0.0 ? -q[1] - sD : -q[1] + sD;
+        double r0 = t / (2.0 * q[2]), r1 = t != 0.0 ? (2.0 * q[0]) / t : r0;
+        if (r0 > r1) { const double tmp = r0; r0 = r1; r1 = tmp; }
+        if (r0 >= a && r0 <= b) { has[0] = true; val[0] = r0; }
+        if (r1 >= a && r1 <= b && r1 != r0) { has[1] = true; val[1] = r1; }
+        if (!has[0] && has[1]) { has[0] = true; val[0] = val[1]; has[1] = false; }
+    }
+};
+template <> struct WaveRoots<1> {
     __device__ __forceinline__ static void run(const double* q, double a, double b, bool* has, double* val) {
         has[0] = false;
         if (q[1] == 0.0) return;
@@ -879,8 +912,9 @@ template <> struct RealRoots<1> {
     }
 };
 
-// MinimizePolynomial (polynomial.cc): interval midpoint first, then both ends, then the critical points, strict "<"
-__device__ __forceinline__ double poly_min_on(const double* p, double umin, double umax) {     // p: degree <= 5, ascending
+// MinimizePolynomial (polynomial.cc): interval midpoint first, then both ends, then the critical points, strict "<".
+// Called by every lane of wave 0 with the same arguments; returns the same value on every lane.
+__device__ __forceinline__ double poly_min_on_wave(const double* p, double umin, double umax) {     // p: degree <= 5, ascending
     double best_u = 0.5 * (umin + umax), best_v = poly_eval<5>(p, best_u);
     const double vmin = poly_eval<5>(p, umin);
     if (vmin < best_v) { best_v = vmin; best_u = umin; }
@@ -890,7 +924,7 @@ __device__ __forceinline__ double poly_min_on(const double* p, double umin, doub
     bool has[4];
 #pragma unroll
     for (int i = 1; i <= 5; ++i) dp[i - 1] = i * p[i];
-    RealRoots<4>::run(dp, umin, umax, has, val);
+    WaveRoots<4>::run(dp, umin, umax, has, val);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (has[i]) {
@@ -905,9 +939,10 @@ struct LsSample { double x, value, gradient; bool value_ok, grad_ok; };
 // LineSearch::InterpolatingPolynomialMinimizingStepSize, CUBIC: p(u) = f0 + g0 xc u + u^2 (r0 + r1 u + r2 u^2 + r3 u^3) with one
 // coefficient per valid constraint {cur value, cur gradient, prev value, prev gradient}; missing constraints pin the
 // highest coefficients to zero (unit rows), so the 4x4 elimination below always runs on compile-time indices.
-__device__ __forceinline__ double interpolating_step(double f0, double g0, const LsSample& cur, const LsSample& prev, double min_step, double max_step) {
-    const double bis = fmin(fmax(cur.x * 0.5, min_step), max_step);
-    if (!cur.value_ok) return bis;
+// -> true: p[0..5] holds the interpolant in u = step / cur.x, to be minimised over [min_step, max_step] / cur.x ; false: the next
+// step is the bisection step (invalid current sample, or a non-finite fit).
+__device__ __forceinline__ bool interpolating_fit(double f0, double g0, const LsSample& cur, const LsSample& prev, double* p) {
+    if (!cur.value_ok) return false;
     const double xc = cur.x, G0 = g0 * xc;
     const double up = prev.value_ok ? prev.x / xc : 2.0;
     const bool valid[4] = {true, cur.grad_ok, prev.value_ok, prev.value_ok && prev.grad_ok};
@@ -964,12 +999,11 @@ __device__ __forceinline__ double interpolating_step(double f0, double g0, const
             r[c] = v / A[c][c];
         }
     }
-    const double p[6] = {f0, G0, r[0], m > 1 ? r[1] : 0.0, m > 2 ? r[2] : 0.0, m > 3 ? r[3] : 0.0};
+    p[0] = f0; p[1] = G0; p[2] = r[0]; p[3] = m > 1 ? r[1] : 0.0; p[4] = m > 2 ? r[2] : 0.0; p[5] = m > 3 ? r[3] : 0.0;
     bool fin = true;
 #pragma unroll
     for (int j = 0; j < 6; ++j) if (!isfinite(p[j])) fin = false;
-    if (!fin) return bis;
-    return poly_min_on(p, min_step / xc, max_step / xc) * xc;
+    return fin;
 }
 
 struct Bounds { double lb[3], ub[3]; };
@@ -987,6 +1021,8 @@ struct LMState {
     double g1[NP], A1[Tri<NP>::N];     // sums of the FIRST trial point (t = 1): the candidate when the line search fails
     double prev_t, prev_f, prev_g;     // previous line-search sample (step, cost, directional derivative)
     int prev_vok, prev_gok;
+    double poly[6], tn;                // pending interpolant (u = step / t) for the wave-wide minimiser, and the step it returns
+    int poly_req, pad_;
     int n_ls_extra, n_ls_late_accept, n_resweep;      // diagnostics: line-search trials beyond the first, accepted ones among them, re-sweeps
 };
 
@@ -1072,6 +1108,30 @@ __device__ __forceinline__ void lm_finish_iteration(LMState<NP>& st, double cand
     lm_begin_iteration<NP>(st);
 }
 
+// Second half of a failed line-search trial: the next step size is known (or the search gives up).
+template <int NP>
+__device__ __forceinline__ void lm_trial_next(LMState<NP>& st, double tn, bool give_up) {
+    if (!give_up && tn * st.dmax < 1e-9) give_up = true;
+    if (give_up) {   // delta stays unscaled: the candidate is the first trial point, whose sums were kept
+        plus_proj<NP>(st.x, st.delta, 1.0, st.lb, st.ub, st.xe);
+        lm_finish_iteration<NP>(st, st.f1, st.g1, st.A1);
+        return;
+    }
+    st.t = tn;
+    plus_proj<NP>(st.x, st.delta, tn, st.lb, st.ub, st.xe);
+}
+
+// Wave 0, all lanes: minimise the pending interpolant (MinimizePolynomial over u in [1e-3 t, 0.6 t] / t).
+template <int NP>
+__device__ __forceinline__ void lm_poly_wave(LMState<NP>& st) {
+    double p[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) p[j] = st.poly[j];
+    const double t = st.t;
+    const double u = poly_min_on_wave(p, (1e-3 * t) / t, (0.6 * t) / t);
+    if ((threadIdx.x & 63) == 0) st.tn = u * t;
+}
+
 // Called by thread 0 after every sweep with the combined sums of the point just evaluated (st.xe).
 template <int NP>
 __device__ __forceinline__ void lm_after_sweep(LMState<NP>& st, bool ok, double fe, const double* ge, const double* Ae) {
@@ -1105,28 +1165,25 @@ __device__ __forceinline__ void lm_after_sweep(LMState<NP>& st, bool ok, double 
         lm_finish_iteration<NP>(st, fe, ge, Ae);       // every sweep carries its normal equations: an accepted trial needs no second sweep
         return;
     }
-    bool give_up = ++st.ls_it >= 20;
-    double tn = 0.0;
-    if (!give_up) {
-        LsSample cur{st.t, fe, 0.0, ok, false}, prev{st.prev_t, st.prev_f, st.prev_g, st.prev_vok != 0, st.prev_gok != 0};
-        if (ok) {
-            double gdir = 0.0;
+    if (++st.ls_it >= 20) { lm_trial_next<NP>(st, 0.0, true); return; }
+    LsSample cur{st.t, fe, 0.0, ok, false}, prev{st.prev_t, st.prev_f, st.prev_g, st.prev_vok != 0, st.prev_gok != 0};
+    if (ok) {
+        double gdir = 0.0;
 #pragma unroll
-            for (int a = 0; a < NP; ++a) gdir += st.delta[a] * ge[a];
-            cur.gradient = gdir;
-            cur.grad_ok = isfinite(gdir);
-        }
-        tn = interpolating_step(st.cost, st.gd, cur, prev, 1e-3 * st.t, 0.6 * st.t);
-        if (tn * st.dmax < 1e-9) give_up = true;
-        st.prev_t = cur.x; st.prev_f = cur.value; st.prev_g = cur.gradient; st.prev_vok = cur.value_ok; st.prev_gok = cur.grad_ok;
+        for (int a = 0; a < NP; ++a) gdir += st.delta[a] * ge[a];
+        cur.gradient = gdir;
+        cur.grad_ok = isfinite(gdir);
     }
-    if (give_up) {   // delta stays unscaled: the candidate is the first trial point, whose sums were kept
-        plus_proj<NP>(st.x, st.delta, 1.0, st.lb, st.ub, st.xe);
-        lm_finish_iteration<NP>(st, st.f1, st.g1, st.A1);
+    st.prev_t = cur.x; st.prev_f = cur.value; st.prev_g = cur.gradient; st.prev_vok = cur.value_ok; st.prev_gok = cur.grad_ok;
+    double p[6];
+    if (interpolating_fit(st.cost, st.gd, cur, prev, p)) {
+        // the minimiser of the interpolant over [1e-3, 0.6] x t is found by the whole wavefront (lm_poly_wave), then lm_trial_next
+#pragma unroll
+        for (int j = 0; j < 6; ++j) st.poly[j] = p[j];
+        st.poly_req = 1;
         return;
     }
-    st.t = tn;
-    plus_proj<NP>(st.x, st.delta, tn, st.lb, st.ub, st.xe);
+    lm_trial_next<NP>(st, fmin(fmax(st.t * 0.5, 1e-3 * st.t), 0.6 * st.t), false);
 }
 
 template <int NP, typename PT, int MINW, int WPH>
@@ -1173,7 +1230,7 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
         for (int i = 0; i < NP; ++i) { st.x[i] = fmin(fmax(st.x[i], st.lb[i]), st.ub[i]); st.xe[i] = st.x[i]; }
         st.radius = 1e4; st.decrease = 2.0; st.reuse_diag = 0; st.invalid_run = 0; st.iter = 0; st.nsweep = 0;
         st.phase = PH_INIT; st.done = 0; st.max_iter = max_iter; st.cost = 0.0; st.gmax = 0.0;
-        st.n_ls_extra = 0; st.n_ls_late_accept = 0; st.n_resweep = 0; st.want_j = 2;
+        st.n_ls_extra = 0; st.n_ls_late_accept = 0; st.n_resweep = 0; st.want_j = 2; st.poly_req = 0;
     }
     __syncthreads();
     long long c_sweep = 0, c_wait = 0, c_lm = 0, c_comb = 0;
@@ -1198,6 +1255,14 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
         if (threadIdx.x == 0) {
             const bool ok = sh.comb[NV - 1] == 0.0 && isfinite(sh.comb[0]);
             lm_after_sweep<NP>(st, ok, sh.comb[0], sh.comb + 1, sh.comb + 1 + NP);
+        }
+        if (threadIdx.x < 64) {                 // wave 0: a failed trial left an interpolant to minimise (wave-uniform branch)
+            __builtin_amdgcn_wave_barrier();
+            if (st.poly_req) {
+                lm_poly_wave<NP>(st);
+                __builtin_amdgcn_wave_barrier();
+                if (threadIdx.x == 0) { st.poly_req = 0; lm_trial_next<NP>(st, st.tn, false); }
+            }
         }
         const long long t3 = prof ? clock64() : 0;
         c_comb += t2b - t2;

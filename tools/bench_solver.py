@@ -47,6 +47,9 @@ for name, lab_np in (("noisy-gt", np.stack([f["labels"] for f in frames])),):
         q = prof.cpu().numpy().reshape(-1, 8)[:, 7]
         print("  line search: extra trials %.1f / hyp, of which accepted %.1f, re-sweeps %.1f (iterations %.1f, sweeps %.1f)" % (
             (q & 0xfffff).mean(), ((q >> 20) & 0xfffff).mean(), (q >> 40).mean(), iters.float().mean().item(), sw.mean()))
+        X = np.stack([iters.cpu().numpy().reshape(-1).astype(float), (q & 0xfffff).astype(float), np.ones(sw.size)], axis=1)
+        coef = np.linalg.lstsq(X, p[:, 2], rcond=None)[0]
+        print("  LM cycles per hypothesis ~ %.0f x iterations + %.0f x extra line-search trials + %.0f" % tuple(coef))
         i = int(np.argmax(sw))
         print("  slowest hyp: sweeps %d cycles total %.3g (sweep %.3g wait %.3g lm %.3g) active/sweep %.1f" % (sw[i], tot[i], p[i, 0], p[i, 1], p[i, 2], p[i, 3] / sw[i]))
         print("  sum over hyps of block cycles %.3g ; max %.3g" % (tot.sum(), tot.max()))
