@@ -153,6 +153,21 @@ struct LoaderIm2colTap4 {
         if (STRIDE == 1) { const F4u t = *reinterpret_cast<const F4u*>(r); return make_float4(t.x, t.y, t.z, t.w); }
         return make_float4(r[c0], r[c1], r[c2], r[c3]);
     }
+    struct Info { int shift; unsigned okmask; };
+    __device__ __forceinline__ Info info() const { return Info{shift, okmask}; }
+    __device__ __forceinline__ void fix(float4& v, int, const Info& in) const {
+        if (STRIDE == 1) {
+            const float4 t = v;
+            const bool l = in.shift < 0, r = in.shift > 0, ok = in.okmask != 0;
+            v.x = !ok || l ? 0.0f : (r ? t.y : t.x);
+            v.y = !ok ? 0.0f : (l ? t.x : (r ? t.z : t.y));
+            v.z = !ok ? 0.0f : (l ? t.y : (r ? t.w : t.z));
+            v.w = !ok || r ? 0.0f : (l ? t.z : t.w);
+        } else {
+            v.x = (in.okmask & 1u) ? v.x : 0.0f; v.y = (in.okmask & 2u) ? v.y : 0.0f;
+            v.z = (in.okmask & 4u) ? v.z : 0.0f; v.w = (in.okmask & 8u) ? v.w : 0.0f;
+        }
+    }
     __device__ __forceinline__ void fix(float4& v, int) const {
         if (STRIDE == 1) {
             const float4 t = v;
@@ -329,7 +344,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
     *reinterpret_cast<float4*>(y + i4) = v;
 }
 
-template <class Cfg, int STRIDE>
+template <class Cfg, int STRIDE, int DEPTH = 1>
 __global__ __launch_bounds__(Cfg::THREADS) void conv2d_vec_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    const float* __restrict__ residual, float* __restrict__ y, int Cin,
@@ -345,13 +360,15 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv2d_vec_kernel(const float* _
     conv_tile(tx, ty, (long long)K * Cout * 4);
     if (splits <= 1) {
         EpiConv ep{scale, shift, residual, y, Cout, OH * OW, Ntot, relu};
-        mfma_gemm_block_vec<Cfg>(lds, la, lb, ep, K, ty * Cfg::BM, tx * Cfg::BN);
+        if (DEPTH == 2) mfma_gemm_block_vec2<Cfg>(lds, la, lb, ep, K, ty * Cfg::BM, tx * Cfg::BN);
+        else mfma_gemm_block_vec<Cfg>(lds, la, lb, ep, K, ty * Cfg::BM, tx * Cfg::BN);
     } else {      // K-slice blockIdx.z: raw partial sums, combined by conv_splitk_reduce_kernel
         const int T = K / Cfg::BK, z = blockIdx.z;
         const int t0 = (int)((long long)T * z / splits), t1 = (int)((long long)T * (z + 1) / splits);
         EpiPartial ep{part + (long long)z * Cout * Ntot, Cout, OH * OW, Ntot};
         lb.pending_seek = t0;
-        mfma_gemm_block_vec<Cfg>(lds, la, lb, ep, K, ty * Cfg::BM, tx * Cfg::BN, t0, t1);
+        if (DEPTH == 2) mfma_gemm_block_vec2<Cfg>(lds, la, lb, ep, K, ty * Cfg::BM, tx * Cfg::BN, t0, t1);
+        else mfma_gemm_block_vec<Cfg>(lds, la, lb, ep, K, ty * Cfg::BM, tx * Cfg::BN, t0, t1);
     }
 }
 
@@ -378,12 +395,13 @@ void launch_conv_vec(const float* x, const float* Wt, const float* scale, const 
                      float* part, int splits, hipStream_t st) {
     const dim3 grid(di2p_cdiv(Ntot, Cfg::BN), di2p_cdiv(Cout, Cfg::BM), splits), block(Cfg::THREADS);
     const size_t lds = Cfg::LDS_FLOATS * sizeof(float);
-    if (stride == 1)
-        hipLaunchKernelGGL((conv2d_vec_kernel<Cfg, 1>), grid, block, lds, st, x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW,
-                           KH, KW, pad, Ntot, relu, part, splits);
-    else
-        hipLaunchKernelGGL((conv2d_vec_kernel<Cfg, 2>), grid, block, lds, st, x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW,
-                           KH, KW, pad, Ntot, relu, part, splits);
+    // depth-2 register prefetch (bit-identical results; +1..10 % per layer, most on the stride-2 layers); conv_depth1 = 1 selects
+    // the depth-1 engine (tests compare the two)
+    const bool depth1 = di2p_opt(DI2P_OPT_CONV_DEPTH1) != 0;
+#define DI2P_CONV_VEC_LAUNCH(S, D) hipLaunchKernelGGL((conv2d_vec_kernel<Cfg, S, D>), grid, block, lds, st, x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, pad, Ntot, relu, part, splits)
+    if (stride == 1) { if (depth1) DI2P_CONV_VEC_LAUNCH(1, 1); else DI2P_CONV_VEC_LAUNCH(1, 2); }
+    else { if (depth1) DI2P_CONV_VEC_LAUNCH(2, 1); else DI2P_CONV_VEC_LAUNCH(2, 2); }
+#undef DI2P_CONV_VEC_LAUNCH
     if (splits > 1) {
         const long long slice = (long long)Cout * Ntot;
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((slice / 4 + 255) / 256)), dim3(256), 0, st, part, splits, slice,

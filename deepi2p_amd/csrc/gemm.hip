@@ -112,6 +112,9 @@ struct LoaderConcat4 {
         return make_float4(p[o0], p[o1], p[o2], p[o3]);
     }
     __device__ __forceinline__ void fix(float4&, int) const {}
+    struct Info {};
+    __device__ __forceinline__ Info info() const { return Info{}; }
+    __device__ __forceinline__ void fix(float4&, int, const Info&) const {}
 };
 
 struct EpiDev {
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void pointwise_gemm_kernel(SrcDev src
     mfma_gemm_block<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
 }
 
-template <class Cfg, bool DENSE>
+template <class Cfg, bool DENSE, bool DEPTH2 = false>
 __global__ __launch_bounds__(Cfg::THREADS) void pointwise_gemm_vec_kernel(SrcDev srcs, const float* __restrict__ Wt, float* __restrict__ Y,
                                                                            int M, int K, int N, EpiDev epi) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -240,7 +243,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void pointwise_gemm_vec_kernel(SrcDev
     lb.N = N;
     lb.K = K;
     EpiPointwise ep{epi, Y, (int)blockIdx.z, M, N};
-    mfma_gemm_block_vec<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
+    if (DEPTH2) mfma_gemm_block_vec2<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
+    else mfma_gemm_block_vec<Cfg>(lds, la, lb, ep, K, blockIdx.y * Cfg::BM, blockIdx.x * Cfg::BN);
 }
 
 // ---- fused per-point head (per_point_pn of networks_united.py:57-74,194-197, coarse variant 736 -> 128 -> 128 -> P):
@@ -389,8 +393,13 @@ void launch_pw(const SrcDev& s, const float* Wt, float* Y, int B, int M, int K, 
 template <class Cfg>
 void launch_pw_vec(bool dense, const SrcDev& s, const float* Wt, float* Y, int B, int M, int K, int N, const EpiDev& e, hipStream_t st) {
     const dim3 grid(di2p_cdiv(N, Cfg::BN), di2p_cdiv(M, Cfg::BM), B);
-    if (dense)
+    const bool d2 = di2p_opt(DI2P_OPT_CONV_DEPTH1) == 0 && K > 2 * Cfg::BK;      // depth-2 prefetch pays from three K-steps on
+    if (dense && d2)
+        hipLaunchKernelGGL((pointwise_gemm_vec_kernel<Cfg, true, true>), grid, dim3(Cfg::THREADS), Cfg::LDS_FLOATS * sizeof(float), st, s, Wt, Y, M, K, N, e);
+    else if (dense)
         hipLaunchKernelGGL((pointwise_gemm_vec_kernel<Cfg, true>), grid, dim3(Cfg::THREADS), Cfg::LDS_FLOATS * sizeof(float), st, s, Wt, Y, M, K, N, e);
+    else if (d2)
+        hipLaunchKernelGGL((pointwise_gemm_vec_kernel<Cfg, false, true>), grid, dim3(Cfg::THREADS), Cfg::LDS_FLOATS * sizeof(float), st, s, Wt, Y, M, K, N, e);
     else
         hipLaunchKernelGGL((pointwise_gemm_vec_kernel<Cfg, false>), grid, dim3(Cfg::THREADS), Cfg::LDS_FLOATS * sizeof(float), st, s, Wt, Y, M, K, N, e);
 }

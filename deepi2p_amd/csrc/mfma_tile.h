@@ -239,6 +239,128 @@ __device__ __forceinline__ void mfma_gemm_block_vec(float* lds, LoaderA& la, Loa
 
 
 // ----------------------------------------------------------------------------------------------------------------
+// Depth-2 variant of mfma_gemm_block_vec: the global loads of K-step t+2 are issued before the MFMAs of step t, i.e. two
+// K-steps (2 x 16..64 MFMAs per wave) cover the L2/HBM latency instead of one.  Measured reason: a single workgroup per CU
+// runs the depth-1 loop at ~30 % MFMA utilisation (45 TF of 147 on the ResNet shapes) -- the latency of the staged loads
+// under load (~2 k cycles) is twice the MFMA time of a 64x64 K-step, and only co-resident workgroups hide the rest.
+// Same K order, same MFMA sequence: results are bit-identical to the depth-1 engine.  Loaders additionally provide
+//   typename Info; Info info() const   -- what fix() needs later about the tile loaded after the last begin_tile()
+//   void fix(float4&, int pass, const Info&) const
+template <class Cfg, class LoaderA, class LoaderB, class Epi>
+__device__ __forceinline__ void mfma_gemm_block_vec2(float* lds, LoaderA& la, LoaderB& lb, Epi& epi, int K, int m_blk, int j_blk,
+                                                     int t_begin = 0, int t_end = -1) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
+    constexpr int A_TPR = BM / 4, B_TPR = BN / 4;
+    constexpr int A_RPP = Cfg::THREADS / A_TPR, B_RPP = Cfg::THREADS / B_TPR;
+    constexpr int A_PASSES = BK >= A_RPP ? BK / A_RPP : 1, B_PASSES = BK >= B_RPP ? BK / B_RPP : 1;
+    static_assert((BK % A_RPP == 0 || A_RPP % BK == 0) && (BK % B_RPP == 0 || B_RPP % BK == 0), "tile/threads mismatch");
+    float* As = lds;
+    float* Bs = lds + 2 * BK * BM;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int a_col = (tid % A_TPR) * 4, a_row0 = tid / A_TPR;
+    const int b_col = (tid % B_TPR) * 4, b_row0 = tid / B_TPR;
+    const bool a_on = A_RPP <= BK || a_row0 < BK, b_on = B_RPP <= BK || b_row0 < BK;
+    lb.column4(j_blk + b_col);
+
+    f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    struct Stage { float4 ra[A_PASSES], rb[B_PASSES]; int k0; typename LoaderB::Info info; };
+    Stage s0, s1;
+    const int T = (t_end < 0 ? (K + BK - 1) / BK : t_end) - t_begin;
+    auto gload = [&](int t, Stage& s) {
+        s.k0 = (t_begin + t) * BK;
+        lb.begin_tile(s.k0);
+        s.info = lb.info();
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) s.ra[p] = la.load4(s.k0 + a_row0 + p * A_RPP, m_blk + a_col);
+#pragma unroll
+        for (int p = 0; p < B_PASSES; ++p) s.rb[p] = lb.load4(s.k0 + b_row0 + p * B_RPP);
+    };
+    auto lstore = [&](int buf, Stage& s) {
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) {
+            la.fix(s.ra[p], s.k0 + a_row0 + p * A_RPP);
+            if (a_on) *reinterpret_cast<float4*>(&As[(buf * BK + a_row0 + p * A_RPP) * BM + a_col]) = s.ra[p];
+        }
+#pragma unroll
+        for (int p = 0; p < B_PASSES; ++p) {
+            lb.fix(s.rb[p], p, s.info);
+            if (b_on) *reinterpret_cast<float4*>(&Bs[(buf * BK + b_row0 + p * B_RPP) * BN + b_col]) = s.rb[p];
+        }
+    };
+    auto compute = [&](int buf) {
+        const float* Ab = As + buf * BK * BM + wm * Cfg::TM * 32 + l31;
+        const float* Bb = Bs + buf * BK * BN + wn * Cfg::TN * 32 + l31;
+        float a[2][Cfg::TM], b[2][Cfg::TN];
+        auto fread = [&](int kk, int s) {
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i) a[s][i] = Ab[(kk + half) * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) b[s][j] = Bb[(kk + half) * BN + j * 32];
+        };
+        fread(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int s = (kk >> 1) & 1;
+            if (kk + 2 < BK) fread(kk + 2, s ^ 1);
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // step t computes from LDS buffer t & 1; stage s0 carries the even steps' data, s1 the odd ones (static register sets).
+    // (Measured and dropped: letting the LDS store of step t+1 interleave with the MFMAs of step t through a
+    //  sched_group_barrier pipeline -- 2 % slower; any instruction between two MFMAs of one accumulator chain costs more
+    //  than it hides.  Long uninterrupted MFMA chains (all operand reads first) are slower too: 84-88 vs 99 TF.)
+    gload(0, s0);
+    if (T > 1) gload(1, s1);
+    lstore(0, s0);
+    __syncthreads();
+    int t = 0;
+    for (; t + 2 < T; t += 2) {
+        gload(t + 2, s0);                       // s0 (step t) is already in LDS
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(1, s1);                          // step t + 1, loaded two steps ago
+        __syncthreads();
+        if (t + 3 < T) gload(t + 3, s1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1);
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(0, s0);                          // step t + 2
+        __syncthreads();
+    }
+    // tail: step t is in buffer 0 (t even); step t + 1, if any, waits in s1
+    compute(0);
+    if (t + 1 < T) {
+        lstore(1, s1);
+        __syncthreads();
+        compute(1);
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) {
+            const int jcol = j_blk + (wn * Cfg::TN + j) * 32 + l31;
+            const int mrow0 = m_blk + (wm * Cfg::TM + i) * 32 + 4 * half;
+            epi.tile(mrow0, jcol, acc[i][j]);
+        }
+}
+
+
+// ----------------------------------------------------------------------------------------------------------------
 // Variant for fused layer chains: the B operand is ALREADY in LDS as a [K][ldb] panel (the previous layer's output tile),
 // only A (weights [K][M], M % 4 == 0) is staged.  Same K order, same MFMA sequence as mfma_gemm_block_vec, so a layer
 // computed here is bit-identical to the same layer computed from global memory.  The accumulators are handed to

@@ -47,6 +47,8 @@ def test_pointwise_gemm_dense_vector_path(dev, B, chans, M, N):
     assert (y - ref).abs().max() <= _tol(ref, K)
     with _lib.option("pw_novec", 1):
         y0 = ops.pointwise_gemm(srcs, Wt, M, N, **args).cpu()
+    with _lib.option("conv_depth1", 1):
+        assert torch.equal(ops.pointwise_gemm(srcs, Wt, M, N, **args).cpu(), y)       # prefetch depth does not change a bit
     assert (y - y0).abs().max() <= _tol(ref, K)
     yt = ops.pointwise_gemm(srcs, Wt, M, N, transpose_out=True, **args).cpu()
     assert torch.equal(yt.transpose(1, 2), y)
@@ -155,6 +157,9 @@ def test_conv2d(dev, B, Cin, H, W, Cout, k, s, p):
         Wtap = w.permute(2, 3, 1, 0).reshape(-1, Cout).contiguous().to(dev)
         y3 = ops.conv2d(x.to(dev), Wtap, scale.to(dev), shift.to(dev), k, k, s, p, True, residual=res.to(dev), tap_major=True).cpu()
         assert (y3 - ref).abs().max() <= _tol(ref0, Cin * k * k)
+        with _lib.option("conv_depth1", 1):          # depth-1 vs depth-2 register prefetch: same K order, same MFMA sequence
+            y6 = ops.conv2d(x.to(dev), Wtap, scale.to(dev), shift.to(dev), k, k, s, p, True, residual=res.to(dev), tap_major=True).cpu()
+        assert torch.equal(y6, y3)
         with _lib.option("conv_nosplit", 1):
             y4 = ops.conv2d(x.to(dev), Wtap, scale.to(dev), shift.to(dev), k, k, s, p, True, residual=res.to(dev), tap_major=True).cpu()
         assert (y4 - y3).abs().max() <= _tol(ref0, Cin * k * k)

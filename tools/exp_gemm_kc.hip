@@ -102,9 +102,70 @@ __device__ __forceinline__ void ablate_block(float* lds, LoaderA& la, LoaderB& l
     float a0[Cfg::TM], b0[Cfg::TN];
     for (int i = 0; i < Cfg::TM; ++i) a0[i] = 1.0f + lane; 
     for (int j = 0; j < Cfg::TN; ++j) b0[j] = 2.0f + lane;
+    // FLAGS bit4 (16): second accumulator set for the odd k-pairs (no two consecutive MFMAs on the same accumulator; summed at the end)
+    // FLAGS bit5 (32): operand fragments read in batches of 4 k-pairs, MFMAs of a batch issued back to back
+    f32x16 acc2[Cfg::TM][Cfg::TN];
+    for (int i = 0; i < Cfg::TM; ++i) for (int j = 0; j < Cfg::TN; ++j) for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.0f;
     auto compute = [&](int buf) {
         const float* Ab = As + buf * BK * BM + wm * Cfg::TM * 32 + l31;
         const float* Bb = Bs + buf * BK * BN + wn * Cfg::TN * 32 + l31;
+        if (FLAGS & 192) {                              // 64: 8 k-pairs per batch, 128: the whole K-step; fragments single-buffered,
+            constexpr int NB = (FLAGS & 128) ? BK / 2 : 8;     // all reads of a batch, one wait, then its MFMAs back to back
+            float a[NB][Cfg::TM], b[NB][Cfg::TN];
+#pragma unroll
+            for (int kp = 0; kp < BK / 2; kp += NB) {
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+#pragma unroll
+                    for (int i = 0; i < Cfg::TM; ++i) a[q][i] = Ab[(2 * (kp + q) + half) * BM + i * 32];
+#pragma unroll
+                    for (int j = 0; j < Cfg::TN; ++j) b[q][j] = Bb[(2 * (kp + q) + half) * BN + j * 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < NB; ++q)
+#pragma unroll
+                    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < Cfg::TN; ++j) {
+                            if ((FLAGS & 16) && (q & 1)) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][i], b[q][j], acc2[i][j], 0, 0, 0);
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][i], b[q][j], acc[i][j], 0, 0, 0);
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
+        if (FLAGS & 32) {
+            constexpr int NB = 4;                       // k-pairs per batch
+            float a[2][NB][Cfg::TM], b[2][NB][Cfg::TN];
+            auto fread = [&](int kp0, int s) {
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+#pragma unroll
+                    for (int i = 0; i < Cfg::TM; ++i) a[s][q][i] = Ab[(2 * (kp0 + q) + half) * BM + i * 32];
+#pragma unroll
+                    for (int j = 0; j < Cfg::TN; ++j) b[s][q][j] = Bb[(2 * (kp0 + q) + half) * BN + j * 32];
+                }
+            };
+            fread(0, 0);
+#pragma unroll
+            for (int kp = 0; kp < BK / 2; kp += NB) {
+                const int s = (kp / NB) & 1;
+                if (kp + NB < BK / 2) fread(kp + NB, s ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < NB; ++q)
+#pragma unroll
+                    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < Cfg::TN; ++j) {
+                            if ((FLAGS & 16) && (q & 1)) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][q][i], b[s][q][j], acc2[i][j], 0, 0, 0);
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][q][i], b[s][q][j], acc[i][j], 0, 0, 0);
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
         float a[2][Cfg::TM], b[2][Cfg::TN];
         auto fread = [&](int kk, int s) {
 #pragma unroll
@@ -120,7 +181,10 @@ __device__ __forceinline__ void ablate_block(float* lds, LoaderA& la, LoaderB& l
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
-                for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < Cfg::TN; ++j) {
+                    if ((FLAGS & 16) && (kk & 2)) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc2[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+                }
         }
     };
     if (FLAGS & 8) glds_A(0, 0);
@@ -135,6 +199,7 @@ __device__ __forceinline__ void ablate_block(float* lds, LoaderA& la, LoaderB& l
         if (!(FLAGS & 2)) __syncthreads();
     }
     compute((T - 1) & 1);
+    if (FLAGS & 16) for (int i = 0; i < Cfg::TM; ++i) for (int j = 0; j < Cfg::TN; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[i][j][r];
     for (int i = 0; i < Cfg::TM; ++i) for (int j = 0; j < Cfg::TN; ++j)
         epi.tile(m_blk + (wm * Cfg::TM + i) * 32 + 4 * half, j_blk + (wn * Cfg::TN + j) * 32 + l31, acc[i][j]);
 }
@@ -303,6 +368,9 @@ template <class Cfg> void run_persist(int M, int K, int N, const char* name, int
     CK(hipFuncSetAttribute((const void*)persist_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_FLOATS * 4));
     CK(hipFuncSetAttribute((const void*)old_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_FLOATS * 4));
     const int ntiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((N + Cfg::BN - 1) / Cfg::BN);
+    int occ = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, persist_kernel<Cfg>, Cfg::THREADS, Cfg::LDS_FLOATS * 4));
+    if (blocks_per_cu > occ) { printf("(requested %d workgroups per CU, only %d fit: clamped)\n", blocks_per_cu, occ); blocks_per_cu = occ; }
     const int grid = std::min(ntiles, 256 * blocks_per_cu);
     CK(hipMemset(dC, 0, (size_t)M * N * 4));
     float ms = time_ms([&]() { persist_kernel<Cfg><<<grid, Cfg::THREADS, Cfg::LDS_FLOATS * 4>>>(dAt, dX, dC, M, K, N); }, 10);
@@ -325,6 +393,29 @@ int main(int argc, char** argv) {
         ablations<TileCfg<2, 2, 1, 2, 32>>(64, 576, 163840, "64x128");
         ablations<TileCfg<2, 2, 1, 1, 32>>(128, 1152, 40960, "64x64");
         ablations<TileCfg<2, 2, 1, 1, 32>>(256, 2304, 10240, "64x64");
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'v') {       // exp_gemm_kc v : MFMA issue-pattern variants of the K-loop (accumulator chains, read batching)
+        auto all = [&](auto cfg, int M, int K, int N, const char* name) {
+            using C = decltype(cfg);
+            run_ablate<C, 0>(M, K, N, name); run_ablate<C, 32>(M, K, N, name); run_ablate<C, 64>(M, K, N, name); run_ablate<C, 128>(M, K, N, name); run_ablate<C, 144>(M, K, N, name);
+        };
+        all(TileCfg<2, 2, 1, 1, 32>{}, 128, 1152, 40960, "64x64");
+        all(TileCfg<2, 2, 1, 2, 32>{}, 64, 576, 163840, "64x128");
+        all(TileCfg<2, 2, 1, 1, 32>{}, 256, 2304, 10240, "64x64");
+        all(TileCfg<2, 2, 2, 1, 32>{}, 128, 1152, 40960, "128x64");
+        all(TileCfg<2, 2, 2, 2, 32>{}, 128, 1152, 40960, "128x128");
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'q') {       // exp_gemm_kc q : persistent loop with the grid clamped to what is co-resident
+        for (int bpc : {1, 2, 3}) {
+            run_persist<TileCfg<2, 2, 1, 2, 32>>(64, 576, 163840, "64x128", bpc);
+            run_persist<TileCfg<2, 2, 1, 1, 32>>(128, 1152, 40960, "64x64", bpc);
+            run_persist<TileCfg<2, 2, 2, 1, 32>>(128, 1152, 40960, "128x64", bpc);
+            run_persist<TileCfg<2, 2, 2, 2, 32>>(128, 1152, 40960, "128x128", bpc);
+            run_persist<TileCfg<2, 2, 1, 1, 32>>(256, 2304, 10240, "64x64", bpc);
+            run_persist<TileCfg<2, 2, 2, 2, 32>>(256, 2304, 10240, "128x128", bpc);
+        }
         return 0;
     }
     if (argc > 1 && argv[1][0] == 'p') {       // exp_gemm_kc p : persistent tile loop vs one tile per workgroup
