@@ -91,6 +91,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams = batches in flight (1 = fully serial)")
     ap.add_argument("--no-h2d-pass", action="store_true", help="skip the second timed loop with the H2D copy inside the step")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per stream")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="only launch the ranks, rendezvous, run one barrier + all_reduce and print n_gpus (no GPU work)")
     return ap.parse_args(argv)
@@ -269,13 +270,52 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    graphs = {}
+
+    def graph_step(with_h2d):
+        """One step = one hipGraph replay: the ~150 launches of a step (network + argmax + solve) captured once per stream."""
+        i = step_no[0] % n_streams
+        key = (i, with_h2d)
+        if key not in graphs:
+            step_no[0] = i
+            step(with_h2d)                              # eager once on this stream: lazily created constants, allocator warm-up
+            streams[i].synchronize()
+            g = torch.cuda.CUDAGraph()
+            step_no[0] = i
+            with torch.cuda.graph(g, stream=streams[i]):
+                # inside capture torch.cuda.stream(streams[i]) is the capturing stream; step() launches on it
+                out_g = step(with_h2d)
+            graphs[key] = (g, out_g)
+            step_no[0] = i
+        g, out_g = graphs[key]
+        step_no[0] += 1
+        with torch.cuda.stream(streams[i]):
+            g.replay()
+        return out_g
+
+    # frames mode: a step is replayed as one hipGraph per stream (the ~150 launches are captured once); the hyp mode keeps
+    # eager launches (its all_gather is issued by torch.distributed).  A failed capture falls back to eager launches.
+    use_graph = not args.no_graph and not hyp
+    if use_graph:
+        try:
+            for i in range(n_streams):
+                step_no[0] = i
+                graph_step(False)
+            torch.cuda.synchronize()
+        except Exception as exc:          # noqa: BLE001 -- any capture problem: run eagerly, say so in the line
+            print("hipGraph capture failed (%s); running eagerly" % exc, file=sys.stderr)
+            use_graph = False
+            graphs.clear()
+        step_no[0] = 0
+    run_step = graph_step if use_graph else step
+
     def timed_loop(with_h2d):
-        for _ in range(args.warmup):
-            step(with_h2d)
+        for _ in range(max(args.warmup, n_streams if use_graph else 0)):
+            run_step(with_h2d)
         sync_all()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            o = step(with_h2d)
+            o = run_step(with_h2d)
         sync_all()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -398,7 +438,7 @@ def main():
                                    ("BASELINE configs[1]: KITTI 20480-pt / 160x512, batch %d per GPU, coarse classification "
                                     "+ %d-restart 2D GN/LM solver, max_iter 500" % (B, R)),
                        "mode": args.mode, "frames_per_gpu_per_step": B, "points": N, "image": [H, W], "restarts": R,
-                       "parallelism": ("hyp%d" if hyp else "dp%d") % world, "streams": n_streams,
+                       "parallelism": ("hyp%d" if hyp else "dp%d") % world, "streams": n_streams, "hip_graph": bool(use_graph),
                        "weights_broadcast_bytes": bcast_bytes},
             "value_with_h2d": (frames / dt_h2d) if dt_h2d else None,
             "ms_per_step_with_h2d": (dt_h2d / args.steps * 1e3) if dt_h2d else None,
