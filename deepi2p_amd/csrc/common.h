@@ -38,6 +38,7 @@ enum Di2pOption {
     DI2P_OPT_CONV_NOVEC,            // 1: scalar stager for the convolutions
     DI2P_OPT_CONV_CFG,              // >= 0: force a convolution tile configuration (experiments)
     DI2P_OPT_CONV_DEPTH1,           // 1: depth-1 register prefetch in the vector convolution engine (default: depth 2; bit-identical)
+    DI2P_OPT_INDEX_MAX_ROWS,        // index_max splits rows along N (3 launches) while B*C*S is below this many workgroups
     DI2P_OPT_PW_NOVEC,              // 1: scalar stager for the pointwise GEMMs
     DI2P_OPT_SOLVER_CFG,            // <waves per hypothesis><min waves per SIMD>, default 43
     DI2P_OPT_SOLVER_NOCULL,         // 1: classify every cluster per point (bit-identical by construction)

@@ -52,7 +52,29 @@ __global__ __launch_bounds__(256) void index_max_kernel(const float* __restrict_
     const bool vec_ok = ((((uintptr_t)row) | ((uintptr_t)idx)) & 15) == 0 && (n0 & 3) == 0;
     if (vec_ok) {
         const int nvec = (n1 - n0) >> 2;
-        for (int i = threadIdx.x; i < nvec; i += blockDim.x) {
+        // four 16-byte loads of data and of index in flight per lane before the first compare (the LDS compare/atomic chain
+        // otherwise serialises the stream: one load pair per iteration leaves the HBM pipe half empty)
+        constexpr int U = 4;
+        int i = threadIdx.x;
+        for (; i + (U - 1) * (int)blockDim.x < nvec; i += U * blockDim.x) {
+            float4 v[U];
+            int4 k4[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int n = n0 + 4 * (i + u * (int)blockDim.x);
+                v[u] = *reinterpret_cast<const float4*>(row + n);
+                k4[u] = *reinterpret_cast<const int4*>(idx + n);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int n = n0 + 4 * (i + u * (int)blockDim.x);
+                offer(state, k4[u].x, v[u].x, n);
+                offer(state, k4[u].y, v[u].y, n + 1);
+                offer(state, k4[u].z, v[u].z, n + 2);
+                offer(state, k4[u].w, v[u].w, n + 3);
+            }
+        }
+        for (; i < nvec; i += blockDim.x) {
             const int n = n0 + 4 * i;
             const float4 v = *reinterpret_cast<const float4*>(row + n);
             const int4 k4 = *reinterpret_cast<const int4*>(idx + n);
@@ -115,7 +137,7 @@ int launch(const float* data, const int* index, int* max_idx, float* max_val, co
     // choose the N split so the grid has >= ~2048 blocks but every block still streams >= 8 KiB
     int S = 1;
     const long long rows = (long long)B * C;
-    while (rows * S < 2048 && (N / (S * 2)) >= 2048) S *= 2;
+    while (rows * S < (long long)di2p_opt(DI2P_OPT_INDEX_MAX_ROWS) && (N / (S * 2)) >= 2048) S *= 2;
     if (S > 1 && workspace == nullptr) S = 1;
     if (S == 1) {
         hipLaunchKernelGGL(index_max_kernel<false>, dim3(C, B, 1), dim3(256), lds, st, data, index, max_idx, max_val,
