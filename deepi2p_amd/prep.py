@@ -87,3 +87,37 @@ def pack_pc_label(pc, coarse_pred, coarse_gt, fine_pred=None, fine_gt=None):
     out = torch.empty((B, 7, N), dtype=torch.float64, device=pc.device)
     call("di2p_pack_pc_label", ptr(pc), ptr(coarse_pred), ptr(coarse_gt), ptr(fine_pred), ptr(fine_gt), ptr(out), B, N, stream())
     return out
+
+
+def random_choice(seed, B, n_src, n_out, device, stream_id=0):
+    """-> i32[B, n_out]: n_out of n_src indices without replacement, uniformly random subset in uniformly random order, drawn
+    ON THE DEVICE from (seed, stream_id, frame, index) (np.random.choice(n_src, n_out, replace=False) of the loaders)."""
+    from . import _lib
+    out = torch.empty((B, n_out), dtype=torch.int32, device=device)
+    ws = torch.empty((_lib.load().di2p_random_choice_workspace_bytes(B, n_src),), dtype=torch.uint8, device=device)
+    call("di2p_random_choice", int(seed), int(stream_id), B, int(n_src), int(n_out), ptr(out), ptr(ws), stream())
+    return out
+
+
+def downsample(pc, intensity, sn, input_pt_num, seed):
+    """Device counterpart of KittiLoader.downsample_np (data/kitti_pc_img_pose_loader.py:158-171) for a batch of equally long
+    raw scans: pc f32[B,3,Nraw] (+ intensity [B,1,Nraw], sn [B,3,Nraw]) -> the same with input_pt_num points.
+    Nraw >= input_pt_num: a random subset; else every point floor(input_pt_num / Nraw) times plus a random remainder."""
+    require_cuda(pc, intensity, sn)
+    B, _, Nraw = pc.shape
+    if Nraw >= input_pt_num:
+        idx = random_choice(seed, B, Nraw, input_pt_num, pc.device)
+    else:
+        reps = input_pt_num // Nraw
+        fix = torch.arange(Nraw, dtype=torch.int32, device=pc.device).repeat(reps).unsqueeze(0).expand(B, -1)
+        rem = input_pt_num - reps * Nraw
+        idx = fix if rem == 0 else torch.cat((fix, random_choice(seed, B, Nraw, rem, pc.device)), dim=1)
+        idx = idx.contiguous()
+    return gather_points(pc, idx), gather_points(intensity, idx), gather_points(sn, idx), idx
+
+
+def sample_nodes_device(pc, node_num, seed, stream_id):
+    """node_a / node_b entirely on the device: node_num * 8 random candidates (:416-423) + FPS from candidate 0."""
+    B, _, N = pc.shape
+    cand_idx = random_choice(seed, B, N, min(N, node_num * 8), pc.device, stream_id=stream_id)
+    return sample_nodes(pc, node_num, cand_idx)

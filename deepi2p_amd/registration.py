@@ -146,6 +146,14 @@ class RegistrationPipeline:
         return (torch.as_tensor(noise, dtype=torch.float64, device=device),
                 torch.as_tensor(Ts, dtype=torch.float64, device=device))
 
+    def draw_on_device(self, F, device, seed):
+        """The restart list drawn on the device (Philox counter-based: a function of (seed, frame, restart) only)."""
+        noise = torch.empty((F, self.R), dtype=torch.float64, device=device)
+        Ts = torch.empty((F, self.R, 3), dtype=torch.float64, device=device)
+        ops.call("di2p_draw_restarts", int(seed), F, self.R, float(self.ry_sigma), float(self.amp), ops.ptr(noise), ops.ptr(Ts),
+                 ops.stream())
+        return noise, Ts
+
     def __call__(self, pc_f32, labels_i32, K_f64, restarts):
         """pc f32[F,3,N], labels i32[F,N], K f64[F,3,3], restarts = (ry_noise f64[F,R], t_init f64[F,R,3])
         -> dict(P f64[F,4,4], cost f64[F], best i32[F], yaw0, costs f64[F,R], iters i32[F,R])."""

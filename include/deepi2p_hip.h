@@ -268,6 +268,18 @@ int di2p_pnp_ransac(const float* pc, const int32_t* coarse, const int32_t* fine,
  * are done by the caller; helper for the fused pipeline: */
 int di2p_f32_to_f64(const float* in, double* out, long long n, void* stream);
 
+/* ---- on-device random draws (counter-based Philox4x32-10: every value is a function of (seed, index) only) -------------
+ * di2p_draw_restarts: the solver's restart list (evaluation/registration_lsq.py:163-164): ry_noise f64[F,R] ~ N(0, ry_sigma)
+ *   (the frame's yaw0 is added by the solver), init_T f64[F,R,3] = (0, 0, U(-t_amplitude, t_amplitude)).
+ * di2p_random_choice: n_out of n_src indices without replacement, in random order, per frame
+ *   (np.random.choice(n_src, n_out, replace=False) of data/kitti_pc_img_pose_loader.py:158-171,416-423);
+ *   stream_id separates independent draws under one seed; workspace: di2p_random_choice_workspace_bytes(B, n_src). */
+int di2p_draw_restarts(unsigned long long seed, int F, int R, double ry_sigma, double t_amplitude, double* ry_noise,
+                       double* init_T, void* stream);
+long long di2p_random_choice_workspace_bytes(int B, int n_src);
+int di2p_random_choice(unsigned long long seed, int stream_id, int B, int n_src, int n_out, int32_t* idx_out, void* workspace,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif
