@@ -429,7 +429,7 @@ struct Planes { double nL, nR, nT, nB; };
 //   label 1: inactive iff all five are positive, else every point is active;
 //   label 0: active   iff all five are positive, else every point is inactive (and cannot raise `bad`).
 // NaN/inf anywhere fails every comparison and falls back to the per-point path.
-// Returns 0: skip, 1: classify per point, 2: all active.
+// Returns 0: skip, 1: classify per point, 2: all active, 3 (label 0 only): no point is active, guard against exact zeros only.
 struct BoxTest {           // per sweep: |n_i^T R|_j * (1 + 1e-5) and the margin factors (wave-uniform)
     float R[9], t[3], T1;
     float aL[3], aR[3], aT[3], aB[3], aZ[3];
@@ -479,11 +479,10 @@ __device__ __forceinline__ int cluster_status(const Box& bx, const BoxTest& q) {
     if (cm > 0.0f) return (LAB == 1) ? (inside ? 0 : 2) : (inside ? 2 : 0);
     // a decided-negative plane already decides every point: not inside.  Label 1: all active.  Label-0 points of such a
     // cluster may still sit exactly on one of the undecided planes (dx, dy or p2 == 0 is an evaluation failure in the
-    // reference), so label 0 keeps the per-point path.
-    if (LAB == 1) {
-        const float hi = fminf(fminf(fminf(fL + tL, fR + tR), fminf(fT + tT, fB + tB)), p2 + tZ);
-        if (hi < 0.0f) return 2;
-    }
+    // reference): status 3 = no point can be active, but every point is still checked against exact zeros (fp32 guard,
+    // exact test when the guard cannot certify) -- without the ballot / queue work of a real classification.
+    const float hi = fminf(fminf(fminf(fL + tL, fR + tR), fminf(fT + tT, fB + tB)), p2 + tZ);
+    if (hi < 0.0f) return LAB == 1 ? 2 : 3;      // label 0: nothing is active, but an exact zero on an undecided plane must still be found
     return 1;
 }
 
@@ -552,6 +551,14 @@ __device__ __forceinline__ void prefilter32(const Pre32& q, float X, float Y, fl
     }
 }
 
+// Zero-guard of a label-0 point that is known to be inactive: true unless every |f_i| clears its margin.
+template <int NP>
+__device__ __forceinline__ bool zero_guard32(const Pre32& q, float X, float Y, float Z) {
+    bool act, unc;
+    prefilter32<NP, 0>(q, X, Y, Z, act, unc);
+    return unc;
+}
+
 // One label-uniform block of records [recs, recs+cnt) = nc clusters of CL records.  Cluster c belongs to wave
 // c % WPH (neighbouring clusters -- which tend to share their status -- spread over the waves).  Per round a lane
 // tests one cluster; the wave then walks the flagged ones:
@@ -616,8 +623,13 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
     BoxTest btest;
     make_box_test<NP>(rot, tx, ty, tz, k, btest);
     // phase A of one flagged cluster: classify its 64 records (status 1) or take them all (status 2), append the active ids
-    auto classify = [&](int c, bool isA, const Rec<PT>& rec) {
+    auto classify = [&](int c, bool isA, bool guard_only, const Rec<PT>& rec) {
         const bool valid = c * CL + lane < cnt;                                     // padding lanes of a partial cluster
+        if (LAB == 0 && guard_only) {            // status 3 (wave-uniform): nothing to queue
+            const bool unc = !use_pre || (valid && zero_guard32<NP>(pre, (float)rec.x, (float)rec.y, (float)rec.z));
+            if (__any(unc)) (void)exact_active(rec, valid);      // sets `bad` on an exact zero / non-finite value
+            return;
+        }
         bool act = valid;
         if (isA) {
             bool unc = true;
@@ -637,12 +649,12 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
         const int j = j0 + lane;
         int status = 0;
         if (j < mine) status = nocull ? 1 : cluster_status<NP, LAB>(boxes[j * WPH + wave], btest);
-        const unsigned long long mA = __ballot(status == 1), mB = __ballot(status == 2);
-        n_active[1] += __popcll(mA); n_active[2] += __popcll(mB); n_active[3] += min(mine - j0, 64);
+        const unsigned long long mA = __ballot(status == 1), mB = __ballot(status == 2), mC = __ballot(status == 3);
+        n_active[1] += __popcll(mA); n_active[2] += __popcll(mB); n_active[3] += __popcll(mC);
         // The flagged clusters are walked in index order with PF records in flight (a cluster's 64 records are one 16-byte load
         // per lane; the L2 latency is several times the ~40 instructions a cluster costs).  Slot i of the ring holds the
         // (bit index, record) of a cluster; exhausted slots carry bit = -1 (and a harmless clamped load).
-        unsigned long long mp = mA | mB;                 // clusters not yet requested
+        unsigned long long mp = mA | mB | mC;            // clusters not yet requested
         auto next_bit = [&]() { int b = -1; if (mp) { b = (int)__builtin_ctzll(mp); mp &= mp - 1; } return b; };
         constexpr int PF = 4;
         int bits[PF];
@@ -658,7 +670,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                         const int bit = bits[u];
                         bits[u] = next_bit();
                         ring[u] = load_rec((j0 + bits[u]) * WPH + wave);
-                        classify((j0 + bit) * WPH + wave, (mA >> bit) & 1ull, rec);
+                        classify((j0 + bit) * WPH + wave, (mA >> bit) & 1ull, (mC >> bit) & 1ull, rec);
                     }
                 }
                 // slots are consumed in order 0..PF-1 and refilled in the same order, so after a full pass slot 0 again holds the

@@ -42,7 +42,7 @@ for name, lab_np in (("noisy-gt", np.stack([f["labels"] for f in frames])),):
         tot = p[:, :3].sum(1)
         print("  per-sweep cycles (mean over hyps): sweep %.0f  barrier-wait %.0f  LM %.0f ; active evals/sweep (wave0) %.1f of %d records/wave"
               % ((p[:, 0] / sw).mean(), (p[:, 1] / sw).mean(), (p[:, 2] / sw).mean(), (p[:, 3] / sw).mean(), kept / 4))
-        print("  clusters per sweep (wave 0): per-point %.1f  all-active %.1f ; partial-combine cycles per sweep %.0f (part of LM)" % ((p[:, 4] / sw).mean(), (p[:, 5] / sw).mean(), (p[:, 6] / sw).mean()))
+        print("  clusters per sweep (wave 0): per-point %.1f  all-active %.1f  (zero-guard only: see n_act[3]) ; partial-combine cycles per sweep %.0f (part of LM)" % ((p[:, 4] / sw).mean(), (p[:, 5] / sw).mean(), (p[:, 6] / sw).mean()))
         print("  sweeps per hypothesis: percentiles 50/75/90/95/99/100 = %s" % np.percentile(sw, [50, 75, 90, 95, 99, 100]).round(0).tolist())
         q = prof.cpu().numpy().reshape(-1, 8)[:, 7]
         print("  line search: extra trials %.1f / hyp, of which accepted %.1f, re-sweeps %.1f (iterations %.1f, sweeps %.1f)" % (
