@@ -27,7 +27,7 @@ class SrcT(ctypes.Structure):
 class EpilogueT(ctypes.Structure):
     _fields_ = [("scale", c_void_p), ("shift", c_void_p), ("batch_bias", c_void_p), ("relu", c_int),
                 ("group_max", c_int), ("g_table", c_void_p * 2), ("g_idx", c_void_p * 2), ("g_w", c_void_p * 2),
-                ("g_nodes", c_int * 2), ("g_k", c_int * 2), ("transpose_out", c_int)]
+                ("g_nodes", c_int * 2), ("g_k", c_int * 2), ("transpose_out", c_int), ("group_max_out", c_void_p)]
 
 
 SRC_DENSE, SRC_GATHER, SRC_GROUP = 0, 1, 2

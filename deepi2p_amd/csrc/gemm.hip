@@ -129,6 +129,7 @@ struct EpiDev {
     int relu;
     int group_max;
     int transpose_out;
+    float* gmax_out;          // with group_max > 1: Y is stored in full AND the group maxima go here ([B,M,N/group_max])
 };
 
 // The accumulator tile of a lane is 16 rows of ONE column: rows mrow0 + 8g + {0..3}, g = 0..3.  All per-row operands
@@ -195,12 +196,13 @@ struct EpiPointwise {
             for (int r = 0; r < 16; ++r) {
                 const int m = mrow0 + (r & 3) + 8 * (r >> 2);
                 const bool ok = col_ok && m < M;
+                if (e.gmax_out && ok) Y[((long long)b * M + m) * N + n] = v[r];
                 float mx = ok ? v[r] : -__builtin_inff();
                 for (int o = 1; o < e.group_max; o <<= 1) {      // torch.max semantics: NaN propagates
                     const float ot = __shfl_xor(mx, o);
                     mx = (mx != mx || ot != ot) ? __builtin_nanf("") : fmaxf(mx, ot);
                 }
-                if (ok && (n % e.group_max) == 0) Y[((long long)b * M + m) * (N / e.group_max) + n / e.group_max] = mx;
+                if (ok && (n % e.group_max) == 0) (e.gmax_out ? e.gmax_out : Y)[((long long)b * M + m) * (N / e.group_max) + n / e.group_max] = mx;
             }
         } else if (e.transpose_out) {        // Y[b][n][m]: one float4 per row group (M % 4 == 0)
 #pragma unroll
@@ -442,6 +444,7 @@ extern "C" int di2p_pointwise_gemm(const di2p_src_t* srcs, int n_src, const floa
         e.group_max = epi->group_max > 1 ? epi->group_max : 1;
         for (int t = 0; t < 2; ++t) { e.g_table[t] = epi->g_table[t]; e.g_idx[t] = epi->g_idx[t]; e.g_w[t] = epi->g_w[t]; e.g_nodes[t] = epi->g_nodes[t]; }
         e.transpose_out = epi->transpose_out;
+        e.gmax_out = epi->group_max > 1 ? epi->group_max_out : nullptr;
         for (int t = 0; t < 2; ++t) {
             e.g_k[t] = e.g_table[t] ? epi->g_k[t] : 0;
             DI2P_CHECK_ARG(e.g_k[t] >= 0 && e.g_k[t] <= DI2P_MAX_GK, "g_k must be in [0, DI2P_MAX_GK]");

@@ -59,6 +59,59 @@ __global__ __launch_bounds__(256) void knn_nodes_kernel(const float* __restrict_
     }
 }
 
+// Node-level queries (a few hundred per frame: the kNN-fusion layer's k = 16 over cluster means, node_a <- node_b): one
+// WAVEFRONT per query instead of one lane.  Each lane holds up to 4 candidate keys (distance bits << 32 | node id: unsigned
+// order = ascending (distance, id) for the non-negative distances), a round picks the wave-wide minimum with a butterfly and
+// retires it; k rounds give the k nearest in order.  Same distances, same tie rule, same weight arithmetic as the kernel above.
+template <int KN>
+__global__ __launch_bounds__(256) void knn_nodes_wave_kernel(const float* __restrict__ query, const float* __restrict__ nodes,
+                                                             int* __restrict__ idx, float* __restrict__ weights, int Nq, int M) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= Nq) return;                                   // wave-uniform
+    const float* nb = nodes + (long long)b * 3 * M;
+    const float* q = query + (long long)b * 3 * Nq;
+    const float qx = q[n], qy = q[Nq + n], qz = q[2 * Nq + n];
+    unsigned long long key[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int m = lane + 64 * u;
+        key[u] = ~0ull;
+        if (m < M) {
+            const float dx = __fsub_rn(qx, nb[m]), dy = __fsub_rn(qy, nb[M + m]), dz = __fsub_rn(qz, nb[2 * M + m]);
+            const float d = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+            key[u] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)m;
+            if (d != d) key[u] = ~0ull - 1 - (unsigned)(M - m);       // NaN distances rank last, by id
+        }
+    }
+    float bd[KN];
+    int mine_i = 0;
+    float mine_d = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KN; ++j) {
+        unsigned long long best = key[0] < key[1] ? key[0] : key[1];
+        const unsigned long long b2 = key[2] < key[3] ? key[2] : key[3];
+        best = best < b2 ? best : b2;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best, o);
+            best = other < best ? other : best;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (key[u] == best) key[u] = ~0ull;      // node ids are unique: exactly one lane retires it
+        bd[j] = __uint_as_float((unsigned)(best >> 32));
+        if (lane == j) { mine_i = best == ~0ull ? 0 : (int)(unsigned)(best & 0xffffffffull); mine_d = bd[j]; }
+    }
+    if (lane < KN) idx[((long long)b * Nq + n) * KN + lane] = mine_i;
+    if (weights) {
+        float sum = bd[0];
+#pragma unroll
+        for (int j = 1; j < KN; ++j) sum = __fadd_rn(sum, bd[j]);
+        if (lane < KN) weights[((long long)b * Nq + n) * KN + lane] = __fsub_rn(1.0f, __fdiv_rn(mine_d, sum));
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // Cluster sums in 2^-24 m fixed point: integer adds are associative, so the result does not depend
 // on the order LDS atomics retire (bit-reproducible run to run), and it is exact for the quantised
@@ -205,8 +258,13 @@ extern "C" int di2p_knn_nodes(const float* query, const float* nodes, int32_t* i
     const dim3 grid(di2p_cdiv(Nq, 256), B), block(256);
     const size_t lds = (size_t)3 * M * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
+    // few queries per frame over few nodes: one wavefront per query (the lane-per-query kernel would leave the chip idle)
+    const bool per_wave = M <= 256 && Nq <= 1024;
+    const dim3 wgrid(di2p_cdiv(Nq, 4), B);
 #define DI2P_KNN_CASE(KK) \
-    case KK: hipLaunchKernelGGL(knn_nodes_kernel<KK>, grid, block, lds, st, query, nodes, idx, weights, Nq, M); break;
+    case KK: if (per_wave) hipLaunchKernelGGL(knn_nodes_wave_kernel<KK>, wgrid, block, 0, st, query, nodes, idx, weights, Nq, M); \
+             else hipLaunchKernelGGL(knn_nodes_kernel<KK>, grid, block, lds, st, query, nodes, idx, weights, Nq, M); \
+             break;
     switch (k) {
         DI2P_KNN_CASE(1) DI2P_KNN_CASE(2) DI2P_KNN_CASE(3) DI2P_KNN_CASE(4) DI2P_KNN_CASE(5) DI2P_KNN_CASE(6)
         DI2P_KNN_CASE(7) DI2P_KNN_CASE(8) DI2P_KNN_CASE(9) DI2P_KNN_CASE(10) DI2P_KNN_CASE(11) DI2P_KNN_CASE(12)

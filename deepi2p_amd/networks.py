@@ -226,9 +226,13 @@ class PCEncoder(_PackedModule):
         coord = ops.gather_neighbors(cluster_mean, node_b, knn_I)
         y = _run_split_layer([Src(coord)], (0, 3), node_a_features, (3, 3 + node_a_features.shape[1]), knn_I.view(B, Mb * K),
                              p["layers_before.0"], Mb * K)
-        y = _run_layer([Src(y)], p["layers_before.1"], Mb * K)
-        Cb = y.shape[1]
-        fmax = ops.channel_max(y.view(B, Cb * Mb, K)).view(B, Cb, Mb)
+        if K & (K - 1) == 0 and K <= 32:      # the max over the K neighbours comes out of the same launch as y itself
+            y, fmax = _run_layer([Src(y)], p["layers_before.1"], Mb * K, group_max=K, also_full=True)
+            Cb = y.shape[1]
+        else:
+            y = _run_layer([Src(y)], p["layers_before.1"], Mb * K)
+            Cb = y.shape[1]
+            fmax = ops.channel_max(y.view(B, Cb * Mb, K)).view(B, Cb, Mb)
         y = _run_split_layer([Src(y)], (Cb, 2 * Cb), fmax, (0, Cb), self._group_index(B, Mb, K, pc.device), p["layers_after.0"], Mb * K)
         if K & (K - 1) == 0 and K <= 32:
             node_b_features = _run_layer([Src(y)], p["layers_after.1"], Mb * K, group_max=K)

@@ -173,9 +173,10 @@ def _fill_gathered(e, gathered, B, M, N):
 
 
 def pointwise_gemm(srcs, Wt, M, N, scale=None, shift=None, batch_bias=None, relu=False, group_max=1, gathered=None,
-                   transpose_out=False):
+                   transpose_out=False, also_full=False):
     """Y[b] = epi(Wt^T @ concat(srcs)[b]).  srcs: list of Src; Wt f32[K,M].  gathered: optional list of up
-    to two (table f32[B,nodes,M] node-major, idx i32[B,N,k], w f32[B,N,k]).  transpose_out: Y is f32[B,N,M]."""
+    to two (table f32[B,nodes,M] node-major, idx i32[B,N,k], w f32[B,N,k]).  transpose_out: Y is f32[B,N,M].
+    group_max > 1 returns the group maxima; with also_full=True it returns (full Y, maxima) from the same launch."""
     B = srcs[0].t.shape[0]
     K = Wt.shape[0]
     arr = _fill_srcs(srcs)
@@ -185,11 +186,17 @@ def pointwise_gemm(srcs, Wt, M, N, scale=None, shift=None, batch_bias=None, relu
     _fill_gathered(e, gathered, B, M, N)
     e.transpose_out = int(bool(transpose_out))
     Nout = N // group_max if group_max > 1 else N
-    Y = torch.empty((B, Nout, M) if transpose_out else (B, M, Nout), dtype=_f32, device=Wt.device)
+    Ymax = None
+    if also_full and group_max > 1:
+        Y = torch.empty((B, M, N), dtype=_f32, device=Wt.device)
+        Ymax = torch.empty((B, M, Nout), dtype=_f32, device=Wt.device)
+        e.group_max_out = ptr(Ymax)
+    else:
+        Y = torch.empty((B, Nout, M) if transpose_out else (B, M, Nout), dtype=_f32, device=Wt.device)
     if _lib.WORK is not None:
         _lib.WORK["di2p_pointwise_gemm"] = _lib.WORK.get("di2p_pointwise_gemm", 0) + B * M * K * N
     call("di2p_pointwise_gemm", arr, len(srcs), ptr(Wt), ptr(Y), B, M, K, N, ctypes.byref(e), stream())
-    return Y
+    return (Y, Ymax) if Ymax is not None else Y
 
 
 def point_head(srcs, layer0, layer1, layer2, N, batch_bias=None, gathered=None):

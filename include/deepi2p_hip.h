@@ -128,6 +128,8 @@ typedef struct {
     int g_k[2];                /* neighbours per column of each table, 1..DI2P_MAX_GK (the two tables may differ:
                                   opt.k_interp_point_a / k_interp_point_b, networks_united.py:158-165,188-191) */
     int transpose_out;         /* 1: Y is written f32[B,N,M] (needs M % 4 == 0, group_max == 1) */
+    float* group_max_out;      /* with group_max > 1: NULL -> Y holds the maxima [B,M,N/group_max]; else Y is written in full
+                                  [B,M,N] and the maxima go here (layers_pc.py:809-813 needs both) */
 } di2p_epilogue_t;
 
 int di2p_pointwise_gemm(const di2p_src_t* srcs_host, int n_src, const float* Wt, float* Y,
