@@ -70,6 +70,7 @@ _SIGS = {
     "di2p_pnp_ransac": [c_void_p] * 5 + [c_int, c_void_p, c_int, c_double, c_int, c_int, c_int, c_int] + [c_void_p] * 7,
     "di2p_draw_restarts": [ctypes.c_ulonglong, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p],
     "di2p_random_choice": [ctypes.c_ulonglong, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "di2p_pnp_ransac_epnp": [c_void_p] * 5 + [c_int, c_void_p, c_int, c_double, c_int, c_int] + [c_void_p] * 7,
     "di2p_pack_pc_label": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
 }
 EXPORTS = sorted(list(_SIGS) + ["di2p_last_error", "di2p_version", "di2p_solve_workspace_bytes", "di2p_solver_set_profile_buffer", "di2p_pnp_workspace_bytes",

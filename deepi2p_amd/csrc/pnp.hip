@@ -16,6 +16,7 @@
 //      reprojection error over it (left-multiplicative rotation update)}, a round kept only if it loses no inliers.
 //   5. acceptance as the reference: success (>= 6 inliers) and |t| < 14.14, else identity / outlier ratio 1 (:134-140).
 #include "common.h"
+#include "epnp.h"
 
 #include <float.h>
 #include <math.h>
@@ -351,6 +352,214 @@ __global__ __launch_bounds__(256) void pnp_select_refine_kernel(const Corr* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// EPnP variant (the estimator the reference actually asks for: cv2.solvePnPRansac(flags=SOLVEPNP_EPNP)):
+//   hypotheses: EPnP on a minimal sample of 5 correspondences (OpenCV's model_points for EPNP; 4 when the frame has only 4 --
+//               OpenCV switches to P3P there -- with a Gauss-Newton polish of the pose, EPnP alone being ambiguous on 4 points);
+//   scoring:    squared reprojection error <= threshold^2 (no depth test, as OpenCV's computeError);
+//   result:     the model with the most inliers, then ONE EPnP re-fit on all its inliers; the inlier count reported is the
+//               winning model's; success iff it has at least the minimal-sample size; |t| < 14.14 as the reference.
+struct ThreadPoints {           // <= 5 correspondences of one sample, one thread
+    double X[5][3], uv[5][2];
+    int m;
+    __device__ int count() const { return m; }
+    template <class F> __device__ void for_each(F f) const { for (int i = 0; i < m; ++i) f(X[i][0], X[i][1], X[i][2], uv[i][0], uv[i][1], i == 0); }
+    __device__ double reduce(double v) const { return v; }
+};
+struct WavePoints {             // the masked correspondences of a frame, lanes of one wavefront stride over them
+    const Corr* c;
+    const unsigned char* mask;
+    int cnt, first;             // first = index of the first masked correspondence
+    __device__ int count() const { return cnt; }
+    template <class F> __device__ void for_each(F f) const {
+        for (int n = threadIdx.x & 63; n < cnt; n += 64)
+            if (mask[n]) { const Corr q = c[n]; f((double)q.x, (double)q.y, (double)q.z, (double)q.u, (double)q.v, n == first); }
+    }
+    __device__ double reduce(double v) const {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    }
+};
+
+// Gauss-Newton polish of a pose on a point set (left-multiplicative rotation update), `iters` steps
+template <class PS>
+__device__ inline void gn_polish(PS& ps, const epnp::Cam4& k, double* R, double* t, int iters) {
+    for (int it = 0; it < iters; ++it) {
+        double acc[27];
+        for (int a = 0; a < 27; ++a) acc[a] = 0.0;
+        ps.for_each([&](double X, double Y, double Z, double u, double v, bool) {
+            const double q0 = R[0] * X + R[1] * Y + R[2] * Z, q1 = R[3] * X + R[4] * Y + R[5] * Z, q2 = R[6] * X + R[7] * Y + R[8] * Z;
+            const double p0 = q0 + t[0], p1 = q1 + t[1], p2 = q2 + t[2];
+            const double iz = 1.0 / p2;
+            const double ru = k.fu * p0 * iz + k.uc - u, rv = k.fv * p1 * iz + k.vc - v;
+            const double dp[3][6] = {{0, q2, -q1, 1, 0, 0}, {-q2, 0, q0, 0, 1, 0}, {q1, -q0, 0, 0, 0, 1}};
+            double Ju[6], Jv[6];
+            for (int a = 0; a < 6; ++a) {
+                Ju[a] = k.fu * iz * dp[0][a] - k.fu * p0 * iz * iz * dp[2][a];
+                Jv[a] = k.fv * iz * dp[1][a] - k.fv * p1 * iz * iz * dp[2][a];
+            }
+            int idx = 0;
+            for (int a = 0; a < 6; ++a) for (int b2 = 0; b2 <= a; ++b2) acc[idx++] += Ju[a] * Ju[b2] + Jv[a] * Jv[b2];
+            for (int a = 0; a < 6; ++a) acc[21 + a] += Ju[a] * ru + Jv[a] * rv;
+        });
+        for (int a = 0; a < 27; ++a) acc[a] = ps.reduce(acc[a]);
+        double L[21], z[6], d[6];
+        bool ok = true;
+        for (int i = 0; i < 6 && ok; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double sv = acc[i * (i + 1) / 2 + j] + (i == j ? 1e-9 * (1.0 + acc[i * (i + 1) / 2 + i]) : 0.0);
+                for (int q = 0; q < j; ++q) sv -= L[i * (i + 1) / 2 + q] * L[j * (j + 1) / 2 + q];
+                if (i == j) { if (!(sv > 0.0)) { ok = false; break; } L[i * (i + 1) / 2 + i] = sqrt(sv); }
+                else L[i * (i + 1) / 2 + j] = sv / L[j * (j + 1) / 2 + j];
+            }
+        if (!ok) return;
+        for (int i = 0; i < 6; ++i) { double sv = -acc[21 + i]; for (int q = 0; q < i; ++q) sv -= L[i * (i + 1) / 2 + q] * z[q]; z[i] = sv / L[i * (i + 1) / 2 + i]; }
+        for (int i = 5; i >= 0; --i) { double sv = z[i]; for (int q = i + 1; q < 6; ++q) sv -= L[q * (q + 1) / 2 + i] * d[q]; d[i] = sv / L[i * (i + 1) / 2 + i]; }
+        double dR[9], Rn[9];
+        rodrigues(d, dR);
+        for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) Rn[r * 3 + cc] = dR[r * 3] * R[cc] + dR[r * 3 + 1] * R[3 + cc] + dR[r * 3 + 2] * R[6 + cc];
+        bool fin = true;
+        for (int a = 0; a < 9; ++a) fin = fin && isfinite(Rn[a]);
+        for (int a = 0; a < 3; ++a) fin = fin && isfinite(d[3 + a]);
+        if (!fin) return;
+        for (int a = 0; a < 9; ++a) R[a] = Rn[a];
+        for (int a = 0; a < 3; ++a) t[a] += d[3 + a];
+    }
+}
+
+__global__ __launch_bounds__(64) void pnp_hypotheses_epnp_kernel(const Corr* __restrict__ corr, const int* __restrict__ counts,
+                                                                 const double* __restrict__ Kmat, const int* __restrict__ samples, int N,
+                                                                 int iters, double* __restrict__ hyp) {
+    const int f = blockIdx.y;
+    const int it = blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= iters) return;
+    double* h = hyp + ((long long)f * iters + it) * HYP;
+    h[12] = 0.0;
+    const int cnt = counts[f];
+    if (cnt < 4) return;
+    const Corr* c = corr + (long long)f * N;
+    const double* K = Kmat + (long long)f * 9;
+    const epnp::Cam4 k{K[0], K[4], K[2], K[5]};
+    ThreadPoints ps;
+    ps.m = cnt >= 5 ? 5 : 4;
+    int ids[5];
+    for (int j = 0; j < ps.m; ++j) {
+        int s = samples[((long long)f * iters + it) * 6 + j] % cnt;
+        if (s < 0) s += cnt;
+        for (int q = 0; q < j; ++q) if (ids[q] == s) return;           // a sample with a repeated correspondence is skipped
+        ids[j] = s;
+        const Corr q = c[s];
+        ps.X[j][0] = q.x; ps.X[j][1] = q.y; ps.X[j][2] = q.z; ps.uv[j][0] = q.u; ps.uv[j][1] = q.v;
+    }
+    epnp::Pose pose;
+    epnp::solve(ps, k, pose);
+    if (!pose.ok) return;
+    if (ps.m == 4) gn_polish(ps, k, pose.R, pose.t, 15);
+    for (int a = 0; a < 9; ++a) { if (!isfinite(pose.R[a])) return; h[a] = pose.R[a]; }
+    for (int a = 0; a < 3; ++a) { if (!isfinite(pose.t[a])) return; h[9 + a] = pose.t[a]; }
+    h[12] = 1.0;
+}
+
+__device__ __forceinline__ bool reproj_inlier_cv(const Corr& q, const double* R, const double* t, double fx, double fy, double cx,
+                                                 double cy, double thr2) {
+    const double X = q.x, Y = q.y, Z = q.z;
+    const double p0 = R[0] * X + R[1] * Y + R[2] * Z + t[0], p1 = R[3] * X + R[4] * Y + R[5] * Z + t[1],
+                 p2 = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+    const double du = fx * p0 / p2 + cx - (double)q.u, dv = fy * p1 / p2 + cy - (double)q.v;
+    return du * du + dv * dv <= thr2;            // false for NaN
+}
+
+__global__ __launch_bounds__(256) void pnp_score_cv_kernel(const Corr* __restrict__ corr, const int* __restrict__ counts,
+                                                           const double* __restrict__ Kmat, const double* __restrict__ hyp, int N, int iters,
+                                                           double thr2, int* __restrict__ inliers) {
+    const int f = blockIdx.y;
+    const int it = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (it >= iters) return;
+    const int lane = threadIdx.x & 63;
+    const double* h = hyp + ((long long)f * iters + it) * HYP;
+    int cntin = 0;
+    if (h[12] != 0.0) {
+        const double* K = Kmat + (long long)f * 9;
+        double R[9], t[3];
+        for (int a = 0; a < 9; ++a) R[a] = h[a];
+        for (int a = 0; a < 3; ++a) t[a] = h[9 + a];
+        const Corr* c = corr + (long long)f * N;
+        const int cnt = counts[f];
+        for (int n = lane; n < cnt; n += 64) cntin += reproj_inlier_cv(c[n], R, t, K[0], K[4], K[2], K[5], thr2) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cntin += __shfl_xor(cntin, o);
+    if (lane == 0) inliers[(long long)f * iters + it] = h[12] != 0.0 ? cntin : -1;
+}
+
+// one workgroup per frame: best hypothesis, its inlier mask, EPnP re-fit on the inliers (wave 0), acceptance
+__global__ __launch_bounds__(256) void pnp_select_refit_kernel(const Corr* __restrict__ corr, const int* __restrict__ counts,
+                                                               const double* __restrict__ Kmat, const double* __restrict__ hyp,
+                                                               const int* __restrict__ inliers, int N, int iters, double thr2,
+                                                               double* __restrict__ P_out, double* __restrict__ outlier_ratio,
+                                                               int* __restrict__ n_inliers, int* __restrict__ best_out,
+                                                               unsigned char* __restrict__ mask) {
+    __shared__ int s_i[256], s_j[256];
+    __shared__ int s_first;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int cnt = counts[f];
+    const Corr* c = corr + (long long)f * N;
+    const double* K = Kmat + (long long)f * 9;
+    unsigned char* m = mask + (long long)f * N;
+    int bi = 0x7fffffff, bn = -1;
+    for (int it = tid; it < iters; it += 256) {
+        const int v = inliers[(long long)f * iters + it];
+        if (v > bn || (v == bn && it < bi)) { bn = v; bi = it; }
+    }
+    s_i[tid] = bn; s_j[tid] = bi;
+    if (tid == 0) s_first = 0x7fffffff;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { if (s_i[tid + o] > s_i[tid] || (s_i[tid + o] == s_i[tid] && s_j[tid + o] < s_j[tid])) { s_i[tid] = s_i[tid + o]; s_j[tid] = s_j[tid + o]; } }
+        __syncthreads();
+    }
+    bn = s_i[0]; bi = s_j[0];
+    double* Pf = P_out + (long long)f * 16;
+    const int msize = cnt >= 5 ? 5 : 4;
+    if (cnt < 4 || bn < msize) {
+        if (tid == 0) {
+            for (int a = 0; a < 16; ++a) Pf[a] = (a % 5 == 0) ? 1.0 : 0.0;
+            outlier_ratio[f] = 1.0; n_inliers[f] = 0; best_out[f] = -1;
+        }
+        return;
+    }
+    const double* h = hyp + ((long long)f * iters + bi) * HYP;
+    double R[9], t[3];
+    for (int a = 0; a < 9; ++a) R[a] = h[a];
+    for (int a = 0; a < 3; ++a) t[a] = h[9 + a];
+    for (int n = tid; n < cnt; n += 256) {
+        const bool in = reproj_inlier_cv(c[n], R, t, K[0], K[4], K[2], K[5], thr2);
+        m[n] = in ? 1 : 0;
+        if (in) atomicMin(&s_first, n);
+    }
+    __syncthreads();
+    if (tid < 64) {              // wave 0: EPnP over all inliers of the winning model
+        WavePoints ps{c, m, cnt, s_first};
+        const epnp::Cam4 k{K[0], K[4], K[2], K[5]};
+        epnp::Pose pose;
+        epnp::solve(ps, k, pose);
+        if (tid == 0) {
+            const double* Ro = pose.ok ? pose.R : R;
+            const double* to = pose.ok ? pose.t : t;
+            const double tn = sqrt(to[0] * to[0] + to[1] * to[1] + to[2] * to[2]);
+            for (int a = 0; a < 16; ++a) Pf[a] = (a % 5 == 0) ? 1.0 : 0.0;
+            if (tn < 14.14) {
+                for (int r = 0; r < 3; ++r) { for (int cc = 0; cc < 3; ++cc) Pf[r * 4 + cc] = Ro[r * 3 + cc]; Pf[r * 4 + 3] = to[r]; }
+                outlier_ratio[f] = 1.0 - (double)bn / (double)cnt;
+            } else {
+                outlier_ratio[f] = 1.0;
+            }
+            n_inliers[f] = bn; best_out[f] = bi;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" long long di2p_pnp_workspace_bytes(int F, int N, int iters) {
@@ -378,5 +587,27 @@ extern "C" int di2p_pnp_ransac(const float* pc, const int32_t* coarse, const int
                        reproj_err * reproj_err, inl);
     hipLaunchKernelGGL(pnp_select_refine_kernel, dim3(F), dim3(256), 0, st, corr, n_corr, K_scaled, hyp, inl, N, iters,
                        reproj_err * reproj_err, refine_rounds, refine_iters, P_out, outlier_ratio, n_inliers, best, mask);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_pnp_ransac_epnp(const float* pc, const int32_t* coarse, const int32_t* fine, const float* pixels,
+                                    const double* K_scaled, int W_fine, const int32_t* samples, int iters, double reproj_err, int F,
+                                    int N, double* P_out, double* outlier_ratio, int32_t* n_inliers, int32_t* n_corr, int32_t* best,
+                                    void* workspace, void* stream) {
+    DI2P_CHECK_ARG(F >= 0 && N >= 1 && iters >= 1 && W_fine >= 1 && reproj_err > 0, "bad size");
+    if (F == 0) return 0;
+    DI2P_CHECK_ARG(pc && coarse && (fine || pixels) && K_scaled && samples && P_out && outlier_ratio && n_inliers && n_corr && best && workspace, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    char* w = (char*)workspace;
+    Corr* corr = (Corr*)w;                                      w += (((size_t)F * N * sizeof(Corr)) + 255) & ~(size_t)255;
+    double* hyp = (double*)w;                                   w += (((size_t)F * iters * HYP * 8) + 255) & ~(size_t)255;
+    int* inl = (int*)w;                                         w += (((size_t)F * iters * 4) + 255) & ~(size_t)255;
+    unsigned char* mask = (unsigned char*)w;
+    hipLaunchKernelGGL(pnp_pack_kernel, dim3(F), dim3(256), 0, st, pc, coarse, fine, pixels, N, W_fine, corr, n_corr);
+    hipLaunchKernelGGL(pnp_hypotheses_epnp_kernel, dim3(di2p_cdiv(iters, 64), F), dim3(64), 0, st, corr, n_corr, K_scaled, samples, N, iters, hyp);
+    hipLaunchKernelGGL(pnp_score_cv_kernel, dim3(di2p_cdiv(iters, 4), F), dim3(256), 0, st, corr, n_corr, K_scaled, hyp, N, iters,
+                       reproj_err * reproj_err, inl);
+    hipLaunchKernelGGL(pnp_select_refit_kernel, dim3(F), dim3(256), 0, st, corr, n_corr, K_scaled, hyp, inl, N, iters,
+                       reproj_err * reproj_err, P_out, outlier_ratio, n_inliers, best, mask);
     DI2P_RETURN_LAUNCH();
 }

@@ -28,9 +28,12 @@ def draw_samples(rng, F, iters):
     return rng.integers(0, 2 ** 30, size=(F, iters, SAMPLE_SIZE), dtype=np.int64).astype(np.int32)
 
 
-def pnp_ransac(pc, coarse, fine, K_scaled, W_fine, samples, reproj_err=0.6, refine_rounds=20, refine_iters=5, pixels=None):
+def pnp_ransac(pc, coarse, fine, K_scaled, W_fine, samples, reproj_err=0.6, refine_rounds=20, refine_iters=5, pixels=None,
+               method="dlt_lo"):
     """Batched device entry.  pc f32[F,3,N], coarse/fine i32[F,N], K_scaled f64[F,3,3], samples i32[F,iters,6]
-    -> dict(P f64[F,4,4], outlier_ratio f64[F], n_inliers, n_corr, best i32[F])."""
+    -> dict(P f64[F,4,4], outlier_ratio f64[F], n_inliers, n_corr, best i32[F]).
+    method "epnp": EPnP minimal-sample hypotheses (5 points, or 4 when a frame has only 4) + one EPnP re-fit on the inliers, the
+    estimator of cv2.solvePnPRansac(flags=SOLVEPNP_EPNP); "dlt_lo": 6-point DLT hypotheses + locally optimised best model."""
     require_cuda(pc, coarse, fine, K_scaled, samples, pixels)
     F, _, N = pc.shape
     iters = samples.shape[1]
@@ -41,15 +44,22 @@ def pnp_ransac(pc, coarse, fine, K_scaled, W_fine, samples, reproj_err=0.6, refi
     n_corr = torch.empty((F,), dtype=torch.int32, device=dev)
     best = torch.empty((F,), dtype=torch.int32, device=dev)
     ws = torch.empty((_lib.load().di2p_pnp_workspace_bytes(F, N, iters),), dtype=torch.uint8, device=dev)
-    call("di2p_pnp_ransac", ptr(pc), ptr(coarse), ptr(fine), ptr(pixels), ptr(K_scaled), int(W_fine), ptr(samples), iters,
-         float(reproj_err), int(refine_rounds), int(refine_iters), F, N, ptr(P), ptr(ratio), ptr(n_in), ptr(n_corr), ptr(best), ptr(ws), stream())
+    if method == "epnp":
+        call("di2p_pnp_ransac_epnp", ptr(pc), ptr(coarse), ptr(fine), ptr(pixels), ptr(K_scaled), int(W_fine), ptr(samples), iters,
+             float(reproj_err), F, N, ptr(P), ptr(ratio), ptr(n_in), ptr(n_corr), ptr(best), ptr(ws), stream())
+    elif method == "dlt_lo":
+        call("di2p_pnp_ransac", ptr(pc), ptr(coarse), ptr(fine), ptr(pixels), ptr(K_scaled), int(W_fine), ptr(samples), iters,
+             float(reproj_err), int(refine_rounds), int(refine_iters), F, N, ptr(P), ptr(ratio), ptr(n_in), ptr(n_corr), ptr(best), ptr(ws), stream())
+    else:
+        raise ValueError("method must be 'epnp' or 'dlt_lo'")
     return dict(P=P, outlier_ratio=ratio, n_inliers=n_in, n_corr=n_corr, best=best)
 
 
 def solve_PnP(pc_np, coarse_predictions_np, fine_predictions_np, K_np, H, W, fine_resolution_scale, iterationsCount,
               method=None, rng=None, samples=None):
     """Reference signature (registration_pnp.py:95-96).  `fine_resolution_scale` is the reference's 1/32 factor
-    (it multiplies H, W and K, :101-104); `method` is accepted for compatibility (the HIP model solver is a DLT)."""
+    (it multiplies H, W and K, :101-104).  `method`: None / cv2.SOLVEPNP_EPNP (the reference's choice) -> the EPnP RANSAC;
+    the string "dlt_lo" selects the builder's 6-point DLT + locally optimised variant."""
     if not torch.cuda.is_available():
         raise RuntimeError("deepi2p_amd.registration_pnp needs a HIP device (there is no CPU fallback)")
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -64,6 +74,7 @@ def solve_PnP(pc_np, coarse_predictions_np, fine_predictions_np, K_np, H, W, fin
     co = torch.as_tensor(np.ascontiguousarray(coarse_predictions_np).astype(np.int32), device=dev).unsqueeze(0)
     fi = torch.as_tensor(np.ascontiguousarray(fine_predictions_np).astype(np.int32), device=dev).unsqueeze(0)
     Kt = torch.as_tensor(K_fine, device=dev).reshape(1, 3, 3)
-    out = pnp_ransac(pc, co, fi, Kt, int(round(Ws)), torch.as_tensor(np.ascontiguousarray(samples, dtype=np.int32), device=dev))
+    out = pnp_ransac(pc, co, fi, Kt, int(round(Ws)), torch.as_tensor(np.ascontiguousarray(samples, dtype=np.int32), device=dev),
+                     method="dlt_lo" if method == "dlt_lo" else "epnp")
     ratio = float(out["outlier_ratio"][0])
     return out["P"][0].cpu().numpy(), (1 if ratio == 1.0 else ratio)

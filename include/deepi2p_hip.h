@@ -265,6 +265,14 @@ int di2p_pnp_ransac(const float* pc, const int32_t* coarse, const int32_t* fine,
                     const double* K_scaled, int W_fine, const int32_t* samples, int iters, double reproj_err,
                     int refine_rounds, int refine_iters, int F, int N, double* P_out, double* outlier_ratio, int32_t* n_inliers,
                     int32_t* n_corr, int32_t* best, void* workspace, void* stream);
+/* The estimator the reference names (flags = cv2.SOLVEPNP_EPNP, evaluation/registration_pnp.py:125-132): EPnP on minimal
+ * samples of 5 correspondences (the first 5 entries of each row of `samples`; 4 when the frame has only 4), inlier iff the squared
+ * reprojection error <= reproj_err^2, the model with the most inliers, one EPnP re-fit on all of its inliers; frames with
+ * fewer than 4 correspondences or no model are rejected (identity, outlier ratio 1).  Same buffers as di2p_pnp_ransac. */
+int di2p_pnp_ransac_epnp(const float* pc, const int32_t* coarse, const int32_t* fine, const float* pixels,
+                         const double* K_scaled, int W_fine, const int32_t* samples, int iters, double reproj_err, int F, int N,
+                         double* P_out, double* outlier_ratio, int32_t* n_inliers, int32_t* n_corr, int32_t* best,
+                         void* workspace, void* stream);
 
 /* f32 -> f64 widening copy of the point cloud for the solver ([B,3,N]) and i32 label passthrough
  * are done by the caller; helper for the fused pipeline: */
