@@ -104,8 +104,12 @@ __device__ inline bool inv3x3(const double* M, double* inv) {
 
 // PS: int count(); template<F> void for_each(F f) with f(double X, Y, Z, u, v, bool first); double reduce(double) (sum over
 // the set, same value returned to every participant).
-template <class PS>
-__device__ inline void solve(PS& ps, const Cam4& k, Pose& out) {
+struct NoPolish { __device__ void operator()(double*, double*) const {} };
+
+// polish(R, t): applied to each of the three candidate poses before their reprojection errors are compared (used for 4-point
+// sets, where EPnP's linearisations are ambiguous and a Gauss-Newton descent from each candidate separates them)
+template <class PS, class Polish = NoPolish>
+__device__ inline void solve(PS& ps, const Cam4& k, Pose& out, Polish polish = Polish()) {
     out.ok = false;
     out.err = DBL_MAX;
     // ---- pass 1: centroid and scatter -> control points (centroid + principal directions scaled by the standard deviations)
@@ -282,6 +286,11 @@ __device__ inline void solve(PS& ps, const Cam4& k, Pose& out) {
         for (int a = 0; a < 9; ++a) { cd.R[a] = R[a]; fin = fin && isfinite(R[a]); }
         for (int a = 0; a < 3; ++a) { cd.t[a] = pc0[a] - (R[a * 3] * pw0[0] + R[a * 3 + 1] * pw0[1] + R[a * 3 + 2] * pw0[2]); fin = fin && isfinite(cd.t[a]); }
         cd.ok = fin;
+        if (fin) {
+            polish(cd.R, cd.t);
+            for (int a = 0; a < 9; ++a) cd.ok = cd.ok && isfinite(cd.R[a]);
+            for (int a = 0; a < 3; ++a) cd.ok = cd.ok && isfinite(cd.t[a]);
+        }
     }
     // ---- pass 3: mean reprojection error of the candidates
     double e[3] = {0, 0, 0};

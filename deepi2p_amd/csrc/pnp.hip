@@ -453,9 +453,9 @@ __global__ __launch_bounds__(64) void pnp_hypotheses_epnp_kernel(const Corr* __r
         ps.X[j][0] = q.x; ps.X[j][1] = q.y; ps.X[j][2] = q.z; ps.uv[j][0] = q.u; ps.uv[j][1] = q.v;
     }
     epnp::Pose pose;
-    epnp::solve(ps, k, pose);
+    if (ps.m == 4) epnp::solve(ps, k, pose, [&](double* R, double* t) { gn_polish(ps, k, R, t, 15); });
+    else epnp::solve(ps, k, pose);
     if (!pose.ok) return;
-    if (ps.m == 4) gn_polish(ps, k, pose.R, pose.t, 15);
     for (int a = 0; a < 9; ++a) { if (!isfinite(pose.R[a])) return; h[a] = pose.R[a]; }
     for (int a = 0; a < 3; ++a) { if (!isfinite(pose.t[a])) return; h[9 + a] = pose.t[a]; }
     h[12] = 1.0;
