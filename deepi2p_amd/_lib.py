@@ -71,10 +71,12 @@ _SIGS = {
     "di2p_draw_restarts": [ctypes.c_ulonglong, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p],
     "di2p_random_choice": [ctypes.c_ulonglong, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "di2p_pnp_ransac_epnp": [c_void_p] * 5 + [c_int, c_void_p, c_int, c_double, c_int, c_int] + [c_void_p] * 7,
+    "di2p_classifier_loss": [c_void_p] * 4 + [c_int, c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 5,
+    "di2p_adam_step": [c_void_p] * 4 + [c_ll, c_int, c_float, c_float, c_float, c_float, c_void_p],
     "di2p_pack_pc_label": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
 }
 EXPORTS = sorted(list(_SIGS) + ["di2p_last_error", "di2p_version", "di2p_solve_workspace_bytes", "di2p_solver_set_profile_buffer", "di2p_pnp_workspace_bytes",
-                 "di2p_conv2d_workspace_bytes", "di2p_set_option", "di2p_get_option", "di2p_random_choice_workspace_bytes"])
+                 "di2p_conv2d_workspace_bytes", "di2p_set_option", "di2p_get_option", "di2p_random_choice_workspace_bytes", "di2p_classifier_loss_workspace_bytes"])
 
 
 def load():
@@ -98,6 +100,8 @@ def load():
         lib.di2p_pnp_workspace_bytes.argtypes = [c_int, c_int, c_int]
         lib.di2p_conv2d_workspace_bytes.restype = c_ll
         lib.di2p_conv2d_workspace_bytes.argtypes = [c_int] * 10
+        lib.di2p_classifier_loss_workspace_bytes.restype = c_ll
+        lib.di2p_classifier_loss_workspace_bytes.argtypes = [c_int, c_int]
         lib.di2p_random_choice_workspace_bytes.restype = c_ll
         lib.di2p_random_choice_workspace_bytes.argtypes = [c_int, c_int]
         lib.di2p_set_option.restype = c_int

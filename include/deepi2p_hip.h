@@ -290,6 +290,20 @@ long long di2p_random_choice_workspace_bytes(int B, int n_src);
 int di2p_random_choice(unsigned long long seed, int stream_id, int B, int n_src, int n_out, int32_t* idx_out, void* workspace,
                        void* stream);
 
+/* ---- training-side head (first slice of SURVEY.md 8f rank 4; the backward of the network itself is not built) ----------------
+ * di2p_classifier_loss: the losses of models/multimodal_classifier.py:189-191 and d loss / d scores in one pass:
+ *   coarse f32[B,2,N] with FocalLoss(alpha, gamma, 'mean') * coarse_loss_alpha (models/focal_loss.py:55-112), fine f32[B,L,N]
+ *   (or NULL) with mean cross-entropy over the points whose coarse label is 1; labels i32[B,N] (di2p_project_labels).
+ *   out8 f64[8] = {loss, coarse loss, fine loss, coarse accuracy, fine accuracy, inside count, 0, 0};
+ *   d_coarse f32[B,2,N] / d_fine f32[B,L,N] (may be NULL: losses only).  workspace: di2p_classifier_loss_workspace_bytes(B, N).
+ * di2p_adam_step: torch.optim.Adam (weight_decay 0, amsgrad off; :44-47) on one flat fp32 buffer, step counted from 1. */
+long long di2p_classifier_loss_workspace_bytes(int B, int N);
+int di2p_classifier_loss(const float* coarse, const float* fine, const int32_t* coarse_labels, const int32_t* fine_labels,
+                         int B, int N, int L, float alpha, float gamma, float coarse_loss_alpha, double* out8,
+                         float* d_coarse, float* d_fine, void* workspace, void* stream);
+int di2p_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step, float lr,
+                   float beta1, float beta2, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

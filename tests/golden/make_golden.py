@@ -18,6 +18,8 @@ where /root/reference exists):   python tests/golden/make_golden.py
                          logits, ALL argmax labels (coarse bit-packed, fine uint8), per-output percentiles / sums, and
                          percentiles of the encoder stages (SURVEY.md 8c fixture policy: "one full-size KITTI-shape run
                          reduced to checksums/percentiles")
+  loss_golden.npz        the reference's models/focal_loss.py (imported) + torch CrossEntropyLoss assembled as
+                         models/multimodal_classifier.py:169-191: loss values, accuracies and AUTOGRAD gradients w.r.t. the scores
 Fixtures hold data only (inputs + expected outputs), never reference source.
 """
 import ast
@@ -162,6 +164,48 @@ def make_fullsize():
     print("network_fullsize_golden.npz written")
 
 
+def make_losses():
+    """Loss values and autograd gradients from the reference's OWN modules: models/focal_loss.py (imported) + torch's
+    CrossEntropyLoss, assembled as models/multimodal_classifier.py:169-191 does (sort-based gather of the inside points)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_focal_loss", os.path.join(REF, "models", "focal_loss.py"))
+    fl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fl)
+    g = torch.Generator().manual_seed(5)
+    out = {}
+    for name, (B, L, N, frac) in {"small": (2, 8, 1024, 0.3), "kitti_L80": (1, 80, 768, 0.15), "coarse_only": (2, 0, 777, 0.5)}.items():
+        coarse = (torch.randn(B, 2, N, generator=g) * 2).requires_grad_(True)
+        clab = (torch.rand(B, N, generator=g) < frac).long()
+        crit_c = fl.FocalLoss(alpha=0.5, gamma=2, reduction="mean")
+        coarse_loss = crit_c(coarse, clab) * 50
+        out[name + "_coarse"], out[name + "_clab"] = coarse.detach().numpy(), clab.numpy().astype(np.int32)
+        if L:
+            fine = (torch.randn(B, L, N, generator=g) * 3).requires_grad_(True)
+            flab = torch.randint(0, L, (B, N), generator=g)
+            inside_Bn = clab.reshape(B * N).to(torch.int32)
+            insider_num = int(inside_Bn.sum())
+            _, idx = torch.sort(inside_Bn, descending=True)
+            insider_idx = idx[:insider_num]
+            flab_in = torch.gather(flab.view(B * N), 0, insider_idx)
+            fs = fine.permute(0, 2, 1).reshape(B * N, L).contiguous()
+            fs_in = torch.gather(fs, 0, insider_idx.unsqueeze(1).expand(insider_num, L))
+            fine_loss = torch.nn.CrossEntropyLoss()(fs_in, flab_in)
+            loss = coarse_loss + fine_loss
+            loss.backward()
+            out[name + "_fine"], out[name + "_flab"] = fine.detach().numpy(), flab.numpy().astype(np.int32)
+            out[name + "_d_fine"] = fine.grad.numpy()
+            out[name + "_fine_acc"] = np.float64((fs_in.argmax(1) == flab_in).float().mean())
+            out[name + "_fine_loss"] = np.float64(fine_loss.item())
+        else:
+            loss = coarse_loss
+            loss.backward()
+        out[name + "_d_coarse"] = coarse.grad.numpy()
+        out[name + "_loss"], out[name + "_coarse_loss"] = np.float64(loss.item()), np.float64(coarse_loss.item())
+        out[name + "_coarse_acc"] = np.float64((coarse.argmax(1) == clab).float().mean())
+    np.savez_compressed(os.path.join(HERE, "loss_golden.npz"), **out)
+    print("loss_golden.npz written", {k: float(v) for k, v in out.items() if k.endswith("_loss")})
+
+
 def _extract_functions(path, names):
     src = open(path).read()
     tree = ast.parse(src)
@@ -243,9 +287,13 @@ if __name__ == "__main__":
     if only == "fullsize":
         make_fullsize()
         sys.exit(0)
+    if only == "losses":
+        make_losses()
+        sys.exit(0)
     make_index_max()
     make_network(True, "network_golden.npz")
     make_network(False, "network_coarse_golden.npz")
     make_lsq_driver()
     make_prep()
     make_fullsize()
+    make_losses()
