@@ -74,9 +74,29 @@ _SIGS = {
     "di2p_classifier_loss": [c_void_p] * 4 + [c_int, c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 5,
     "di2p_adam_step": [c_void_p] * 4 + [c_ll, c_int, c_float, c_float, c_float, c_float, c_void_p],
     "di2p_pack_pc_label": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "di2p_bn_train_forward": [c_void_p] * 9 + [c_float, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "di2p_bn_train_backward": [c_void_p] * 6 + [c_int] + [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p, c_void_p],
+    "di2p_channel_sum": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "di2p_bmm_rc": [c_void_p, c_ll, c_ll, c_void_p, c_ll, c_ll, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_ll, c_void_p],
+    "di2p_bmm_km": [c_void_p, c_int, c_ll, c_void_p, c_int, c_ll, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "di2p_gather_backward": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_ll, c_void_p],
+    "di2p_conv2d_wgrad": [c_void_p] * 3 + [c_int] * 9 + [c_void_p, c_ll, c_void_p],
+    "di2p_conv2d_dgrad": [c_void_p] * 3 + [c_int] * 9 + [c_void_p],
+    "di2p_maxpool3x3s2_backward": [c_void_p] * 3 + [c_int] * 4 + [c_void_p],
+    "di2p_segment_max_backward": [c_void_p] * 4 + [c_int] * 4 + [c_void_p],
+    "di2p_group_max_forward": [c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p],
+    "di2p_group_max_backward": [c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p],
+    "di2p_dropout_mask": [ctypes.c_ulonglong, c_int, c_float, c_ll, c_void_p, c_void_p],
+    "di2p_apply_mask": [c_void_p, c_void_p, c_float, c_void_p, c_ll, c_void_p],
+}
+_WS_SIGS = {        # <name>_workspace_bytes helpers returning long long
+    "di2p_channel_reduce_workspace_bytes": [c_int] * 3,
+    "di2p_bmm_rc_workspace_bytes": [c_int] * 4,
+    "di2p_gather_backward_workspace_bytes": [c_int] * 4,
+    "di2p_conv2d_wgrad_workspace_bytes": [c_int] * 9,
 }
 EXPORTS = sorted(list(_SIGS) + ["di2p_last_error", "di2p_version", "di2p_solve_workspace_bytes", "di2p_solver_set_profile_buffer", "di2p_pnp_workspace_bytes",
-                 "di2p_conv2d_workspace_bytes", "di2p_set_option", "di2p_get_option", "di2p_random_choice_workspace_bytes", "di2p_classifier_loss_workspace_bytes"])
+                 "di2p_conv2d_workspace_bytes", "di2p_set_option", "di2p_get_option", "di2p_random_choice_workspace_bytes", "di2p_classifier_loss_workspace_bytes"] + list(_WS_SIGS))
 
 
 def load():
@@ -104,6 +124,10 @@ def load():
         lib.di2p_classifier_loss_workspace_bytes.argtypes = [c_int, c_int]
         lib.di2p_random_choice_workspace_bytes.restype = c_ll
         lib.di2p_random_choice_workspace_bytes.argtypes = [c_int, c_int]
+        for name, args in _WS_SIGS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = c_ll
         lib.di2p_set_option.restype = c_int
         lib.di2p_set_option.argtypes = [ctypes.c_char_p, c_ll]
         lib.di2p_get_option.restype = c_ll

@@ -107,6 +107,20 @@ __global__ __launch_bounds__(1024) void random_choice_kernel(unsigned long long 
     for (int i = tid; i < n_out; i += 1024) out[(long long)b * n_out + i] = (int)(unsigned)(keys[i] & 0xffffffffull);
 }
 
+// stream tag 3: the keep-mask of nn.Dropout (per_point_pn, networks_united.py:57-74; layers_pc.py:300-303,339-340): element i is kept
+// with probability 1 - p.  Four elements per Philox block; a pure function of (seed, stream_id, i), so the backward pass can
+// re-read or re-draw it.
+__global__ __launch_bounds__(256) void dropout_mask_kernel(unsigned long long seed, int stream_id, float p, long long n, unsigned char* __restrict__ mask) {
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q * 4 >= n) return;
+    const U4 r = philox4x32_10(U4{(unsigned)q, (unsigned)(q >> 32), (unsigned)stream_id, 3u}, (unsigned)seed, (unsigned)(seed >> 32));
+    const unsigned v[4] = {r.x, r.y, r.z, r.w};
+    const double thr = (double)p * 4294967296.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (q * 4 + k < n) mask[q * 4 + k] = (double)v[k] >= thr ? 1 : 0;
+}
+
 int pow2_at_least(int n) { int p = 64; while (p < n) p <<= 1; return p; }
 
 }  // namespace
@@ -133,5 +147,12 @@ extern "C" int di2p_random_choice(unsigned long long seed, int stream_id, int B,
     if (B == 0 || n_out == 0) return 0;
     hipLaunchKernelGGL(random_choice_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, seed, stream_id, n_src, pow2_at_least(n_src),
                        n_out, (unsigned long long*)workspace, idx_out);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_dropout_mask(unsigned long long seed, int stream_id, float p, long long n, uint8_t* mask, void* stream) {
+    DI2P_CHECK_ARG(mask && n >= 0 && p >= 0.0f && p < 1.0f, "bad args (0 <= p < 1)");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(di2p_cdiv((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, seed, stream_id, p, n, (unsigned char*)mask);
     DI2P_RETURN_LAUNCH();
 }

@@ -1,0 +1,607 @@
+// Training path of the classifier: the backward kernels that torch.autograd supplies in the reference
+// (models/multimodal_classifier.py:213-218 `loss.backward()`) written for gfx950, plus train-mode BatchNorm.
+//
+//   rc-GEMM          out[row][col] = sum_r A(r,row) * B(r,col) with BOTH operands contiguous along the reduction index r
+//                    (the shape of every "gradient with respect to a weight": reduce over points / pixels).  Lanes load along r
+//                    (coalesced dwords), the tile is transposed on its way into LDS ([r][row] panels, row pitch 65: the 32 lanes
+//                    of a store group hit 32 different banks) and feeds v_mfma_f32_32x32x2_f32 exactly like the forward engine.
+//                    The reduction is cut into chunks (one workgroup each, partial tiles in scratch) that a second kernel adds in
+//                    chunk order: deterministic, no float atomics.  Instances:
+//                      * d W of a 1x1 layer            A = dY[b][m][n],  B = X[b][k][n]                (nn.Conv1d / MyConv2d)
+//                      * d W of a convolution          A = dY[b][co][p], B = im2col(X)[b][(ci,ky,kx)][p]
+//                      * backward of column gathers    A = dY[b][c][j],  B = sum_k w[b][j][k] [idx[b][j][k] == m]
+//                        (torch.gather along the point axis and upsample_by_interpolation, networks_united.py:76-103: the scatter
+//                        of a gather written as a product with the sparse selection matrix -- no atomics, any fan-in)
+//                      * attention: d feat               A = dOut[b][c][m], B = score[b][hw][m]
+//   km-GEMM          out[row][col] = sum_k A[k][row] * B[k][col] per batch (attention: d score)
+//   conv dgrad       d X as an implicit GEMM over (co, ky, kx) with the stride folded into the loader
+//   BatchNorm        batch statistics in fp64 partial sums (two kernels), normalise + affine (+ residual) (+ ReLU) fused;
+//                    backward = one reduction pass (sum g, sum g*xhat) + one elementwise pass
+//   arg-max routers  segment max (index_max), max over neighbours / nodes, 3x3/2 max-pool: gradient goes to the saved / recomputed
+//                    arg-max (first maximum in scan order, the rule of torch.max / max_pool2d)
+#include "common.h"
+#include "mfma_tile.h"
+
+namespace {
+
+// =============================================================================================== rc-GEMM
+constexpr int RC_BK = 32, RC_BM = 64, RC_LD = 65, RC_PASSES = 8;
+constexpr int RC_LDS_FLOATS = 2 * 2 * RC_BK * RC_LD;
+
+// Loader protocol: set_index(p, i) once per pass p (row / column i of the output tile, may be out of range), set_r(r, ok)
+// once per K-step (this lane's reduction index; !ok = past the end), load(p) -> value (0 where out of range).
+template <class LA, class LB>
+__device__ __forceinline__ void rc_gemm_tile(float* lds, LA& la, LB& lb, int r_begin, int r_end, int row_blk, int col_blk,
+                                             float* __restrict__ out, int rows, int cols) {
+    float* As = lds;                          // [2][BK][LD]
+    float* Bs = lds + 2 * RC_BK * RC_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
+    const int r_in = tid & 31, q0 = tid >> 5;
+#pragma unroll
+    for (int p = 0; p < RC_PASSES; ++p) { la.set_index(p, row_blk + q0 + 8 * p); lb.set_index(p, col_blk + q0 + 8 * p); }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    float ra[RC_PASSES], rb[RC_PASSES];
+    const int T = (r_end - r_begin + RC_BK - 1) / RC_BK;
+    auto gload = [&](int t) {
+        const int r = r_begin + t * RC_BK + r_in;
+        const bool ok = r < r_end;
+        const int rc = ok ? r : r_end - 1;
+        la.set_r(rc, ok); lb.set_r(rc, ok);
+#pragma unroll
+        for (int p = 0; p < RC_PASSES; ++p) { ra[p] = la.load(p); rb[p] = lb.load(p); }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < RC_PASSES; ++p) {
+            As[(buf * RC_BK + r_in) * RC_LD + q0 + 8 * p] = ra[p];
+            Bs[(buf * RC_BK + r_in) * RC_LD + q0 + 8 * p] = rb[p];
+        }
+    };
+    if (T > 0) { gload(0); lstore(0); }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < T) gload(t + 1);
+        const float* Ab = As + buf * RC_BK * RC_LD + wm * 32 + l31;
+        const float* Bb = Bs + buf * RC_BK * RC_LD + wn * 32 + l31;
+        float a[RC_BK / 2], b[RC_BK / 2];
+#pragma unroll
+        for (int kk = 0; kk < RC_BK; kk += 2) { a[kk / 2] = Ab[(kk + half) * RC_LD]; b[kk / 2] = Bb[(kk + half) * RC_LD]; }
+#pragma unroll
+        for (int kk = 0; kk < RC_BK / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc, 0, 0, 0);
+        if (t + 1 < T) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    const int col = col_blk + wn * 32 + l31;
+    if (col < cols) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row_blk + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row < rows) out[(long long)row * cols + col] = acc[r];
+        }
+    }
+}
+
+// value(r, i) = p[i * ld + r], i < n
+struct RcStrided {
+    const float* base;
+    long long ld, batch_stride;
+    int n;
+    const float* p;
+    long long off[RC_PASSES];
+    bool okp[RC_PASSES];
+    int r;
+    bool okr;
+    __device__ __forceinline__ void batch(int z) { p = base + (long long)z * batch_stride; }
+    __device__ __forceinline__ void set_index(int ps, int i) { okp[ps] = i < n; off[ps] = (long long)min(i, n - 1) * ld; }
+    __device__ __forceinline__ void set_r(int r_, bool ok) { r = r_; okr = ok; }
+    __device__ __forceinline__ float load(int ps) const { const float v = p[off[ps] + r]; return (okr && okp[ps]) ? v : 0.0f; }
+};
+
+// value(r = output pixel, i = (ci, ky, kx)) = x[b][ci][oy*s - pad + ky][ox*s - pad + kx] or 0
+struct RcIm2col {
+    const float* base;
+    int Cin, H, W, OW, KH, KW, stride, pad, ncols;
+    const float* p;
+    int ci_off[RC_PASSES], ky[RC_PASSES], kx[RC_PASSES];
+    bool okp[RC_PASSES];
+    int iy0, ix0;
+    bool okr;
+    __device__ __forceinline__ void batch(int z) { p = base + (long long)z * Cin * H * W; }
+    __device__ __forceinline__ void set_index(int ps, int i) {
+        okp[ps] = i < ncols;
+        const int ic = min(i, ncols - 1);
+        const int ci = ic / (KH * KW), t = ic - ci * KH * KW;
+        ci_off[ps] = ci * H * W; ky[ps] = t / KW; kx[ps] = t - (t / KW) * KW;
+    }
+    __device__ __forceinline__ void set_r(int r, bool ok) { okr = ok; const int oy = r / OW; iy0 = oy * stride - pad; ix0 = (r - oy * OW) * stride - pad; }
+    __device__ __forceinline__ float load(int ps) const {
+        const int iy = iy0 + ky[ps], ix = ix0 + kx[ps];
+        const bool in = okr && okp[ps] && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const float v = p[ci_off[ps] + min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1)];
+        return in ? v : 0.0f;
+    }
+};
+
+// value(r = column j of the gathered tensor, i = node m) = sum_k w[b][j][k] * [idx[b][j][k] == m]   (w == nullptr: weights 1)
+template <int KN>
+struct RcSelect {
+    const int* idx_base;
+    const float* w_base;
+    int J, M;
+    const int* idx;
+    const float* w;
+    int m[RC_PASSES];
+    int id[KN];
+    float wk[KN];
+    __device__ __forceinline__ void batch(int z) { idx = idx_base + (long long)z * J * KN; w = w_base ? w_base + (long long)z * J * KN : nullptr; }
+    __device__ __forceinline__ void set_index(int ps, int i) { m[ps] = i < M ? i : -1; }
+    __device__ __forceinline__ void set_r(int r, bool ok) {
+#pragma unroll
+        for (int k = 0; k < KN; ++k) { id[k] = ok ? idx[(long long)r * KN + k] : -2; wk[k] = w ? w[(long long)r * KN + k] : 1.0f; }
+    }
+    __device__ __forceinline__ float load(int ps) const {
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KN; ++k) v += id[k] == m[ps] ? wk[k] : 0.0f;
+        return v;
+    }
+};
+
+template <class LA, class LB>
+__global__ __launch_bounds__(256) void rc_gemm_kernel(LA la, LB lb, int R, int rch, int chunks, float* __restrict__ partial, int rows, int cols) {
+    extern __shared__ float lds[];
+    const int z = blockIdx.z / chunks, ch = blockIdx.z % chunks;
+    la.batch(z); lb.batch(z);
+    const int r_begin = ch * rch, r_end = min(R, r_begin + rch);
+    rc_gemm_tile(lds, la, lb, r_begin, r_end, blockIdx.y * RC_BM, blockIdx.x * RC_BM, partial + (long long)blockIdx.z * rows * cols, rows, cols);
+}
+
+// out[g][e] = alpha * sum_{p < per_group} partial[g * per_group + p][e], summed in p order
+__global__ __launch_bounds__(256) void rc_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int per_group, long long elems,
+                                                        long long total, float alpha) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long g = i / elems, e = i - g * elems;
+    const float* p = partial + g * per_group * elems + e;
+    float s = 0.0f;
+    for (int k = 0; k < per_group; ++k) s += p[(long long)k * elems];
+    out[i] = alpha * s;
+}
+
+struct RcPlan { int rch, chunks; long long bytes; };
+RcPlan rc_plan(int Z, int rows, int cols, int R) {
+    RcPlan pl;
+    // enough workgroups to fill the chip, chunks of at least 256 reduction steps
+    const long long tiles = (long long)di2p_cdiv(rows, RC_BM) * di2p_cdiv(cols, RC_BM) * Z;
+    int chunks = (int)((1024 + tiles - 1) / tiles);
+    const int max_chunks = R / 256 > 1 ? R / 256 : 1;
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    pl.rch = ((di2p_cdiv(R, chunks) + RC_BK - 1) / RC_BK) * RC_BK;
+    pl.chunks = di2p_cdiv(R, pl.rch);
+    pl.bytes = (long long)Z * pl.chunks * rows * cols * 4;
+    return pl;
+}
+
+template <class LA, class LB>
+int rc_launch(const char* who, LA la, LB lb, int Z, int rows, int cols, int R, float alpha, bool reduce_z, float* out, void* ws, long long ws_bytes,
+              hipStream_t st) {
+    const RcPlan pl = rc_plan(Z, rows, cols, R);
+    if (!ws || ws_bytes < pl.bytes) { di2p_set_error("%s: workspace too small (%lld bytes needed)", who, pl.bytes); return -1; }
+    if ((long long)Z * pl.chunks > 65535) { di2p_set_error("%s: too many reduction chunks", who); return -1; }
+    const dim3 grid(di2p_cdiv(cols, RC_BM), di2p_cdiv(rows, RC_BM), Z * pl.chunks);
+    hipLaunchKernelGGL((rc_gemm_kernel<LA, LB>), grid, dim3(256), RC_LDS_FLOATS * sizeof(float), st, la, lb, R, pl.rch, pl.chunks, (float*)ws, rows, cols);
+    const long long elems = (long long)rows * cols;
+    const int per_group = reduce_z ? Z * pl.chunks : pl.chunks;
+    const long long total = reduce_z ? elems : elems * Z;
+    hipLaunchKernelGGL(rc_reduce_kernel, dim3(di2p_cdiv(total, 256)), dim3(256), 0, st, (const float*)ws, out, per_group, elems, total, alpha);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { di2p_set_error("%s: launch failed: %s", who, hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+// =============================================================================================== km-GEMM (per batch, k-major operands)
+struct KmA {
+    const float* p; int ld, K, M;
+    __device__ __forceinline__ float load(int k, int m) const { return (k < K && m < M) ? p[(long long)k * ld + m] : 0.0f; }
+};
+struct KmB {
+    const float* p; int ld, K, N, n; bool valid;
+    __device__ __forceinline__ void column(int j) { n = j; valid = j < N; }
+    __device__ __forceinline__ void begin_tile(int) {}
+    __device__ __forceinline__ float load(int k) const { return (valid && k < K) ? p[(long long)k * ld + n] : 0.0f; }
+};
+struct KmEpi {
+    float* out; int M, N; float alpha;
+    __device__ __forceinline__ void tile(int mrow0, int n, const f32x16& acc) {
+        if (n >= N) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+            if (m < M) out[(long long)m * N + n] = alpha * acc[r];
+        }
+    }
+};
+using KmCfg = TileCfg<2, 2, 1, 1, 16>;
+__global__ __launch_bounds__(KmCfg::THREADS) void bmm_km_kernel(const float* __restrict__ A, int lda, long long a_bs, const float* __restrict__ Bm, int ldb,
+                                                                long long b_bs, float* __restrict__ out, int rows, int cols, int K, float alpha) {
+    extern __shared__ float lds[];
+    const int z = blockIdx.z;
+    KmA la{A + z * a_bs, lda, K, rows};
+    KmB lb{Bm + z * b_bs, ldb, K, cols, 0, false};
+    KmEpi ep{out + (long long)z * rows * cols, rows, cols, alpha};
+    mfma_gemm_block<KmCfg>(lds, la, lb, ep, K, blockIdx.y * KmCfg::BM, blockIdx.x * KmCfg::BN);
+}
+
+// =============================================================================================== convolution: d input
+// dX[b][ci][iy][ix] = sum_{co,ky,kx} W[co][ci][ky][kx] * dY[b][co][(iy+pad-ky)/s][(ix+pad-kx)/s]   (where divisible and in range)
+struct DgradA {   // A(k = (co,ky,kx), m = ci)
+    const float* Wg; int Cin, KH, KW, K;
+    __device__ __forceinline__ float load(int k, int m) const {
+        if (k >= K || m >= Cin) return 0.0f;
+        const int co = k / (KH * KW), t = k - co * KH * KW;
+        return Wg[((long long)co * Cin + m) * KH * KW + t];
+    }
+};
+struct DgradB {   // B(k, column = input pixel)
+    const float* dy; int OH, OW, H, W, KH, KW, stride, pad, K;
+    int iy, ix; bool valid;
+    __device__ __forceinline__ void column(int j) { valid = j < H * W; const int jc = valid ? j : 0; iy = jc / W; ix = jc - iy * W; }
+    __device__ __forceinline__ void begin_tile(int) {}
+    __device__ __forceinline__ float load(int k) const {
+        if (!valid || k >= K) return 0.0f;
+        const int co = k / (KH * KW), t = k - co * KH * KW, ky = t / KW, kx = t - ky * KW;
+        const int ty = iy + pad - ky, tx = ix + pad - kx;
+        if (ty < 0 || tx < 0) return 0.0f;
+        const int oy = ty / stride, ox = tx / stride;
+        if (oy * stride != ty || ox * stride != tx || oy >= OH || ox >= OW) return 0.0f;
+        return dy[((long long)co * OH + oy) * OW + ox];
+    }
+};
+__global__ __launch_bounds__(KmCfg::THREADS) void conv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ Wg, float* __restrict__ dx,
+                                                                    int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int OH, int OW) {
+    extern __shared__ float lds[];
+    const int b = blockIdx.z, K = Cout * KH * KW;
+    DgradA la{Wg, Cin, KH, KW, K};
+    DgradB lb{dy + (long long)b * Cout * OH * OW, OH, OW, H, W, KH, KW, stride, pad, K, 0, 0, false};
+    KmEpi ep{dx + (long long)b * Cin * H * W, Cin, H * W, 1.0f};
+    mfma_gemm_block<KmCfg>(lds, la, lb, ep, K, blockIdx.y * KmCfg::BM, blockIdx.x * KmCfg::BN);
+}
+
+// =============================================================================================== per-channel reductions (BatchNorm, bias)
+// x[B][C][N]; grid (C, B * SN): block (c, s) reduces n in [chunk*per, ...) of row (b, c); fp64 partial pairs
+template <int MODE>   // 0: (sum x, sum x^2)   1: (sum g, sum g*xhat) with g = dy * [y > 0 if relu]
+__global__ __launch_bounds__(256) void channel_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd, int relu, int C, int N,
+                                                             int SN, int per, double* __restrict__ partial) {
+    __shared__ double sh[2][4];
+    const int c = blockIdx.x, s = blockIdx.y, b = s / SN, ch = s - b * SN;
+    const long long row = ((long long)b * C + c) * N;
+    const int n0 = ch * per, n1 = min(N, n0 + per);
+    double a0 = 0.0, a1 = 0.0;
+    float mu = 0.0f, is = 0.0f;
+    if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
+    for (int n = n0 + threadIdx.x; n < n1; n += 256) {
+        if (MODE == 0) {
+            const double v = x[row + n];
+            a0 += v; a1 += v * v;
+        } else {
+            float g = dy[row + n];
+            if (relu && !(y[row + n] > 0.0f)) g = 0.0f;
+            const float xh = (x[row + n] - mu) * is;
+            a0 += g; a1 += (double)g * xh;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sh[0][wave] = a0; sh[1][wave] = a1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[((long long)c * gridDim.y + s) * 2 + 0] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        partial[((long long)c * gridDim.y + s) * 2 + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    }
+}
+
+// MODE 0: batch statistics -> save_mean, save_invstd, running stats (unbiased variance, torch.nn.BatchNorm semantics)
+// MODE 1: -> dgamma = sum g*xhat, dbeta = sum g, and the two means the elementwise pass needs (sums[c] = {sum g, sum g*xhat} / count)
+// MODE 2: -> out0 = sum x (bias gradient)
+template <int MODE>
+__global__ __launch_bounds__(64) void channel_finalize_kernel(const double* __restrict__ partial, int S, int C, double count, float eps, float momentum,
+                                                              float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ run_mean,
+                                                              float* __restrict__ run_var, float* __restrict__ sums) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    double a0 = 0.0, a1 = 0.0;
+    for (int s = 0; s < S; ++s) { a0 += partial[((long long)c * S + s) * 2]; a1 += partial[((long long)c * S + s) * 2 + 1]; }
+    if (MODE == 0) {
+        const double mu = a0 / count;
+        double var = a1 / count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        out0[c] = (float)mu;
+        out1[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (run_mean) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mu);
+            run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unb);
+        }
+    } else if (MODE == 1) {
+        out0[c] = (float)a1;          // dgamma
+        out1[c] = (float)a0;          // dbeta
+        sums[2 * c] = (float)(a0 / count);
+        sums[2 * c + 1] = (float)(a1 / count);
+    } else {
+        out0[c] = (float)a0;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ res,
+                                                       float* __restrict__ y, int relu, int C, int N, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)((i / N) % C);
+    float v = (x[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+    if (res) v += res[i];
+    if (relu) v = fmaxf(v, 0.0f);
+    y[i] = v;
+}
+
+// dx = gamma * invstd * (g - mean(g) - xhat * mean(g*xhat)),  dres = g
+__global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, const float* __restrict__ sums, int relu,
+                                                                float* __restrict__ dx, float* __restrict__ dres, int C, int N, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)((i / N) % C);
+    float g = dy[i];
+    if (relu && !(y[i] > 0.0f)) g = 0.0f;
+    const float xh = (x[i] - mean[c]) * invstd[c];
+    dx[i] = gamma[c] * invstd[c] * (g - sums[2 * c] - xh * sums[2 * c + 1]);
+    if (dres) dres[i] = g;
+}
+
+struct RedPlan { int SN, per, S; long long bytes; };
+RedPlan red_plan(int B, int C, int N) {
+    RedPlan p;
+    p.SN = N / 4096; if (p.SN < 1) p.SN = 1; if (p.SN > 16) p.SN = 16;
+    p.per = di2p_cdiv(N, p.SN);
+    p.SN = di2p_cdiv(N, p.per);
+    p.S = B * p.SN;
+    p.bytes = (long long)C * p.S * 16 + (long long)C * 8;
+    return p;
+}
+
+// =============================================================================================== arg-max routers
+// 3x3 / stride 2 / pad 1 max-pool backward: the gradient of an output goes to the FIRST maximum of its window in (ky, kx)
+// scan order (max_pool2d keeps `val > maxval`); windows overlap, so the adds are atomic (<= 4 terms per input element).
+__global__ __launch_bounds__(256) void maxpool_backward_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int H, int W,
+                                                               int OH, int OW, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
+    const long long plane = i / ((long long)OW * OH);
+    const float* xp = x + plane * H * W;
+    float best = 0.0f;
+    int arg = -1;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - 1 + ky;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 - 1 + kx;
+            if (ix < 0 || ix >= W) continue;
+            const float v = xp[iy * W + ix];
+            if (arg < 0 || v > best) { best = v; arg = iy * W + ix; }
+        }
+    }
+    if (arg >= 0) atomicAdd(dx + plane * H * W + arg, dy[i]);
+}
+
+// dX[b][c][max_idx[b][c][m]] += dV[b][c][m] * mask[b][m]   (index_max + gather + mask of networks_pc.py:88-93,101-104)
+__global__ __launch_bounds__(256) void segment_max_backward_kernel(const float* __restrict__ dv, const int* __restrict__ max_idx, const float* __restrict__ mask,
+                                                                   float* __restrict__ dx, int C, int N, int M, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int m = (int)(i % M);
+    const long long bc = i / M;
+    const int b = (int)(bc / C);
+    const float w = mask ? mask[(long long)b * M + m] : 1.0f;
+    if (w == 0.0f) return;
+    const int n = max_idx[i];
+    if (n >= 0 && n < N) atomicAdd(dx + bc * N + n, dv[i] * w);
+}
+
+// y[row] = max_k x[row][k] with the first arg-max (torch.max(dim) rule on ties: lowest index)
+__global__ __launch_bounds__(256) void group_max_forward_kernel(const float* __restrict__ x, float* __restrict__ y, int* __restrict__ arg, int K, long long rows) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    const float* p = x + i * K;
+    float best = p[0];
+    int a = 0;
+    for (int k = 1; k < K; ++k) {
+        const float v = p[k];
+        if (v > best || (v != v && best == best)) { best = v; a = k; }
+    }
+    y[i] = best;
+    arg[i] = a;
+}
+__global__ __launch_bounds__(256) void group_max_backward_kernel(const float* __restrict__ dy, const int* __restrict__ arg, float* __restrict__ dx, int K, long long rows) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    dx[i * K + arg[i]] = dy[i];
+}
+
+__global__ __launch_bounds__(256) void apply_mask_kernel(const float* __restrict__ x, const unsigned char* __restrict__ mask, float scale, float* __restrict__ y, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = mask[i] ? x[i] * scale : 0.0f;
+}
+
+}  // namespace
+
+// =============================================================================================== C ABI
+extern "C" long long di2p_channel_reduce_workspace_bytes(int B, int C, int N) {
+    if (B < 1 || C < 1 || N < 1) return 0;
+    return red_plan(B, C, N).bytes;
+}
+
+extern "C" int di2p_bn_train_forward(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* save_mean,
+                                     float* save_invstd, float* running_mean, float* running_var, float momentum, float eps, int relu, int B, int C,
+                                     int N, void* workspace, void* stream) {
+    DI2P_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd && workspace, "null pointer");
+    DI2P_CHECK_ARG(B >= 1 && C >= 1 && N >= 1 && (long long)B * N >= 2, "batch statistics need at least two values per channel");
+    DI2P_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running_mean / running_var go together");
+    hipStream_t st = (hipStream_t)stream;
+    const RedPlan p = red_plan(B, C, N);
+    double* part = (double*)workspace;
+    hipLaunchKernelGGL((channel_reduce_kernel<0>), dim3(C, p.S), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, 0, C, N, p.SN, p.per, part);
+    hipLaunchKernelGGL((channel_finalize_kernel<0>), dim3(di2p_cdiv(C, 64)), dim3(64), 0, st, (const double*)part, p.S, C, (double)B * N, eps, momentum,
+                       save_mean, save_invstd, running_mean, running_var, (float*)nullptr);
+    const long long total = (long long)B * C * N;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(di2p_cdiv(total, 256)), dim3(256), 0, st, x, gamma, beta, (const float*)save_mean, (const float*)save_invstd,
+                       residual, y, relu, C, N, total);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_bn_train_backward(const float* x, const float* y, const float* dy, const float* gamma, const float* save_mean,
+                                      const float* save_invstd, int relu, float* dx, float* dresidual, float* dgamma, float* dbeta, int B, int C, int N,
+                                      void* workspace, void* stream) {
+    DI2P_CHECK_ARG(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && workspace, "null pointer");
+    DI2P_CHECK_ARG(!relu || y, "relu needs the forward output");
+    DI2P_CHECK_ARG(B >= 1 && C >= 1 && N >= 1, "bad size");
+    hipStream_t st = (hipStream_t)stream;
+    const RedPlan p = red_plan(B, C, N);
+    double* part = (double*)workspace;
+    float* sums = (float*)((char*)workspace + (long long)C * p.S * 16);
+    hipLaunchKernelGGL((channel_reduce_kernel<1>), dim3(C, p.S), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, relu, C, N, p.SN, p.per, part);
+    hipLaunchKernelGGL((channel_finalize_kernel<1>), dim3(di2p_cdiv(C, 64)), dim3(64), 0, st, (const double*)part, p.S, C, (double)B * N, 0.0f, 0.0f, dgamma,
+                       dbeta, (float*)nullptr, (float*)nullptr, sums);
+    const long long total = (long long)B * C * N;
+    hipLaunchKernelGGL(bn_backward_apply_kernel, dim3(di2p_cdiv(total, 256)), dim3(256), 0, st, x, dy, y, gamma, save_mean, save_invstd, (const float*)sums,
+                       relu, dx, dresidual, C, N, total);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_channel_sum(const float* x, float* out, int B, int C, int N, void* workspace, void* stream) {
+    DI2P_CHECK_ARG(x && out && workspace && B >= 1 && C >= 1 && N >= 1, "bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const RedPlan p = red_plan(B, C, N);
+    double* part = (double*)workspace;
+    hipLaunchKernelGGL((channel_reduce_kernel<0>), dim3(C, p.S), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, 0, C, N, p.SN, p.per, part);
+    hipLaunchKernelGGL((channel_finalize_kernel<2>), dim3(di2p_cdiv(C, 64)), dim3(64), 0, st, (const double*)part, p.S, C, 1.0, 0.0f, 0.0f, out, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" long long di2p_bmm_rc_workspace_bytes(int Z, int rows, int cols, int R) {
+    if (Z < 1 || rows < 1 || cols < 1 || R < 1) return 0;
+    return rc_plan(Z, rows, cols, R).bytes;
+}
+
+extern "C" int di2p_bmm_rc(const float* A, long long lda, long long a_batch_stride, const float* Bm, long long ldb, long long b_batch_stride, float* out,
+                           int Z, int rows, int cols, int R, float alpha, int reduce_z, void* workspace, long long workspace_bytes, void* stream) {
+    DI2P_CHECK_ARG(A && Bm && out && Z >= 1 && rows >= 1 && cols >= 1 && R >= 1, "bad args");
+    RcStrided la{}; la.base = A; la.ld = lda; la.batch_stride = a_batch_stride; la.n = rows;
+    RcStrided lb{}; lb.base = Bm; lb.ld = ldb; lb.batch_stride = b_batch_stride; lb.n = cols;
+    return rc_launch(__func__, la, lb, Z, rows, cols, R, alpha, reduce_z != 0, out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int di2p_bmm_km(const float* A, int lda, long long a_batch_stride, const float* Bm, int ldb, long long b_batch_stride, float* out, int Z,
+                           int rows, int cols, int K, float alpha, void* stream) {
+    DI2P_CHECK_ARG(A && Bm && out && Z >= 1 && rows >= 1 && cols >= 1 && K >= 1 && Z <= 65535, "bad args");
+    hipLaunchKernelGGL(bmm_km_kernel, dim3(di2p_cdiv(cols, KmCfg::BN), di2p_cdiv(rows, KmCfg::BM), Z), dim3(KmCfg::THREADS), KmCfg::LDS_FLOATS * sizeof(float),
+                       (hipStream_t)stream, A, lda, a_batch_stride, Bm, ldb, b_batch_stride, out, rows, cols, K, alpha);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" long long di2p_gather_backward_workspace_bytes(int B, int C, int J, int M) {
+    if (B < 1 || C < 1 || J < 1 || M < 1) return 0;
+    return rc_plan(B, C, M, J).bytes;
+}
+
+extern "C" int di2p_gather_backward(const float* dy, const int32_t* idx, const float* weights, int k, float* dfeats, int B, int C, int J, int M,
+                                    void* workspace, long long workspace_bytes, void* stream) {
+    DI2P_CHECK_ARG(dy && idx && dfeats && B >= 1 && C >= 1 && J >= 1 && M >= 1, "bad args");
+    DI2P_CHECK_ARG(k == 1 || k == 3, "k must be 1 (gather) or 3 (3-NN interpolation)");
+    RcStrided la{}; la.base = dy; la.ld = J; la.batch_stride = (long long)C * J; la.n = C;
+    if (k == 1) {
+        RcSelect<1> lb{}; lb.idx_base = idx; lb.w_base = weights; lb.J = J; lb.M = M;
+        return rc_launch(__func__, la, lb, B, C, M, J, 1.0f, false, dfeats, workspace, workspace_bytes, (hipStream_t)stream);
+    }
+    RcSelect<3> lb{}; lb.idx_base = idx; lb.w_base = weights; lb.J = J; lb.M = M;
+    return rc_launch(__func__, la, lb, B, C, M, J, 1.0f, false, dfeats, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" long long di2p_conv2d_wgrad_workspace_bytes(int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
+    if (B < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1 || stride < 1) return 0;
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    if (OH < 1 || OW < 1) return 0;
+    return rc_plan(B, Cout, Cin * KH * KW, OH * OW).bytes;
+}
+
+extern "C" int di2p_conv2d_wgrad(const float* x, const float* dy, float* dW, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                                 void* workspace, long long workspace_bytes, void* stream) {
+    DI2P_CHECK_ARG(x && dy && dW && B >= 1 && Cin >= 1 && Cout >= 1 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0, "bad args");
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    DI2P_CHECK_ARG(OH >= 1 && OW >= 1, "empty output");
+    RcStrided la{}; la.base = dy; la.ld = (long long)OH * OW; la.batch_stride = (long long)Cout * OH * OW; la.n = Cout;
+    RcIm2col lb{}; lb.base = x; lb.Cin = Cin; lb.H = H; lb.W = W; lb.OW = OW; lb.KH = KH; lb.KW = KW; lb.stride = stride; lb.pad = pad; lb.ncols = Cin * KH * KW;
+    return rc_launch(__func__, la, lb, B, Cout, Cin * KH * KW, OH * OW, 1.0f, true, dW, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int di2p_conv2d_dgrad(const float* dy, const float* Wgt, float* dx, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                                 void* stream) {
+    DI2P_CHECK_ARG(dy && Wgt && dx && B >= 1 && B <= 65535 && Cin >= 1 && Cout >= 1 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0, "bad args");
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    DI2P_CHECK_ARG(OH >= 1 && OW >= 1, "empty output");
+    hipLaunchKernelGGL(conv_dgrad_kernel, dim3(di2p_cdiv((long long)H * W, KmCfg::BN), di2p_cdiv(Cin, KmCfg::BM), B), dim3(KmCfg::THREADS),
+                       KmCfg::LDS_FLOATS * sizeof(float), (hipStream_t)stream, dy, Wgt, dx, Cin, H, W, Cout, KH, KW, stride, pad, OH, OW);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_maxpool3x3s2_backward(const float* x, const float* dy, float* dx, int B, int C, int H, int W, void* stream) {
+    DI2P_CHECK_ARG(x && dy && dx && B >= 1 && C >= 1 && H >= 1 && W >= 1, "bad args");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dx, 0, (size_t)B * C * H * W * 4, st) != hipSuccess) { di2p_set_error("%s: memset failed", __func__); return -1; }
+    const long long total = (long long)B * C * OH * OW;
+    hipLaunchKernelGGL(maxpool_backward_kernel, dim3(di2p_cdiv(total, 256)), dim3(256), 0, st, x, dy, dx, H, W, OH, OW, total);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_segment_max_backward(const float* dvalues, const int32_t* max_idx, const float* mask, float* dx, int B, int C, int N, int M,
+                                         void* stream) {
+    DI2P_CHECK_ARG(dvalues && max_idx && dx && B >= 1 && C >= 1 && N >= 1 && M >= 1, "bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dx, 0, (size_t)B * C * N * 4, st) != hipSuccess) { di2p_set_error("%s: memset failed", __func__); return -1; }
+    const long long total = (long long)B * C * M;
+    hipLaunchKernelGGL(segment_max_backward_kernel, dim3(di2p_cdiv(total, 256)), dim3(256), 0, st, dvalues, max_idx, mask, dx, C, N, M, total);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_group_max_forward(const float* x, float* y, int32_t* arg, long long rows, int K, void* stream) {
+    DI2P_CHECK_ARG(x && y && arg && rows >= 1 && K >= 1, "bad args");
+    hipLaunchKernelGGL(group_max_forward_kernel, dim3(di2p_cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, x, y, arg, K, rows);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_group_max_backward(const float* dy, const int32_t* arg, float* dx, long long rows, int K, void* stream) {
+    DI2P_CHECK_ARG(dy && arg && dx && rows >= 1 && K >= 1, "bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dx, 0, (size_t)rows * K * 4, st) != hipSuccess) { di2p_set_error("%s: memset failed", __func__); return -1; }
+    hipLaunchKernelGGL(group_max_backward_kernel, dim3(di2p_cdiv(rows, 256)), dim3(256), 0, st, dy, arg, dx, K, rows);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_apply_mask(const float* x, const uint8_t* mask, float scale, float* y, long long n, void* stream) {
+    DI2P_CHECK_ARG(x && mask && y && n >= 0, "bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(apply_mask_kernel, dim3(di2p_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (const unsigned char*)mask, scale, y, n);
+    DI2P_RETURN_LAUNCH();
+}

@@ -10,8 +10,8 @@ as the reference, so a released checkpoint loads unchanged:
   KeypointDetector                 models/networks_united.py:14-210
   MMClassifer / MMClassiferCoarse  models/multimodal_classifier.py:25-117, :380-469 (inference part)
 
-Only inference (eval mode) is implemented: BatchNorm uses running statistics, dropout is identity.
-The modules hold the reference's parameters verbatim; ``_pack()`` derives the kernel operands once
+The module forwards here are the inference (eval-mode) path: BatchNorm uses running statistics, dropout is
+identity; the train-mode forward and the backward live in train_net.py / training.py.  The modules hold the reference's parameters verbatim; ``_pack()`` derives the kernel operands once
 per load (weights transposed to [K,M]; BN folded to scale/shift; concatenated inputs that are
 broadcasts folded into per-frame bias vectors; per_point_pn layer 0 split so that the interpolated
 inputs are contracted per NODE instead of per POINT -- W*sum_k w_k f_k == sum_k w_k (W f_k)).
@@ -414,7 +414,8 @@ def model_state_dict_convert_auto(sd):
 
 
 class MMClassifer:
-    """Inference part of models/multimodal_classifier.py:25-117 (coarse + fine)."""
+    """models/multimodal_classifier.py:25-225 (coarse + fine): inference_pass, and optimize / test_model through
+    deepi2p_amd.training.ClassifierTrainer (train-mode forward + backward on the HIP kernels, Adam)."""
 
     fine = True
 
@@ -443,6 +444,26 @@ class MMClassifer:
 
     def forward(self, pc, intensity, sn, node_a, node_b, img):
         return self.detector(pc, intensity, sn, node_a, node_b, img)
+
+    def _trainer(self):
+        if getattr(self, "_trainer_obj", None) is None:
+            from .training import ClassifierTrainer
+            self._trainer_obj = ClassifierTrainer(self.detector, self.opt)
+        return self._trainer_obj
+
+    def _record(self, L, prefix):
+        setattr(self, prefix + "_loss_dict", {"loss": L["loss"], "coarse": L["coarse"], "fine": L["fine"]})
+        setattr(self, prefix + "_accuracy", {"coarse_accuracy": L["coarse_accuracy"], "fine_accuracy": L["fine_accuracy"]})
+
+    def optimize(self):
+        """multimodal_classifier.py:213-218: train(), zero_grad, foraward_pass, backward, optimizer step."""
+        self.detector.train()
+        self._record(self._trainer().optimize(self.pc, self.intensity, self.sn, self.node_a, self.node_b, self.img, self.K, self.P), "train")
+
+    def test_model(self):
+        """multimodal_classifier.py:220-223: eval-mode losses and accuracies."""
+        self._record(self._trainer().test_model(self.pc, self.intensity, self.sn, self.node_a, self.node_b, self.img, self.K, self.P), "test")
+        self.detector.eval()
 
     def inference_labels(self):
         """Device-resident variant of inference_pass: coarse argmax as i32 [B,N] (what the solver consumes)."""

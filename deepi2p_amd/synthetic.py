@@ -200,3 +200,28 @@ def synthetic_state_dict(opt, seed=0):
             v = 0.05 * base
         sd[key] = v.to(torch.float32).reshape(shape)
     return sd
+
+
+def random_state_dict(opt, seed=0):
+    """He-normal weights, BN gamma in [0.9, 1.1], small biases, fresh running buffers: a freshly initialised network as the
+    reference's constructors leave it (layers_pc.py:308-323, resnet.py:148-160), drawn from a seeded CPU generator (the
+    training-parity fixtures use it: train-mode gradients of the closed-form weights above are ill-conditioned in fp32)."""
+    gen = torch.Generator().manual_seed(seed)
+    sd = {}
+    for key, shape in state_dict_spec(opt):
+        if key.endswith("num_batches_tracked"):
+            sd[key] = torch.tensor(0, dtype=torch.long)
+        elif key.endswith("running_var"):
+            sd[key] = torch.ones(shape)
+        elif key.endswith("running_mean"):
+            sd[key] = torch.zeros(shape)
+        elif len(shape) >= 2:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            sd[key] = torch.randn(shape, generator=gen) * math.sqrt(2.0 / fan_in)
+        elif key.endswith("weight"):
+            sd[key] = 1.0 + 0.2 * (torch.rand(shape, generator=gen) - 0.5)
+        else:
+            sd[key] = 0.1 * torch.randn(shape, generator=gen)
+    return sd

@@ -1,4 +1,4 @@
-"""Training-side pieces on the device (first slice of SURVEY.md 8f rank 4).
+"""Training on the device.
 
 classifier_loss        losses + d loss / d scores of models/multimodal_classifier.py:189-191 (FocalLoss of models/focal_loss.py:55-112
                        for the coarse head, cross-entropy over the inside points for the fine head) and the accuracies (:195-201)
@@ -6,12 +6,12 @@ adam_step              torch.optim.Adam as the reference builds it (multimodal_c
 allreduce_gradients    the data-parallel gradient exchange (replaces nn.DataParallel's gather/reduce, :37-38): ONE all-reduce of a
                        flat fp32 buffer over RCCL (or gloo in the CPU tests), averaged
 
-The backward of the network itself (dgrad/wgrad of the contractions, train-mode BatchNorm, the fused gather / segment-max
-epilogues) is NOT built: this module is the part of a training step that sits after the logits and after the gradients.
+ClassifierTrainer      MMClassifer.optimize / test_model (models/multimodal_classifier.py:119-225): labels by projection, train-mode
+                       forward and backward on the HIP kernels (deepi2p_amd/train_net.py), gradient all-reduce, Adam
 """
 import torch
 
-from . import _lib
+from . import _lib, ops, prep, train_net
 from ._lib import call, ptr, require_cuda, stream
 
 
@@ -58,3 +58,79 @@ def allreduce_gradients(flat_grads, group=None):
     dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
     flat_grads.div_(dist.get_world_size(group))
     return flat_grads
+
+
+class ClassifierTrainer:
+    """One optimisation step of the reference's MMClassifer (multimodal_classifier.py:213-218) for a
+    deepi2p_amd.networks.KeypointDetector on the device.
+
+    All parameters are re-seated as views of ONE flat fp32 buffer (and their gradients as views of one flat gradient buffer): the
+    data-parallel exchange is a single all-reduce and the optimiser a single launch.  `optimize` returns device scalars; nothing
+    synchronises with the host."""
+
+    def __init__(self, detector, opt, lr=None, betas=(0.9, 0.999), group=None, seed=0):
+        self.detector, self.opt, self.group, self.seed, self.steps = detector, opt, group, int(seed), 0
+        params = [p for _, p in detector.named_parameters()]
+        if not params or not params[0].is_cuda:
+            raise RuntimeError("the detector must live on a GPU")
+        n = sum(p.numel() for p in params)
+        dev = params[0].device
+        self.flat = torch.empty((n,), dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros((n,), dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                self.flat[off:off + k].copy_(p.data.reshape(-1))
+                p.data = self.flat[off:off + k].view(p.shape)
+                p.requires_grad_(True)
+                p.grad = self.flat_grad[off:off + k].view(p.shape)
+                off += k
+        self.adam = FlatAdam(self.flat, lr=getattr(opt, "lr", 1e-3) if lr is None else lr, betas=betas)
+
+    def tensors(self):
+        P = dict(self.detector.named_parameters())
+        P.update(dict(self.detector.named_buffers()))
+        return P
+
+    def labels(self, pc, P_gt, K, H, W):
+        return prep.project_labels(pc, P_gt, K, H, W, getattr(self.opt, "img_fine_resolution_scale", 32))
+
+    def forward_pass(self, pc, intensity, sn, node_a, node_b, img, K, P_gt, train=True, dropouts="draw", want_grads=True):
+        """foraward_pass (sic) of the reference (:119-211): scores, labels, losses, accuracies.  train=False is test_model's
+        eval-mode pass (:220-223) on the inference kernels."""
+        B, N = pc.shape[0], pc.shape[2]
+        H, W = img.shape[2], img.shape[3]
+        coarse_labels, fine_labels = self.labels(pc, P_gt, K, H, W)
+        fine_on = bool(getattr(self.opt, "is_fine_resolution", True))
+        if train:
+            P = self.tensors()
+            if dropouts == "draw":
+                c0, c1 = train_net.head_widths(P)
+                dropouts = [train_net.dropout_mask((B, c, N), 0.5, self.seed, 2 * self.steps + i, pc.device) for i, c in enumerate((c0, c1))]
+            scores = train_net.keypoint_detector(P, self.opt, pc, intensity, sn, node_a, node_b, img, dropouts)
+        else:
+            with torch.no_grad():
+                out = self.detector(pc, intensity, sn, node_a, node_b, img)
+            scores = torch.cat(out, dim=1) if fine_on else out
+        coarse = scores[:, 0:2].contiguous()
+        fine = scores[:, 2:].contiguous() if fine_on else None
+        L = classifier_loss(coarse.detach(), coarse_labels, fine.detach() if fine is not None else None, fine_labels if fine_on else None,
+                            coarse_loss_alpha=getattr(self.opt, "coarse_loss_alpha", 50.0), want_grads=want_grads and train)
+        L["coarse_labels"], L["fine_labels"] = coarse_labels, fine_labels
+        return scores, L
+
+    def optimize(self, pc, intensity, sn, node_a, node_b, img, K, P_gt, dropouts="draw"):
+        self.flat_grad.zero_()
+        scores, L = self.forward_pass(pc, intensity, sn, node_a, node_b, img, K, P_gt, True, dropouts)
+        d = L["d_coarse"] if L["d_fine"] is None else torch.cat((L["d_coarse"], L["d_fine"]), dim=1)
+        scores.backward(d)
+        allreduce_gradients(self.flat_grad, self.group)
+        self.adam.step(self.flat_grad)
+        self.steps += 1
+        self.detector._invalidate()          # the packed inference operands (folded BN, transposed weights) are stale now
+        return L
+
+    def test_model(self, pc, intensity, sn, node_a, node_b, img, K, P_gt):
+        self.detector.eval()
+        return self.forward_pass(pc, intensity, sn, node_a, node_b, img, K, P_gt, train=False, want_grads=False)[1]

@@ -290,7 +290,7 @@ long long di2p_random_choice_workspace_bytes(int B, int n_src);
 int di2p_random_choice(unsigned long long seed, int stream_id, int B, int n_src, int n_out, int32_t* idx_out, void* workspace,
                        void* stream);
 
-/* ---- training-side head (first slice of SURVEY.md 8f rank 4; the backward of the network itself is not built) ----------------
+/* ---- training-side head (losses and optimiser; the backward kernels follow below) ----------------
  * di2p_classifier_loss: the losses of models/multimodal_classifier.py:189-191 and d loss / d scores in one pass:
  *   coarse f32[B,2,N] with FocalLoss(alpha, gamma, 'mean') * coarse_loss_alpha (models/focal_loss.py:55-112), fine f32[B,L,N]
  *   (or NULL) with mean cross-entropy over the points whose coarse label is 1; labels i32[B,N] (di2p_project_labels).
@@ -303,6 +303,54 @@ int di2p_classifier_loss(const float* coarse, const float* fine, const int32_t* 
                          float* d_coarse, float* d_fine, void* workspace, void* stream);
 int di2p_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step, float lr,
                    float beta1, float beta2, float eps, void* stream);
+
+/* ---- training: backward kernels and train-mode BatchNorm (replaces the torch.autograd backward of
+ *      models/multimodal_classifier.py:213-218).  All tensors f32, [B,C,N] (or NCHW with N = H*W), contiguous. ----------------------
+ * di2p_bn_train_forward: nn.BatchNorm1d/2d in train mode (layers_pc.py:283,150-160; resnet.py:44-70): batch mean / biased variance over
+ *   (B,N), y = relu?((x-mean)*invstd*gamma + beta + residual?); running stats updated with `momentum` and the unbiased variance
+ *   (running_* may both be NULL).  workspace: di2p_channel_reduce_workspace_bytes(B, C, N).
+ * di2p_bn_train_backward: g = dy * [y > 0] (relu) ; dgamma = sum g*xhat, dbeta = sum g, dx = gamma*invstd*(g - mean g - xhat*mean(g*xhat)),
+ *   dresidual = g (may be NULL).
+ * di2p_channel_sum: out[c] = sum_{b,n} x[b,c,n] (bias gradients).
+ * di2p_bmm_rc: out[z][row][col] = alpha * sum_r A[z][row*lda + r] * B[z][col*ldb + r]  (both operands contiguous along the reduction:
+ *   d W[M][K] = sum_{b,n} dY[b][m][n] X[b][k][n] with reduce_z = 1; attention d feat with reduce_z = 0).  Deterministic chunked reduction;
+ *   workspace: di2p_bmm_rc_workspace_bytes(Z, rows, cols, R).
+ * di2p_bmm_km: out[z][row][col] = alpha * sum_k A[z][k*lda + row] * B[z][k*ldb + col]  (attention d score).
+ * di2p_gather_backward: d feats[b,c,m] = sum_j dy[b,c,j] * sum_k w[b,j,k] * [idx[b,j,k] == m]; k = 1 (torch.gather along the point axis,
+ *   weights NULL = 1) or k = 3 (upsample_by_interpolation, networks_united.py:90-103).  workspace: di2p_gather_backward_workspace_bytes.
+ * di2p_conv2d_wgrad / di2p_conv2d_dgrad: gradients of nn.Conv2d (bias-free; resnet.py) w.r.t. weight[Cout][Cin][KH][KW] and input.
+ * di2p_maxpool3x3s2_backward, di2p_segment_max_backward (index_max + gather + mask, networks_pc.py:88-93), di2p_group_max_forward /
+ *   _backward (max over the last axis with its first arg-max): the gradient goes to the arg-max element.
+ * di2p_dropout_mask / di2p_apply_mask: nn.Dropout keep-mask from the counter-based generator (a function of seed, stream_id, index)
+ *   and y = mask ? x*scale : 0. */
+long long di2p_channel_reduce_workspace_bytes(int B, int C, int N);
+int di2p_bn_train_forward(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* save_mean,
+                          float* save_invstd, float* running_mean, float* running_var, float momentum, float eps, int relu, int B, int C,
+                          int N, void* workspace, void* stream);
+int di2p_bn_train_backward(const float* x, const float* y, const float* dy, const float* gamma, const float* save_mean,
+                           const float* save_invstd, int relu, float* dx, float* dresidual, float* dgamma, float* dbeta, int B, int C, int N,
+                           void* workspace, void* stream);
+int di2p_channel_sum(const float* x, float* out, int B, int C, int N, void* workspace, void* stream);
+long long di2p_bmm_rc_workspace_bytes(int Z, int rows, int cols, int R);
+int di2p_bmm_rc(const float* A, long long lda, long long a_batch_stride, const float* Bm, long long ldb, long long b_batch_stride, float* out,
+                int Z, int rows, int cols, int R, float alpha, int reduce_z, void* workspace, long long workspace_bytes, void* stream);
+int di2p_bmm_km(const float* A, int lda, long long a_batch_stride, const float* Bm, int ldb, long long b_batch_stride, float* out, int Z,
+                int rows, int cols, int K, float alpha, void* stream);
+long long di2p_gather_backward_workspace_bytes(int B, int C, int J, int M);
+int di2p_gather_backward(const float* dy, const int32_t* idx, const float* weights, int k, float* dfeats, int B, int C, int J, int M,
+                         void* workspace, long long workspace_bytes, void* stream);
+long long di2p_conv2d_wgrad_workspace_bytes(int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad);
+int di2p_conv2d_wgrad(const float* x, const float* dy, float* dW, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                      void* workspace, long long workspace_bytes, void* stream);
+int di2p_conv2d_dgrad(const float* dy, const float* Wgt, float* dx, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                      void* stream);
+int di2p_maxpool3x3s2_backward(const float* x, const float* dy, float* dx, int B, int C, int H, int W, void* stream);
+int di2p_segment_max_backward(const float* dvalues, const int32_t* max_idx, const float* mask, float* dx, int B, int C, int N, int M,
+                              void* stream);
+int di2p_group_max_forward(const float* x, float* y, int32_t* arg, long long rows, int K, void* stream);
+int di2p_group_max_backward(const float* dy, const int32_t* arg, float* dx, long long rows, int K, void* stream);
+int di2p_dropout_mask(unsigned long long seed, int stream_id, float p, long long n, uint8_t* mask, void* stream);
+int di2p_apply_mask(const float* x, const uint8_t* mask, float scale, float* y, long long n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,11 @@ where /root/reference exists):   python tests/golden/make_golden.py
                          reduced to checksums/percentiles")
   loss_golden.npz        the reference's models/focal_loss.py (imported) + torch CrossEntropyLoss assembled as
                          models/multimodal_classifier.py:169-191: loss values, accuracies and AUTOGRAD gradients w.r.t. the scores
+  training_golden.npz    the imported reference KeypointDetector in TRAIN mode (batch-statistics BatchNorm, Dropout(0.5) in per_point_pn
+                         with recorded keep-masks: torch.nn.functional.dropout is replaced by a mask multiply for the run) + the
+                         reference's FocalLoss / CrossEntropyLoss assembled as foraward_pass does, then loss.backward():
+                         train-mode scores (sub-sampled), losses, and for EVERY parameter the gradient's (l2, sum, abs-max) and 16
+                         sampled entries, plus the BatchNorm running buffers after the step (B=2, N=1024, 64x128, coarse+fine)
 Fixtures hold data only (inputs + expected outputs), never reference source.
 """
 import ast
@@ -206,6 +211,109 @@ def make_losses():
     print("loss_golden.npz written", {k: float(v) for k, v in out.items() if k.endswith("_loss")})
 
 
+TRAIN_SAMPLES = 16
+TRAIN_WEIGHT_SEED = 3          # deepi2p_amd.synthetic.random_state_dict(opt, 3)
+
+
+def grad_digest(t):
+    """(l2, sum, abs-max) in float64 and TRAIN_SAMPLES entries at evenly spaced flat positions."""
+    a = t.detach().double().reshape(-1)
+    pos = torch.linspace(0, a.numel() - 1, TRAIN_SAMPLES).long()
+    return np.array([float(a.norm()), float(a.sum()), float(a.abs().max())]), a[pos].numpy()
+
+
+def training_labels(pc, H, W, scale=32):
+    """Coarse / fine labels of models/multimodal_classifier.py:135-156 for P = identity, K = [[0.7W,0,W/2],[0,0.7W,H/2],[0,0,1]]
+    (inputs of the loss; stored in the fixture)."""
+    fx = 0.7 * W
+    z = pc[:, 2]
+    px = fx * pc[:, 0] / z + W / 2
+    py = fx * pc[:, 1] / z + H / 2
+    inside = (px >= 0) & (px <= W - 1) & (py >= 0) & (py <= H - 1) & (z > 0.1)
+    Wf = int(round(W / scale))
+    fine = torch.floor(px / scale).long() + torch.floor(py / scale).long() * Wf
+    return inside.long(), torch.where(inside, fine, torch.zeros_like(fine))
+
+
+def run_training_reference(det, inputs, clab, flab, masks, focal_module, coarse_loss_alpha=50.0):
+    """One train-mode forward + backward of the imported reference detector with the given dropout keep-masks."""
+    import torch.nn.functional as F
+    queue = list(masks)
+    real = F.dropout
+
+    def fixed_dropout(x, p=0.5, training=True, inplace=False):
+        if not training or p == 0:
+            return x
+        m = queue.pop(0)
+        return x * m.to(x.dtype) / (1.0 - p)
+
+    F.dropout = fixed_dropout
+    try:
+        det.train()
+        det.zero_grad()
+        coarse, fine = det(*inputs)
+        B, L, N = fine.shape
+        closs = focal_module.FocalLoss(alpha=0.5, gamma=2, reduction="mean")(coarse, clab) * coarse_loss_alpha
+        inside_Bn = clab.reshape(B * N).to(torch.int32)
+        insider_num = int(inside_Bn.sum())
+        _, idx = torch.sort(inside_Bn, descending=True)
+        insider_idx = idx[:insider_num]
+        flab_in = torch.gather(flab.view(B * N), 0, insider_idx)
+        fs = fine.permute(0, 2, 1).reshape(B * N, L).contiguous()
+        fs_in = torch.gather(fs, 0, insider_idx.unsqueeze(1).expand(insider_num, L))
+        floss = torch.nn.CrossEntropyLoss()(fs_in, flab_in)
+        loss = closs + floss
+        loss.backward()
+    finally:
+        F.dropout = real
+    assert not queue, "dropout was called fewer times than masks were provided"
+    return coarse, fine, loss, closs, floss
+
+
+def make_training():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_focal_loss", os.path.join(REF, "models", "focal_loss.py"))
+    fl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fl)
+    B, N, H, W = 2, 1024, 64, 128
+    opt = rn.make_opt(N, H, W, True, B=B)
+    det = rn.load_reference_detector(opt)
+    det.load_state_dict(nt.random_state_dict(nt.OptLike(N, H, W, True), TRAIN_WEIGHT_SEED))
+    inputs = network_inputs(7, B, N, H, W)
+    clab, flab = training_labels(inputs[0], H, W)
+    g = torch.Generator().manual_seed(11)
+    widths = [det.per_point_pn.layers[0].conv.out_channels, det.per_point_pn.layers[1].conv.out_channels]
+    masks = [(torch.rand(B, c, N, generator=g) >= 0.5) for c in widths]
+    coarse, fine, loss, closs, floss = run_training_reference(det, inputs, clab, flab, masks, fl)
+    out = {"meta": np.array([B, N, H, W, 1, TRAIN_WEIGHT_SEED], dtype=np.int32), "coarse_labels": clab.numpy().astype(np.int32),
+           "fine_labels": flab.numpy().astype(np.int32), "loss": np.float64(loss.item()), "coarse_loss": np.float64(closs.item()),
+           "fine_loss": np.float64(floss.item()), "coarse_sub": coarse.detach().numpy()[:, :, ::8].copy(),
+           "fine_sub": fine.detach().numpy()[:, :, ::8].copy()}
+    for i, m in enumerate(masks):
+        out["mask%d" % i] = np.packbits(m.numpy().astype(np.uint8).reshape(-1))
+        out["mask%d_shape" % i] = np.array(m.shape, dtype=np.int32)
+    names, dig, samp = [], [], []
+    unused = []
+    for k, p in det.named_parameters():
+        if p.grad is None:          # parameters the forward never touches get no gradient from the reference either
+            unused.append(k)
+            continue
+        d, sm = grad_digest(p.grad)
+        names.append(k); dig.append(d); samp.append(sm)
+    out["unused_params"] = np.array(unused)
+    out["param_names"] = np.array(names)
+    out["grad_digest"] = np.stack(dig)
+    out["grad_samples"] = np.stack(samp)
+    bn, bd = [], []
+    for k, b in det.named_buffers():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            bn.append(k); bd.append(grad_digest(b)[0])
+    out["buffer_names"] = np.array(bn)
+    out["buffer_digest"] = np.stack(bd)
+    np.savez_compressed(os.path.join(HERE, "training_golden.npz"), **out)
+    print("training_golden.npz written: loss", loss.item(), "inside", int(clab.sum()), "params", len(names))
+
+
 def _extract_functions(path, names):
     src = open(path).read()
     tree = ast.parse(src)
@@ -290,6 +398,9 @@ if __name__ == "__main__":
     if only == "losses":
         make_losses()
         sys.exit(0)
+    if only == "training":
+        make_training()
+        sys.exit(0)
     make_index_max()
     make_network(True, "network_golden.npz")
     make_network(False, "network_coarse_golden.npz")
@@ -297,3 +408,4 @@ if __name__ == "__main__":
     make_prep()
     make_fullsize()
     make_losses()
+    make_training()
