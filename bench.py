@@ -84,7 +84,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", choices=("frames", "hyp"), default="frames")
+    ap.add_argument("--mode", choices=("frames", "hyp", "train"), default="frames",
+                    help="frames: the headline (BASELINE configs[1]); hyp: configs[4], hypotheses sharded over the ranks; "
+                         "train: one optimisation step of the classifier (SURVEY 8f rank 4), data-parallel with one gradient all-reduce")
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (frames: 32, hyp: 16 in total)")
     ap.add_argument("--points", type=int, default=None)
     ap.add_argument("--restarts", type=int, default=None)
@@ -179,6 +181,9 @@ def main():
     maybe_spawn(args)
     if args.launch_selftest:
         launch_selftest(args)
+        return
+    if args.mode == "train":
+        main_train(args)
         return
     import numpy as np
     import torch
@@ -446,6 +451,86 @@ def main():
             "pose_check": pose_check(out, batch),
         }
         print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main_train(args):
+    """--mode train: K optimisation steps of the reference's training configuration (kitti/options.py: batch 8 per GPU, 20480 points,
+    160x512, coarse + fine heads, Adam lr 1e-3) -- train-mode forward, losses, backward, ONE all-reduce of the flat gradient buffer,
+    Adam -- all on the HIP kernels (deepi2p_amd/train_net.py).  Not the headline metric: a separate line for SURVEY.md 8f rank 4."""
+    import numpy as np
+    import torch
+    rank, local_rank, world, backend, dist = init_dist(args)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from deepi2p_amd import _lib, synthetic
+    from deepi2p_amd.networks import KeypointDetector
+    from deepi2p_amd.training import ClassifierTrainer
+
+    B, N, H, W = args.batch or 8, args.points or 20480, 160, 512
+    opt = synthetic.OptLike(N, H, W, True)
+    opt.lr, opt.coarse_loss_alpha = 1e-3, 50.0
+    det = KeypointDetector(opt)
+    det.load_state_dict(synthetic.random_state_dict(opt, 0))
+    det = det.to(dev)
+    bcast_bytes = broadcast_weights(det, dist, backend) if world > 1 else 0
+    tr = ClassifierTrainer(det, opt, seed=rank)
+    b = synthetic.make_batch(2000 + rank, B, N=N, H=H, W=W)
+    t = [torch.from_numpy(np.ascontiguousarray(b[k])).to(dev) for k in ("pc", "intensity", "sn", "node_a", "node_b", "img")]
+    K = torch.from_numpy(b["K"]).float().to(dev)
+    Pgt = torch.from_numpy(np.ascontiguousarray(b["P_gt"][:, :3, :])).float().to(dev)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    losses = []
+    for _ in range(args.warmup):
+        losses.append(tr.optimize(*t, K, Pgt)["loss"])
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(tr.optimize(*t, K, Pgt)["loss"])
+    sync_all()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # the gradient exchange on its own (one all-reduce of the flat fp32 buffer), and a serial pass with events around every C-ABI call
+    ar_ms = None
+    if world > 1:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sync_all()
+        e0.record()
+        for _ in range(5):
+            dist.all_reduce(tr.flat_grad)
+        e1.record()
+        torch.cuda.synchronize()
+        ar_ms = e0.elapsed_time(e1) / 5
+    _lib.TIMED = {name: [] for name in _lib._SIGS}
+    tr.optimize(*t, K, Pgt)
+    torch.cuda.synchronize()
+    fam = {k: (sum(a.elapsed_time(c) for a, c, _ in v), len(v)) for k, v in _lib.TIMED.items() if v}
+    _lib.TIMED = None
+    if rank == 0:
+        top = sorted(fam.items(), key=lambda kv: -kv[1][0])[:10]
+        line = {"metric": "training frames/sec (train-mode fwd + focal/CE loss + bwd + gradient all-reduce + Adam) KITTI 20k-pt 160x512, batch %d per GPU" % B,
+                "value": B * world * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32 (fp32-input MFMA contractions, fp64 BatchNorm/bias reductions)", "data": "synthetic frames, seeded He-normal initial weights",
+                "config": {"workload": "reference training configuration kitti/options.py:20-60 (batch 8, 20480 pts, 160x512, coarse+fine, Adam 1e-3)",
+                           "mode": "train", "frames_per_gpu_per_step": B, "points": N, "image": [H, W], "parallelism": "dp%d" % world,
+                           "weights_broadcast_bytes": bcast_bytes},
+                "gradient_allreduce": {"bytes": int(tr.flat_grad.numel() * 4), "ms": ar_ms, "launches_per_step": 1},
+                "loss_first_last": [float(losses[0]), float(losses[-1])],
+                "calls_ms_per_step": {k: {"ms": round(v[0], 3), "calls": v[1]} for k, v in top},
+                "note": "calls_ms_per_step: HIP events around every C-ABI call of one extra serial step (ATen views/concatenations excluded)"}
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -102,13 +102,21 @@ def _unit_affine(C, device):
     return _UNIT[key]
 
 
+def _conv_forward(x, W, stride, pad):
+    """conv2d through the inference engine with an identity epilogue; Cin % 16 == 0 takes its tap-major (16-byte staged) path."""
+    Cout, Cin, KH, KW = W.shape
+    one, zero = _unit_affine(Cout, x.device)
+    if Cin % 16 == 0:
+        return ops.conv2d(x, W.permute(2, 3, 1, 0).reshape(-1, Cout).contiguous(), one, zero, KH, KW, stride, pad, False, tap_major=True)
+    return ops.conv2d(x, W.reshape(Cout, -1).t().contiguous(), one, zero, KH, KW, stride, pad, False)
+
+
 class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x, W, stride, pad):
         x = _c(x)
         Cout, Cin, KH, KW = W.shape
-        one, zero = _unit_affine(Cout, x.device)
-        y = ops.conv2d(x, W.reshape(Cout, -1).t().contiguous(), one, zero, KH, KW, stride, pad, False)
+        y = _conv_forward(x, W, stride, pad)
         ctx.save_for_backward(x, W)
         ctx.cfg = (stride, pad)
         return y
@@ -123,8 +131,13 @@ class _Conv2d(Function):
         lib = _lib.load()
         dx = dW = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            call("di2p_conv2d_dgrad", ptr(dy), ptr(_c(W)), ptr(dx), B, Cin, H, Wd, Cout, KH, KW, stride, pad, stream())
+            if stride == 1 and KH == KW and 2 * pad == KH - 1:
+                # a stride-1 "same" convolution's input gradient is the convolution of dY with the flipped, channel-transposed filter:
+                # the forward engine does it (the strided layers go through the generic gather-form kernel)
+                dx = _conv_forward(dy, W.flip(2, 3).transpose(0, 1), 1, pad)
+            else:
+                dx = torch.empty_like(x)
+                call("di2p_conv2d_dgrad", ptr(dy), ptr(_c(W)), ptr(dx), B, Cin, H, Wd, Cout, KH, KW, stride, pad, stream())
         if ctx.needs_input_grad[1]:
             dW = torch.empty_like(W, memory_format=torch.contiguous_format)
             nb = lib.di2p_conv2d_wgrad_workspace_bytes(B, Cin, H, Wd, Cout, KH, KW, stride, pad)
