@@ -22,9 +22,9 @@ def camera_matrix_scaling(K, s):
 
 
 def draw_samples(rng, F, iters):
-    """RANSAC draws: i32[F, iters, 6]; each entry is reduced modulo the frame's correspondence count on the device.
-    Entries of one sample are distinct offsets of a random base, so they stay distinct after the modulo whenever the
-    frame has >= 6 correspondences... (distinctness is not required for correctness, degenerate samples are rejected)."""
+    """RANSAC draws: i32[F, iters, 6] INDEPENDENT uniform integers; the device reduces each modulo the frame's correspondence
+    count.  A sample may therefore repeat a correspondence (likely only for frames with a handful of them); such samples are
+    rejected as degenerate by the estimators, which lowers the effective iteration count for those frames but is never wrong."""
     return rng.integers(0, 2 ** 30, size=(F, iters, SAMPLE_SIZE), dtype=np.int64).astype(np.int32)
 
 
