@@ -44,6 +44,10 @@ enum Di2pOption {
     DI2P_OPT_SOLVER_NOCULL,         // 1: classify every cluster per point (bit-identical by construction)
     DI2P_OPT_SOLVER_NOPREFILTER,    // 1: skip the fp32 pre-filter of the per-point classification (bit-identical by construction)
     DI2P_OPT_SOLVER_TIER_SWEEPS,    // sweeps after which a hypothesis is handed to the wide (16-wave) tail kernel; 0 = never
+    DI2P_OPT_WINO_COB,              // 32 / 64: force the output-channel block of the Winograd convolution (0: by grid size)
+    DI2P_OPT_CONV_NOWINOGRAD,       // 1: the host layer runs 3x3 stride-1 convolutions on the direct implicit-GEMM kernel (read by networks.py)
+    DI2P_OPT_WINO_DB,               // 1 (default): double-buffered operand panels in the Winograd convolution; 0: single (measured slower)
+    DI2P_OPT_WINO_MAP,              // workgroup -> XCD mapping of the Winograd convolution: 0 automatic, 1 by tile block, 2 by co-block
     DI2P_OPT_COUNT
 };
 long long di2p_opt(int id);

@@ -283,6 +283,11 @@ class ImageEncoder(_PackedModule):
                            "stride": 2 if (bi == 0 and li > 1) else 1, "last_of_stage": bi == nb - 1, "stage": li}
                     if (q + ".downsample.0.weight") in sd:
                         blk["ds"] = _fold(sd, q + ".downsample.0", q + ".downsample.1", True)
+                    # 3x3 stride-1 layers: Winograd-domain weights U[16][Cin][Cout] for di2p_conv3x3_winograd (device tensors only)
+                    for name in ("conv1", "conv2"):
+                        w = sd[q + "." + name + ".weight"]
+                        if w.is_cuda and (name == "conv2" or blk["stride"] == 1):
+                            blk["U" + name[-1]] = ops.winograd_weights(w)
                     p["blocks"].append(blk)
             self._packed = p
         return self._packed
@@ -294,15 +299,22 @@ class ImageEncoder(_PackedModule):
         x = ops.conv2d(x, Wt, sc, sh, 7, 7, 2, 3, True)
         x = ops.maxpool3x3s2(x)
         stage_out = {}
+        wino = not _lib.get_option("conv_nowinograd")
         for blk in p["blocks"]:
             identity = x
             Wt, sc, sh, _ = blk["c1"]
-            y = ops.conv2d(x, Wt, sc, sh, 3, 3, blk["stride"], 1, True, tap_major=True)
+            if wino and "U1" in blk:
+                y = ops.conv3x3_winograd(x, blk["U1"], sc, sh, True)
+            else:
+                y = ops.conv2d(x, Wt, sc, sh, 3, 3, blk["stride"], 1, True, tap_major=True)
             if "ds" in blk:
                 Wd, sd_, shd, _ = blk["ds"]
                 identity = ops.conv2d(x, Wd, sd_, shd, 1, 1, blk["stride"], 0, False, tap_major=True)
             Wt, sc, sh, _ = blk["c2"]
-            x = ops.conv2d(y, Wt, sc, sh, 3, 3, 1, 1, True, residual=identity, tap_major=True)
+            if wino and "U2" in blk:
+                x = ops.conv3x3_winograd(y, blk["U2"], sc, sh, True, residual=identity)
+            else:
+                x = ops.conv2d(y, Wt, sc, sh, 3, 3, 1, 1, True, residual=identity, tap_major=True)
             if blk["last_of_stage"]:
                 stage_out[blk["stage"]] = x
         return stage_out[3], stage_out[4], ops.global_avgpool(stage_out[4])

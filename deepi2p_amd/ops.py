@@ -268,6 +268,32 @@ def conv2d(x, Wt, scale, shift, KH, KW, stride, pad, relu, residual=None, tap_ma
     return y
 
 
+def winograd_weights(weight):
+    """weight f32[Cout,Cin,3,3] -> U f32[16,Cin,Cout] = G g G^T per (ci, co): the operand of conv3x3_winograd."""
+    require_cuda(weight)
+    Cout, Cin, KH, KW = weight.shape
+    if (KH, KW) != (3, 3) or weight.dtype != _f32:
+        raise RuntimeError("winograd_weights needs an f32 3x3 filter bank")
+    w = weight.detach().contiguous()
+    U = torch.empty((16, Cin, Cout), dtype=_f32, device=w.device)
+    call("di2p_winograd_weight_transform", ptr(w), ptr(U), Cin, Cout, stream())
+    return U
+
+
+def conv3x3_winograd(x, U, scale, shift, relu, residual=None):
+    """3x3 / stride 1 / pad 1 convolution via Winograd F(2x2,3x3): y = relu?(scale * conv(x) + shift + residual)."""
+    require_cuda(x, U, scale, shift, residual)
+    B, Cin, H, W = x.shape
+    Cout = U.shape[2]
+    if U.shape[0] != 16 or U.shape[1] != Cin:
+        raise RuntimeError("U must be f32[16, Cin, Cout]")
+    y = torch.empty((B, Cout, H, W), dtype=_f32, device=x.device)
+    if _lib.WORK is not None:
+        _lib.WORK["di2p_conv3x3_winograd"] = _lib.WORK.get("di2p_conv3x3_winograd", 0) + B * Cout * Cin * 16 * ((H + 1) // 2) * ((W + 1) // 2)
+    call("di2p_conv3x3_winograd", ptr(x), ptr(U), ptr(scale), ptr(shift), ptr(residual), ptr(y), B, Cin, H, W, Cout, int(bool(relu)), stream())
+    return y
+
+
 def maxpool3x3s2(x):
     require_cuda(x)
     B, C, H, W = x.shape

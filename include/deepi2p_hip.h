@@ -178,6 +178,13 @@ int di2p_conv2d_ws(const float* x, const float* Wt, const float* scale, const fl
                    void* workspace, long long workspace_bytes, void* stream);
 long long di2p_conv2d_workspace_bytes(int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
                                       int tap_major);
+/* 3x3 / stride 1 / pad 1 convolutions (26 of the 36 of ResNet-34, models/resnet.py:56-72) as a fused Winograd F(2x2,3x3) kernel:
+ * 16 multiplications per 2x2 output tile and (ci, co) pair instead of 36; exact in exact arithmetic.
+ *   di2p_winograd_weight_transform: weight f32[Cout,Cin,3,3] -> U f32[16,Cin,Cout] (= G g G^T), once per checkpoint load.
+ *   di2p_conv3x3_winograd: y = relu?( scale * conv(x) + shift + residual ); needs Cin % 8 == 0 and Cout % 32 == 0. */
+int di2p_winograd_weight_transform(const float* weight, float* U, int Cin, int Cout, void* stream);
+int di2p_conv3x3_winograd(const float* x, const float* U, const float* scale, const float* shift, const float* residual, float* y, int B,
+                          int Cin, int H, int W, int Cout, int relu, void* stream);
 int di2p_maxpool3x3s2(const float* x, float* y, int B, int C, int H, int W, void* stream);
 int di2p_global_avgpool(const float* x, float* y, int B, int C, int HW, void* stream);
 /* out[b,c] = max_n x[b,c,n]  (networks_pc.py:115) */

@@ -167,6 +167,33 @@ def test_conv2d(dev, B, Cin, H, W, Cout, k, s, p):
         assert torch.equal(y5, y3)                                    # run-to-run identical (ordered split-K reduce, no atomics)
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 64, 40, 128, 64), (2, 128, 20, 64, 128), (3, 256, 5, 16, 256), (1, 64, 7, 10, 96),
+                                            (2, 32, 9, 12, 32), (1, 512, 5, 16, 512), (1, 64, 3, 4, 32)])
+def test_conv3x3_winograd(dev, B, Cin, H, W, Cout):
+    """Fused Winograd F(2x2,3x3) vs an fp64 convolution: same tolerance class as the direct kernel (its rounding error is a small
+    multiple of the direct form's), odd heights / widths, residual + ReLU epilogue, both output-channel blockings."""
+    from deepi2p_amd import ops
+    g = torch.Generator().manual_seed(Cin * 3 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    ref0 = (F.conv2d(x.double(), w.double(), None, stride=1, padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    res = torch.randn(ref0.shape, generator=g)
+    ref = torch.relu(ref0 + res.double())
+    U = ops.winograd_weights(w.to(dev))
+    direct = ops.conv2d(x.to(dev), w.reshape(Cout, -1).t().contiguous().to(dev), scale.to(dev), shift.to(dev), 3, 3, 1, 1, True, residual=res.to(dev)).cpu()
+    e_direct = float((direct.double() - ref).abs().max())
+    for cob in (32, 64) if Cout % 64 == 0 else (32,):
+        with _lib.option("wino_cob", cob):
+            y = ops.conv3x3_winograd(x.to(dev), U, scale.to(dev), shift.to(dev), True, residual=res.to(dev)).cpu()
+            y2 = ops.conv3x3_winograd(x.to(dev), U, scale.to(dev), shift.to(dev), False).cpu()
+        assert y.shape == ref.shape
+        err = float((y.double() - ref).abs().max())
+        assert err <= 2 * _tol(ref0.float(), Cin * 9), (cob, err, e_direct)
+        assert float((y2.double() - ref0).abs().max()) <= 2 * _tol(ref0.float(), Cin * 9)
+    print("winograd max error %.3g vs direct %.3g (tolerance %.3g)" % (err, e_direct, 2 * float(_tol(ref0.float(), Cin * 9))))
+
+
 def test_pools(dev):
     from deepi2p_amd import ops
     x = torch.randn(2, 64, 32, 64)
