@@ -23,12 +23,12 @@
 
 namespace {
 
-constexpr int WG_TILES = 32, WG_KC = 8;
+constexpr int WG_TILES = 32;
 typedef float f32x4 __attribute__((ext_vector_type(4)));      // a plain vector type: its loads / stores stay register values (no memcpy)
 
-template <int COB, bool DB>
+template <int COB, bool DB, int KC>
 struct WinoLds {
-    static constexpr int U_FLOATS = 16 * WG_KC * COB, V_FLOATS = 16 * WG_KC * WG_TILES;
+    static constexpr int U_FLOATS = 16 * KC * COB, V_FLOATS = 16 * KC * WG_TILES;
     static constexpr int STAGE = U_FLOATS + V_FLOATS;
     static constexpr int TOTAL = (DB ? 2 : 1) * STAGE;
 };
@@ -61,11 +61,13 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 
 // DB: operand panels double buffered (one barrier per K-step, 64 KB at COB 32: two workgroups per CU) or single buffered (two
 // barriers per K-step, 32 KB: four workgroups per CU cover each other's barriers and the grid quantises finer)
-template <int COB, bool DB>
+// KC: input channels per K-step (8: every thread transforms one tile-channel per step; 4: half the panel bytes, waves 0-1 transform)
+template <int COB, bool DB, int KC>
 __global__ __launch_bounds__(256) void wino_conv_kernel(const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, const float* __restrict__ residual, float* __restrict__ y,
                                                         int Cin, int H, int W, int Cout, int TH, int TW, int total_tiles, int n_tb, int n_cb, int relu, int by_co) {
-    using L = WinoLds<COB, DB>;
+    using L = WinoLds<COB, DB, KC>;
+    constexpr int UP = (16 * KC * COB / 4 + 255) / 256;      // 16-byte U loads per thread and K-step
     constexpr int MT = COB / 32;                 // MFMA row tiles per xi
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // XCD-aware order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs; all co-blocks of a tile block go to one XCD
@@ -89,7 +91,9 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(const float* __restrict_
     const int b = gtc / (TH * TW), rem = gtc - b * TH * TW, ty = rem / TW, tx = rem - ty * TW;
     // One 16-byte (dword-aligned) load per tile row: image columns cs .. cs+3 with cs = clamp(2tx-1, 0, W-4).  W is even, so the
     // wanted columns 2tx-1 .. 2tx+2 are the loaded ones shifted by -1 (left edge: column -1 is padding), 0, or +1 (right edge:
-    // column W is padding); rows outside the image are loaded from a clamped row and zeroed.
+    // column W is padding); rows outside the image are loaded from a clamped row and zeroed.  (Measured alternatives: 16 scalar
+    // loads per tile: 15 % slower; unclamped loads + a zero buffer for the padding rows, fewer selects: 20 % slower -- the
+    // compiler then splits the 16-byte loads.)
     const int c0 = 2 * tx - 1, cs = min(max(c0, 0), W - 4);
     const bool left = c0 < cs, right = c0 > cs;
     bool rowok[4];
@@ -100,30 +104,36 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(const float* __restrict_
         rowok[r] = tvalid && iy >= 0 && iy < H;
         rp[r] = x + ((long long)b * Cin + cl) * H * W + (long long)min(max(iy, 0), H - 1) * W + cs;
     }
-    const float* up[COB / 8];
+    const long long x_step = (long long)KC * H * W;
+    const bool v_on = cl < KC;                   // wave-uniform: with KC = 4 only waves 0-1 stage input tiles
+    const float* up[UP];
 #pragma unroll
-    for (int p = 0; p < COB / 8; ++p) {
-        const int f = tid + 256 * p, co4 = f % (COB / 4), row = f / (COB / 4);      // row = xi*8 + k
-        up[p] = U + ((long long)(row >> 3) * Cin + (row & 7)) * Cout + co_blk + co4 * 4;
+    for (int p = 0; p < UP; ++p) {
+        const int f = tid + 256 * p, co4 = f % (COB / 4), row = f / (COB / 4);      // row = xi*KC + k
+        up[p] = U + ((long long)(row / KC) * Cin + (row % KC)) * Cout + co_blk + co4 * 4;
     }
-    const long long x_step = (long long)WG_KC * H * W, u_step = (long long)WG_KC * Cout;
+    const long long u_step = (long long)KC * Cout;
+    const int T = Cin / KC;
 
     F4u drow[4];
-    f32x4 ureg[COB / 8];
+    f32x4 ureg[UP];
     auto gload = [&](int t) __attribute__((always_inline)) {
+        if (v_on) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) drow[r] = *reinterpret_cast<const F4u*>(rp[r] + t * x_step);
+            for (int r = 0; r < 4; ++r) drow[r] = *reinterpret_cast<const F4u*>(rp[r] + t * x_step);
+        }
 #pragma unroll
-        for (int p = 0; p < COB / 8; ++p) ureg[p] = *reinterpret_cast<const f32x4*>(up[p] + t * u_step);
+        for (int p = 0; p < UP; ++p) ureg[p] = *reinterpret_cast<const f32x4*>(up[p] + t * u_step);
     };
     auto lstore = [&](int buf) __attribute__((always_inline)) {
         float* Us = lds + buf * L::STAGE;
         float* Vs = Us + L::U_FLOATS;
 #pragma unroll
-        for (int p = 0; p < COB / 8; ++p) {
+        for (int p = 0; p < UP; ++p) {
             const int f = tid + 256 * p, co4 = f % (COB / 4), row = f / (COB / 4);
             *reinterpret_cast<f32x4*>(Us + row * COB + co4 * 4) = ureg[p];
         }
+        if (!v_on) return;
         float v[16];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -145,10 +155,10 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 4; ++r) {            // (.) B : columns
             const float a0 = t[r * 4 + 0], a1 = t[r * 4 + 1], a2 = t[r * 4 + 2], a3 = t[r * 4 + 3];
-            Vs[((r * 4 + 0) * WG_KC + cl) * WG_TILES + tl] = a0 - a2;
-            Vs[((r * 4 + 1) * WG_KC + cl) * WG_TILES + tl] = a1 + a2;
-            Vs[((r * 4 + 2) * WG_KC + cl) * WG_TILES + tl] = a2 - a1;
-            Vs[((r * 4 + 3) * WG_KC + cl) * WG_TILES + tl] = a1 - a3;
+            Vs[((r * 4 + 0) * KC + cl) * WG_TILES + tl] = a0 - a2;
+            Vs[((r * 4 + 1) * KC + cl) * WG_TILES + tl] = a1 + a2;
+            Vs[((r * 4 + 2) * KC + cl) * WG_TILES + tl] = a2 - a1;
+            Vs[((r * 4 + 3) * KC + cl) * WG_TILES + tl] = a1 - a3;
         }
     };
 
@@ -160,7 +170,6 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][h][r] = 0.0f;
 
-    const int T = Cin / WG_KC;
     gload(0);
     lstore(0);
     __syncthreads();
@@ -170,17 +179,17 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(const float* __restrict_
         const float* Us = lds + buf * L::STAGE;
         const float* Vs = Us + L::U_FLOATS;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j) {            // (hoisting all 32 operand reads of the K-step ahead of the 16 MFMAs measured no gain)
             const int xi = wave * 4 + j;
-            float a[WG_KC / 2][MT], bv[WG_KC / 2];
+            float a[KC / 2][MT], bv[KC / 2];
 #pragma unroll
-            for (int kk = 0; kk < WG_KC; kk += 2) {
+            for (int kk = 0; kk < KC; kk += 2) {
 #pragma unroll
-                for (int h = 0; h < MT; ++h) a[kk / 2][h] = Us[(xi * WG_KC + kk + half) * COB + h * 32 + l31];
-                bv[kk / 2] = Vs[(xi * WG_KC + kk + half) * WG_TILES + l31];
+                for (int h = 0; h < MT; ++h) a[kk / 2][h] = Us[(xi * KC + kk + half) * COB + h * 32 + l31];
+                bv[kk / 2] = Vs[(xi * KC + kk + half) * WG_TILES + l31];
             }
 #pragma unroll
-            for (int kk = 0; kk < WG_KC / 2; ++kk)
+            for (int kk = 0; kk < KC / 2; ++kk)
 #pragma unroll
                 for (int h = 0; h < MT; ++h) acc[j][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][h], bv[kk], acc[j][h], 0, 0, 0);
         }
@@ -280,18 +289,23 @@ extern "C" int di2p_conv3x3_winograd(const float* x, const float* U, const float
     hipStream_t st = (hipStream_t)stream;
     const bool db = di2p_opt(DI2P_OPT_WINO_DB) != 0;
     const int map_opt = (int)di2p_opt(DI2P_OPT_WINO_MAP);      // 0: automatic, 1: tile blocks over the XCDs, 2: co-blocks over the XCDs
-#define DI2P_WINO_LAUNCH(COBV, DBV)                                                                                                          \
+#define DI2P_WINO_LAUNCH(COBV, DBV, KCV)                                                                                                     \
     do {                                                                                                                                     \
         const int n_cb = Cout / COBV;                                                                                                        \
         const int by_co = map_opt ? map_opt == 2 : (n_cb % 8 == 0 && (long long)16 * Cin * Cout * 4 > (2ll << 20));                         \
         const int grid = by_co ? n_cb * n_tb : di2p_cdiv(n_tb, 8) * 8 * n_cb;                                                                \
-        const size_t lds = WinoLds<COBV, DBV>::TOTAL * sizeof(float);                                                                        \
-        (void)hipFuncSetAttribute((const void*)wino_conv_kernel<COBV, DBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-        hipLaunchKernelGGL((wino_conv_kernel<COBV, DBV>), dim3(grid), dim3(256), lds, st, x, U, scale, shift, residual, y, Cin, H, W, Cout, \
+        const size_t lds = WinoLds<COBV, DBV, KCV>::TOTAL * sizeof(float);                                                                        \
+        (void)hipFuncSetAttribute((const void*)wino_conv_kernel<COBV, DBV, KCV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+        hipLaunchKernelGGL((wino_conv_kernel<COBV, DBV, KCV>), dim3(grid), dim3(256), lds, st, x, U, scale, shift, residual, y, Cin, H, W, Cout, \
                            TH, TW, (int)total, n_tb, n_cb, relu, by_co);                                                                     \
     } while (0)
-    if (cob64) { if (db) DI2P_WINO_LAUNCH(64, true); else DI2P_WINO_LAUNCH(64, false); }
-    else { if (db) DI2P_WINO_LAUNCH(32, true); else DI2P_WINO_LAUNCH(32, false); }
+    const long long kc_opt = di2p_opt(DI2P_OPT_WINO_KC);
+    const bool kc4 = kc_opt ? kc_opt == 4 : Cin <= 256;      // measured in the pipeline: K-step 4 wins up to 256 input channels, 8 at 512
+    if (cob64) {
+        if (!db) DI2P_WINO_LAUNCH(64, false, 8); else if (kc4) DI2P_WINO_LAUNCH(64, true, 4); else DI2P_WINO_LAUNCH(64, true, 8);
+    } else {
+        if (!db) DI2P_WINO_LAUNCH(32, false, 8); else if (kc4) DI2P_WINO_LAUNCH(32, true, 4); else DI2P_WINO_LAUNCH(32, true, 8);
+    }
 #undef DI2P_WINO_LAUNCH
     DI2P_RETURN_LAUNCH();
 }

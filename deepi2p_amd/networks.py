@@ -303,7 +303,8 @@ class ImageEncoder(_PackedModule):
         for blk in p["blocks"]:
             identity = x
             Wt, sc, sh, _ = blk["c1"]
-            if wino and "U1" in blk:
+            wino_ok = wino and x.shape[3] % 2 == 0 and x.shape[3] >= 4       # the kernel wants an even width (else: direct kernel)
+            if wino_ok and "U1" in blk:
                 y = ops.conv3x3_winograd(x, blk["U1"], sc, sh, True)
             else:
                 y = ops.conv2d(x, Wt, sc, sh, 3, 3, blk["stride"], 1, True, tap_major=True)
@@ -311,7 +312,7 @@ class ImageEncoder(_PackedModule):
                 Wd, sd_, shd, _ = blk["ds"]
                 identity = ops.conv2d(x, Wd, sd_, shd, 1, 1, blk["stride"], 0, False, tap_major=True)
             Wt, sc, sh, _ = blk["c2"]
-            if wino and "U2" in blk:
+            if wino and "U2" in blk and y.shape[3] % 2 == 0 and y.shape[3] >= 4:
                 x = ops.conv3x3_winograd(y, blk["U2"], sc, sh, True, residual=identity)
             else:
                 x = ops.conv2d(y, Wt, sc, sh, 3, 3, 1, 1, True, residual=identity, tap_major=True)

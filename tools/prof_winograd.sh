@@ -18,9 +18,11 @@ for _ in range(10):
     ops.conv3x3_winograd(x, U, sc, sh, True)
 torch.cuda.synchronize()
 PY
-rocprofv3 --list-avail 2>/dev/null | grep -oE "SQ_[A-Z_0-9]*(MFMA|LDS|WAIT|BUSY|VMEM|ACTIVE)[A-Z_0-9]*" | sort -u | tr '\n' ' ' > $OUT/avail.txt
+rocprofv3 --list-avail 2>/dev/null | grep -oE "(TA|TCP|TD)_[A-Z_0-9a-z]*" | sort -u | tr '\n' ' ' > $OUT/avail.txt
 i=0
-for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM" "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM"; do
+SETS=${SETS:-"SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES|SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INSTS_VALU|SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS|SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL|TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum|TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum GRBM_GUI_ACTIVE|TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_TA_TCP_STATE_READ_sum"}
+IFS='|' read -ra SETARR <<< "$SETS"
+for set in "${SETARR[@]}"; do
   i=$((i+1)); rm -rf /tmp/wp$i
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/wp$i -- python /tmp/wino_one.py > /tmp/wp$i.log 2>&1
   f=$(find /tmp/wp$i -name "*counter_collection.csv" | head -1)
