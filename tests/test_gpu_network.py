@@ -45,6 +45,11 @@ def test_network_vs_reference_golden(dev, golden, fname):
     assert mism < 2e-3, "3-NN index mismatch rate %.4f" % mism
     s16, s32, glob = det.img_encoder(t["img"])
     _close(s16, g["s16"], "s16"); _close(s32, g["s32"], "s32"); _close(glob, g["img_global"], "img_global")
+    from deepi2p_amd import _lib
+    with _lib.option("conv_nowinograd", 1):          # the direct implicit-GEMM kernel on the 3x3 stride-1 layers: same goldens
+        d16, d32, dglob = det.img_encoder(t["img"])
+    _close(d16, g["s16"], "s16 (direct)"); _close(d32, g["s32"], "s32 (direct)"); _close(dglob, g["img_global"], "img_global (direct)")
+    assert not torch.equal(d32, s32)                  # (two different algorithms did run)
     out = det(t["pc"], t["intensity"], t["sn"], t["node_a"], t["node_b"], t["img"])
     coarse = out[0] if fine else out
     _close(coarse, g["coarse"], "coarse logits")
