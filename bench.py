@@ -336,7 +336,7 @@ def main():
 
     # per-kernel-family durations: HIP events on the launch stream, in a SERIAL pass right after the timed region
     # (with several batches in flight, events inside the timed region would measure contention, not the kernels)
-    timed_names = ("di2p_conv2d", "di2p_conv2d_ws", "di2p_conv3x3_winograd", "di2p_pointwise_gemm", "di2p_point_head", "di2p_index_max_values",
+    timed_names = ("di2p_conv2d", "di2p_conv2d_ws", "di2p_conv3x3_winograd", "di2p_conv7x7s2_stem", "di2p_pointwise_gemm", "di2p_point_head", "di2p_index_max_values",
                    "di2p_solve_batched_f32", "di2p_knn_nodes")
     prof_steps = 2
     _lib.TIMED = {n: [] for n in timed_names}
@@ -356,8 +356,9 @@ def main():
     # the convolution family = the plain entry point + the split-K one (K-slice kernel + ordered reduce pass)
     # and the fused Winograd kernel that runs the 3x3 stride-1 layers
     direct_ms, wino_ms, wino_calls = fam_ms["di2p_conv2d"] + fam_ms["di2p_conv2d_ws"], fam_ms["di2p_conv3x3_winograd"], launches["di2p_conv3x3_winograd"]
-    fam_ms["di2p_conv2d"] += fam_ms.pop("di2p_conv2d_ws") + fam_ms.pop("di2p_conv3x3_winograd")
-    launches["di2p_conv2d"] += launches.pop("di2p_conv2d_ws") + launches.pop("di2p_conv3x3_winograd")
+    stem_ms = fam_ms["di2p_conv7x7s2_stem"]
+    fam_ms["di2p_conv2d"] += fam_ms.pop("di2p_conv2d_ws") + fam_ms.pop("di2p_conv3x3_winograd") + fam_ms.pop("di2p_conv7x7s2_stem")
+    launches["di2p_conv2d"] += launches.pop("di2p_conv2d_ws") + launches.pop("di2p_conv3x3_winograd") + launches.pop("di2p_conv7x7s2_stem")
     wino_exec_flops = 2.0 * work.get("di2p_conv3x3_winograd", 0) / prof_steps
     # pointwise family = the single-layer launches + the fused three-layer point head
     fam_ms["di2p_pointwise_gemm"] += fam_ms.pop("di2p_point_head")
@@ -385,7 +386,7 @@ def main():
             "algorithmic_flop_per_launch": conv_flops / 36.0,
             "compulsory_bytes_per_launch": (conv_bytes_per_frame(H, W) * B + 85.1e6) / 36.0,
             "winograd": {"calls_per_step": wino_calls, "ms_per_step": wino_ms, "executed_mfma_tflops": wino_exec_flops / max(wino_ms, 1e-9) / 1e9,
-                         "direct_kernel_ms_per_step": direct_ms},
+                         "direct_kernel_ms_per_step": direct_ms, "stem_kernel_ms_per_step": stem_ms},
             "note": "achieved = reference-algorithmic 2*MAC of the 36 convolutions (SURVEY 8d) / time of the whole family; the 3x3 "
                     "stride-1 layers run as Winograd F(2x2,3x3) (16 instead of 36 multiplications per tile and channel pair, exact "
                     "arithmetic in fp32): `winograd.executed_mfma_tflops` is what the MFMA units actually issue for them"},

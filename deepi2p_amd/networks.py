@@ -276,6 +276,9 @@ class ImageEncoder(_PackedModule):
             sd = self._sd()
             r = "backbone"
             p = {"stem": _fold(sd, r + ".conv1", r + ".bn1"), "blocks": []}
+            w_stem = sd[r + ".conv1.weight"]
+            if w_stem.is_cuda and tuple(w_stem.shape) == (64, 3, 7, 7):
+                p["stem_p"] = ops.stem_weights(w_stem)
             for li, nb in enumerate(self.LAYERS, start=1):
                 for bi in range(nb):
                     q = "%s.layer%d.%d" % (r, li, bi)
@@ -296,7 +299,10 @@ class ImageEncoder(_PackedModule):
         p = self._pack()
         ops.require_cuda(x)
         Wt, sc, sh, _ = p["stem"]
-        x = ops.conv2d(x, Wt, sc, sh, 7, 7, 2, 3, True)
+        if "stem_p" in p and not _lib.get_option("conv_nostem"):
+            x = ops.conv_stem(x, p["stem_p"], sc, sh, True)
+        else:
+            x = ops.conv2d(x, Wt, sc, sh, 7, 7, 2, 3, True)
         x = ops.maxpool3x3s2(x)
         stage_out = {}
         wino = not _lib.get_option("conv_nowinograd")

@@ -268,6 +268,28 @@ def conv2d(x, Wt, scale, shift, KH, KW, stride, pad, relu, residual=None, tap_ma
     return y
 
 
+def stem_weights(weight):
+    """weight f32[64,3,7,7] -> Wp f32[168,64]: the packed filter bank of conv_stem."""
+    require_cuda(weight)
+    if tuple(weight.shape) != (64, 3, 7, 7) or weight.dtype != _f32:
+        raise RuntimeError("stem_weights needs the f32[64,3,7,7] ResNet stem filter")
+    w = weight.detach().contiguous()
+    Wp = torch.empty((168, 64), dtype=_f32, device=w.device)
+    call("di2p_stem_pack", ptr(w), ptr(Wp), stream())
+    return Wp
+
+
+def conv_stem(x, Wp, scale, shift, relu=True):
+    """ResNet stem: y = relu?(scale * conv7x7/2(x) + shift); x f32[B,3,H,W] -> f32[B,64,OH,OW]."""
+    require_cuda(x, Wp, scale, shift)
+    B, C, H, W = x.shape
+    if C != 3:
+        raise RuntimeError("the stem takes 3 input channels")
+    y = torch.empty((B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=_f32, device=x.device)
+    call("di2p_conv7x7s2_stem", ptr(x), ptr(Wp), ptr(scale), ptr(shift), ptr(y), B, H, W, int(bool(relu)), stream())
+    return y
+
+
 def winograd_weights(weight):
     """weight f32[Cout,Cin,3,3] -> U f32[16,Cin,Cout] = G g G^T per (ci, co): the operand of conv3x3_winograd."""
     require_cuda(weight)

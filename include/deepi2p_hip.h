@@ -185,6 +185,13 @@ long long di2p_conv2d_workspace_bytes(int B, int Cin, int H, int W, int Cout, in
 int di2p_winograd_weight_transform(const float* weight, float* U, int Cin, int Cout, void* stream);
 int di2p_conv3x3_winograd(const float* x, const float* U, const float* scale, const float* shift, const float* residual, float* y, int B,
                           int Cin, int H, int W, int Cout, int relu, void* stream);
+/* The ResNet stem (7x7 / stride 2 / pad 3, 3 -> 64 channels, models/resnet.py:137-139,197-199) as a direct kernel: the filter bank and
+ * the input row segments of a workgroup are staged once (columns de-interleaved by parity), then 168 MFMAs per wave without a barrier.
+ *   di2p_stem_pack: weight f32[64,3,7,7] -> Wp f32[168,64] (taps padded 7 -> 8 per row), once per checkpoint load.
+ *   di2p_conv7x7s2_stem: y f32[B,64,OH,OW] = relu?(scale * conv(x f32[B,3,H,W]) + shift). */
+int di2p_stem_pack(const float* weight, float* Wp, void* stream);
+int di2p_conv7x7s2_stem(const float* x, const float* Wp, const float* scale, const float* shift, float* y, int B, int H, int W, int relu,
+                        void* stream);
 int di2p_maxpool3x3s2(const float* x, float* y, int B, int C, int H, int W, void* stream);
 int di2p_global_avgpool(const float* x, float* y, int B, int C, int HW, void* stream);
 /* out[b,c] = max_n x[b,c,n]  (networks_pc.py:115) */

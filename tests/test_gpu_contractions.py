@@ -194,6 +194,22 @@ def test_conv3x3_winograd(dev, B, Cin, H, W, Cout):
     print("winograd max error %.3g vs direct %.3g (tolerance %.3g)" % (err, e_direct, 2 * float(_tol(ref0.float(), Cin * 9))))
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 32, 64), (1, 160, 512), (3, 33, 70), (1, 7, 9)])
+def test_conv_stem(dev, B, H, W):
+    """Direct 7x7/2 stem kernel vs an fp64 convolution (and the generic implicit-GEMM path), odd sizes and partial column tiles."""
+    from deepi2p_amd import ops
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.rand(B, 3, H, W, generator=g) * 255
+    w = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    scale, shift = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    ref = torch.relu(F.conv2d(x.double(), w.double(), None, stride=2, padding=3) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    y = ops.conv_stem(x.to(dev), ops.stem_weights(w.to(dev)), scale.to(dev), shift.to(dev), True).cpu()
+    assert y.shape == ref.shape
+    assert float((y.double() - ref).abs().max()) <= _tol(ref.float(), 147)
+    y0 = ops.conv2d(x.to(dev), w.reshape(64, -1).t().contiguous().to(dev), scale.to(dev), shift.to(dev), 7, 7, 2, 3, True).cpu()
+    assert float((y - y0).abs().max()) <= _tol(ref.float(), 147)
+
+
 def test_pools(dev):
     from deepi2p_amd import ops
     x = torch.randn(2, 64, 32, 64)

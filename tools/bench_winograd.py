@@ -40,3 +40,12 @@ for (C, H, W, calls) in ((64, 40, 128, 6), (128, 20, 64, 7), (256, 10, 32, 11), 
     print("%-22s %10.1f %8.1f | K-step 8: cob32 %6.1f cob64 %6.1f | K-step 4: cob32 %6.1f cob64 %6.1f | best %.1f TF" % (
         "%d,%d,%d,%d" % (C, H, W, C), td, fl / td / 1e6, out[0], out[1], out[2], out[3], fl / best / 1e6))
 print("26 layers per 32-frame step: direct %.3f ms, Winograd (better blocking per shape) %.3f ms" % (tot[0] / 1e3, tot[1] / 1e3))
+
+x = torch.rand(B, 3, 160, 512, device=dev) * 255
+w = torch.randn(64, 3, 7, 7, device=dev) * 0.05
+sc, sh = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+Wt, Wp = w.reshape(64, -1).t().contiguous(), ops.stem_weights(w)
+fl = 2.0 * B * 80 * 256 * 64 * 147
+t0 = timeit(lambda: ops.conv2d(x, Wt, sc, sh, 7, 7, 2, 3, True))
+t1 = timeit(lambda: ops.conv_stem(x, Wp, sc, sh, True))
+print("stem 3->64 7x7/2 at 160x512: implicit GEMM %.1f us (%.1f TF), direct kernel %.1f us (%.1f TF algorithmic)" % (t0, fl / t0 / 1e6, t1, fl / t1 / 1e6))

@@ -13,7 +13,7 @@ cd /tmp
 stats() {  # name, args...
   local name=$1; shift
   rm -rf $OUT/prof_$TAG/$name
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG/$name -- python $ROOT/bench.py --no-cpu-baseline "$@" > $OUT/prof_$TAG/$name.log 2>&1
+  timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG/$name -- python $ROOT/bench.py --no-cpu-baseline "$@" > $OUT/prof_$TAG/$name.log 2>&1
   f=$(find $OUT/prof_$TAG/$name -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/${TAG}_bench_kernel_stats_$name.csv
   grep '^{' $OUT/prof_$TAG/$name.log | tail -1 > $OUT/${TAG}_bench_line_$name.json
@@ -23,7 +23,7 @@ stats serial --streams 1 --no-h2d-pass
 pmc() {  # counter, tool
   local c=$1 tool=$2 name=$3
   rm -rf $OUT/prof_$TAG/pmc_${name}_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/prof_$TAG/pmc_${name}_$c -- python $ROOT/tools/$tool > $OUT/prof_$TAG/pmc_${name}_$c.log 2>&1
+  timeout 180 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/prof_$TAG/pmc_${name}_$c -- python $ROOT/tools/$tool > $OUT/prof_$TAG/pmc_${name}_$c.log 2>&1
   f=$(find $OUT/prof_$TAG/pmc_${name}_$c -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python - "$f" $OUT/${TAG}_pmc_${name}_$c.csv <<'PY'
 import csv, sys, collections
@@ -40,4 +40,5 @@ with open(sys.argv[2], "w") as fh:
 PY
 }
 for c in FETCH_SIZE WRITE_SIZE; do pmc $c bench_solver.py solver; done
+for c in FETCH_SIZE WRITE_SIZE; do pmc $c bench_conv.py conv; done
 ls -la $OUT | grep ${TAG}_
