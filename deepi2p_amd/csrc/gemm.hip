@@ -470,8 +470,9 @@ extern "C" int di2p_pointwise_gemm(const di2p_src_t* srcs, int n_src, const floa
         // small grids (node-level layers: N = 128 columns per frame) take smaller tiles to spread over the CUs
         const long long wg128 = (long long)B * di2p_cdiv(N, 128) * di2p_cdiv(M, 128);
         const long long wg64x128 = (long long)B * di2p_cdiv(N, 128) * di2p_cdiv(M, 64);
-        if (wg128 >= 1024) launch_pw_vec<TileCfg<2, 2, 2, 2, 32>>(dense, s, Wt, Y, B, M, K, N, e, st);
-        else if (wg64x128 >= 1024 || N % 64 != 0) launch_pw_vec<TileCfg<2, 2, 1, 2, 32>>(dense, s, Wt, Y, B, M, K, N, e, st);
+        const long long force = di2p_opt(DI2P_OPT_PW_CFG);       // experiments: 1 = 64x64, 2 = 64x128, 3 = 128x128 tiles
+        if (force == 3 || (!force && wg128 >= 1024)) launch_pw_vec<TileCfg<2, 2, 2, 2, 32>>(dense, s, Wt, Y, B, M, K, N, e, st);
+        else if (force == 2 || (!force && (wg64x128 >= 1024 || N % 64 != 0)) || (force == 1 && N % 64 != 0)) launch_pw_vec<TileCfg<2, 2, 1, 2, 32>>(dense, s, Wt, Y, B, M, K, N, e, st);
         else launch_pw_vec<TileCfg<2, 2, 1, 1, 32>>(dense, s, Wt, Y, B, M, K, N, e, st);
         DI2P_RETURN_LAUNCH();
     }
