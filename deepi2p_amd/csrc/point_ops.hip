@@ -12,26 +12,27 @@ namespace {
 // ----------------------------------------------------------------------------------------------
 // k nearest nodes, ascending (distance, node id).  Distance is sqrtf((dx*dx + dy*dy) + dz*dz) with
 // separately rounded operations, the same value torch.norm(dim=1) produces for 3 components.
+// The scan orders the candidates by the SQUARED distance (sqrtf is monotone: a quarter-rate instruction per node and lane is
+// only spent on the k winners) and the node coordinates are wave-uniform reads straight from global memory (scalar loads
+// through the constant cache: no LDS staging, no LDS traffic in the loop); the k winners are then re-ordered on the rounded
+// distance itself, so that nodes whose distances round to the same float come out lowest-index first, as a sort on d would.
 template <int KN>
 __global__ __launch_bounds__(256) void knn_nodes_kernel(const float* __restrict__ query, const float* __restrict__ nodes,
                                                         int* __restrict__ idx, float* __restrict__ weights, int Nq,
                                                         int M) {
-    extern __shared__ float s_nodes[];  // [3][M]
     const int b = blockIdx.y;
-    const float* nb = nodes + (long long)b * 3 * M;
-    for (int i = threadIdx.x; i < 3 * M; i += blockDim.x) s_nodes[i] = nb[i];
-    __syncthreads();
+    const float* __restrict__ nb = nodes + (long long)b * 3 * M;
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= Nq) return;
+    const int nc = min(n, Nq - 1);
     const float* q = query + (long long)b * 3 * Nq;
-    const float qx = q[n], qy = q[Nq + n], qz = q[2 * Nq + n];
+    const float qx = q[nc], qy = q[Nq + nc], qz = q[2 * Nq + nc];
     float bd[KN];
     int bi[KN];
 #pragma unroll
     for (int j = 0; j < KN; ++j) { bd[j] = __builtin_inff(); bi[j] = 0x7fffffff; }
-    for (int m = 0; m < M; ++m) {
-        const float dx = __fsub_rn(qx, s_nodes[m]), dy = __fsub_rn(qy, s_nodes[M + m]), dz = __fsub_rn(qz, s_nodes[2 * M + m]);
-        float d = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    auto consider = [&](float nx, float ny, float nz, int m) __attribute__((always_inline)) {
+        const float dx = __fsub_rn(qx, nx), dy = __fsub_rn(qy, ny), dz = __fsub_rn(qz, nz);
+        float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
         int i = m;
         if (d < bd[KN - 1] || (d == bd[KN - 1] && i < bi[KN - 1])) {
 #pragma unroll
@@ -45,7 +46,28 @@ __global__ __launch_bounds__(256) void knn_nodes_kernel(const float* __restrict_
                 i = lt ? ti : i;
             }
         }
+    };
+    int m = 0;
+    for (; m + 4 <= M; m += 4) {          // uniform addresses: the compiler turns these into s_load_dwordx4
+        const float x0 = nb[m], x1 = nb[m + 1], x2 = nb[m + 2], x3 = nb[m + 3];
+        const float y0 = nb[M + m], y1 = nb[M + m + 1], y2 = nb[M + m + 2], y3 = nb[M + m + 3];
+        const float z0 = nb[2 * M + m], z1 = nb[2 * M + m + 1], z2 = nb[2 * M + m + 2], z3 = nb[2 * M + m + 3];
+        consider(x0, y0, z0, m); consider(x1, y1, z1, m + 1); consider(x2, y2, z2, m + 2); consider(x3, y3, z3, m + 3);
     }
+    for (; m < M; ++m) consider(nb[m], nb[M + m], nb[2 * M + m], m);
+    if (n >= Nq) return;
+#pragma unroll
+    for (int j = 0; j < KN; ++j) bd[j] = __fsqrt_rn(bd[j]);
+    // equal rounded distances: lowest node id first (insertion sort on (d, id); the squared order is already almost that)
+#pragma unroll
+    for (int a = 1; a < KN; ++a)
+#pragma unroll
+        for (int j = a; j > 0; --j) {
+            const bool sw = bd[j] == bd[j - 1] && bi[j] < bi[j - 1];
+            const int t = bi[j];
+            bi[j] = sw ? bi[j - 1] : t;
+            bi[j - 1] = sw ? t : bi[j - 1];
+        }
     int* o = idx + ((long long)b * Nq + n) * KN;
 #pragma unroll
     for (int j = 0; j < KN; ++j) o[j] = bi[j] == 0x7fffffff ? 0 : bi[j];
@@ -256,14 +278,13 @@ extern "C" int di2p_knn_nodes(const float* query, const float* nodes, int32_t* i
     DI2P_CHECK_ARG(M <= 4096, "M too large for the LDS node table");
     if (B == 0 || Nq == 0) return 0;
     const dim3 grid(di2p_cdiv(Nq, 256), B), block(256);
-    const size_t lds = (size_t)3 * M * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     // few queries per frame over few nodes: one wavefront per query (the lane-per-query kernel would leave the chip idle)
     const bool per_wave = M <= 256 && Nq <= 1024;
     const dim3 wgrid(di2p_cdiv(Nq, 4), B);
 #define DI2P_KNN_CASE(KK) \
     case KK: if (per_wave) hipLaunchKernelGGL(knn_nodes_wave_kernel<KK>, wgrid, block, 0, st, query, nodes, idx, weights, Nq, M); \
-             else hipLaunchKernelGGL(knn_nodes_kernel<KK>, grid, block, lds, st, query, nodes, idx, weights, Nq, M); \
+             else hipLaunchKernelGGL(knn_nodes_kernel<KK>, grid, block, 0, st, query, nodes, idx, weights, Nq, M); \
              break;
     switch (k) {
         DI2P_KNN_CASE(1) DI2P_KNN_CASE(2) DI2P_KNN_CASE(3) DI2P_KNN_CASE(4) DI2P_KNN_CASE(5) DI2P_KNN_CASE(6)
