@@ -21,6 +21,7 @@
 //                    arg-max (first maximum in scan order, the rule of torch.max / max_pool2d)
 #include "common.h"
 #include "mfma_tile.h"
+#include <type_traits>
 
 namespace {
 
@@ -30,41 +31,89 @@ constexpr int RC_LDS_FLOATS = 2 * 2 * RC_BK * RC_LD;
 
 // Loader protocol: set_index(p, i) once per pass p (row / column i of the output tile, may be out of range), set_r(r, ok)
 // once per K-step (this lane's reduction index; !ok = past the end), load(p) -> value (0 where out of range).
-template <class LA, class LB>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Scalar stager of one operand: lane = (reduction index r_in, 8 rows per pass); any loader.
+template <class L>
+struct RcStageScalar {
+    float v[RC_PASSES];
+    int r_in, q0;
+    __device__ __forceinline__ void init(int tid, L& l, int blk) {
+        r_in = tid & 31; q0 = tid >> 5;
+#pragma unroll
+        for (int p = 0; p < RC_PASSES; ++p) l.set_index(p, blk + q0 + 8 * p);
+    }
+    __device__ __forceinline__ void load(L& l, int r0, int r_end) {
+        const int r = r0 + r_in;
+        const bool ok = r < r_end;
+        l.set_r(ok ? r : r_end - 1, ok);
+#pragma unroll
+        for (int p = 0; p < RC_PASSES; ++p) v[p] = l.load(p);
+    }
+    __device__ __forceinline__ void store(float* S) const {
+#pragma unroll
+        for (int p = 0; p < RC_PASSES; ++p) S[r_in * RC_LD + q0 + 8 * p] = v[p];
+    }
+};
+
+// 16-byte stager for an operand that is plainly strided (value(r, i) = base[i*ld + r]) with 16-byte addressable rows and a
+// reduction range that is a multiple of 4: lane = (4 consecutive r, 32 rows per pass): 2 loads instead of 8 per K-step.
+struct RcStageVec {
+    f32x4 v[2];
+    const float* ptr[2];
+    bool okp[2];
+    int r4, row0;
+    template <class L>
+    __device__ __forceinline__ void init(int tid, L& l, int blk) {
+        r4 = tid & 7; row0 = tid >> 3;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int i = blk + row0 + 32 * p;
+            okp[p] = i < l.n;
+            ptr[p] = l.p + (long long)min(i, l.n - 1) * l.ld + r4 * 4;
+        }
+    }
+    template <class L>
+    __device__ __forceinline__ void load(L&, int r0, int r_end) {
+        const bool ok = r0 + r4 * 4 < r_end;
+        const int rc = ok ? r0 : r_end - 32;           // (a clamped, still in-range 16-byte read; zeroed below)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(ptr[p] + (rc < 0 ? 0 : rc));
+            v[p] = (ok && okp[p]) ? t : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    }
+    __device__ __forceinline__ void store(float* S) const {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) S[(r4 * 4 + i) * RC_LD + row0 + 32 * p] = v[p][i];
+    }
+};
+
+template <bool AV, bool BV, class LA, class LB>
 __device__ __forceinline__ void rc_gemm_tile(float* lds, LA& la, LB& lb, int r_begin, int r_end, int row_blk, int col_blk,
                                              float* __restrict__ out, int rows, int cols) {
     float* As = lds;                          // [2][BK][LD]
     float* Bs = lds + 2 * RC_BK * RC_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
-    const int r_in = tid & 31, q0 = tid >> 5;
-#pragma unroll
-    for (int p = 0; p < RC_PASSES; ++p) { la.set_index(p, row_blk + q0 + 8 * p); lb.set_index(p, col_blk + q0 + 8 * p); }
+    typename std::conditional<AV, RcStageVec, RcStageScalar<LA>>::type sa;
+    typename std::conditional<BV, RcStageVec, RcStageScalar<LB>>::type sb;
+    sa.init(tid, la, row_blk);
+    sb.init(tid, lb, col_blk);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    float ra[RC_PASSES], rb[RC_PASSES];
     const int T = (r_end - r_begin + RC_BK - 1) / RC_BK;
-    auto gload = [&](int t) {
-        const int r = r_begin + t * RC_BK + r_in;
-        const bool ok = r < r_end;
-        const int rc = ok ? r : r_end - 1;
-        la.set_r(rc, ok); lb.set_r(rc, ok);
-#pragma unroll
-        for (int p = 0; p < RC_PASSES; ++p) { ra[p] = la.load(p); rb[p] = lb.load(p); }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < RC_PASSES; ++p) {
-            As[(buf * RC_BK + r_in) * RC_LD + q0 + 8 * p] = ra[p];
-            Bs[(buf * RC_BK + r_in) * RC_LD + q0 + 8 * p] = rb[p];
-        }
-    };
-    if (T > 0) { gload(0); lstore(0); }
+    if (T > 0) {
+        sa.load(la, r_begin, r_end); sb.load(lb, r_begin, r_end);
+        sa.store(As); sb.store(Bs);
+    }
     __syncthreads();
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
-        if (t + 1 < T) gload(t + 1);
+        if (t + 1 < T) { sa.load(la, r_begin + (t + 1) * RC_BK, r_end); sb.load(lb, r_begin + (t + 1) * RC_BK, r_end); }
         const float* Ab = As + buf * RC_BK * RC_LD + wm * 32 + l31;
         const float* Bb = Bs + buf * RC_BK * RC_LD + wn * 32 + l31;
         float a[RC_BK / 2], b[RC_BK / 2];
@@ -72,7 +121,7 @@ __device__ __forceinline__ void rc_gemm_tile(float* lds, LA& la, LB& lb, int r_b
         for (int kk = 0; kk < RC_BK; kk += 2) { a[kk / 2] = Ab[(kk + half) * RC_LD]; b[kk / 2] = Bb[(kk + half) * RC_LD]; }
 #pragma unroll
         for (int kk = 0; kk < RC_BK / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc, 0, 0, 0);
-        if (t + 1 < T) lstore(buf ^ 1);
+        if (t + 1 < T) { sa.store(As + (buf ^ 1) * RC_BK * RC_LD); sb.store(Bs + (buf ^ 1) * RC_BK * RC_LD); }
         __syncthreads();
     }
     const int col = col_blk + wn * 32 + l31;
@@ -151,13 +200,13 @@ struct RcSelect {
     }
 };
 
-template <class LA, class LB>
+template <bool AV, bool BV, class LA, class LB>
 __global__ __launch_bounds__(256) void rc_gemm_kernel(LA la, LB lb, int R, int rch, int chunks, float* __restrict__ partial, int rows, int cols) {
     extern __shared__ float lds[];
     const int z = blockIdx.z / chunks, ch = blockIdx.z % chunks;
     la.batch(z); lb.batch(z);
     const int r_begin = ch * rch, r_end = min(R, r_begin + rch);
-    rc_gemm_tile(lds, la, lb, r_begin, r_end, blockIdx.y * RC_BM, blockIdx.x * RC_BM, partial + (long long)blockIdx.z * rows * cols, rows, cols);
+    rc_gemm_tile<AV, BV>(lds, la, lb, r_begin, r_end, blockIdx.y * RC_BM, blockIdx.x * RC_BM, partial + (long long)blockIdx.z * rows * cols, rows, cols);
 }
 
 // out[g][e] = alpha * sum_{p < per_group} partial[g * per_group + p][e], summed in p order
@@ -187,14 +236,27 @@ RcPlan rc_plan(int Z, int rows, int cols, int R) {
     return pl;
 }
 
+inline bool rc_vec_ok(const float* base, long long ld, long long batch_stride, int R) {
+    return ((uintptr_t)base & 15) == 0 && ld % 4 == 0 && batch_stride % 4 == 0 && R % 4 == 0 && R >= 32;
+}
+
 template <class LA, class LB>
 int rc_launch(const char* who, LA la, LB lb, int Z, int rows, int cols, int R, float alpha, bool reduce_z, float* out, void* ws, long long ws_bytes,
-              hipStream_t st) {
+              hipStream_t st, bool a_vec = false, bool b_vec = false) {
     const RcPlan pl = rc_plan(Z, rows, cols, R);
     if (!ws || ws_bytes < pl.bytes) { di2p_set_error("%s: workspace too small (%lld bytes needed)", who, pl.bytes); return -1; }
     if ((long long)Z * pl.chunks > 65535) { di2p_set_error("%s: too many reduction chunks", who); return -1; }
     const dim3 grid(di2p_cdiv(cols, RC_BM), di2p_cdiv(rows, RC_BM), Z * pl.chunks);
-    hipLaunchKernelGGL((rc_gemm_kernel<LA, LB>), grid, dim3(256), RC_LDS_FLOATS * sizeof(float), st, la, lb, R, pl.rch, pl.chunks, (float*)ws, rows, cols);
+    const size_t lds = RC_LDS_FLOATS * sizeof(float);
+    if constexpr (std::is_same<LA, RcStrided>::value && std::is_same<LB, RcStrided>::value) {
+        if (a_vec && b_vec) hipLaunchKernelGGL((rc_gemm_kernel<true, true, LA, LB>), grid, dim3(256), lds, st, la, lb, R, pl.rch, pl.chunks, (float*)ws, rows, cols);
+        else hipLaunchKernelGGL((rc_gemm_kernel<false, false, LA, LB>), grid, dim3(256), lds, st, la, lb, R, pl.rch, pl.chunks, (float*)ws, rows, cols);
+    } else if constexpr (std::is_same<LA, RcStrided>::value) {
+        if (a_vec) hipLaunchKernelGGL((rc_gemm_kernel<true, false, LA, LB>), grid, dim3(256), lds, st, la, lb, R, pl.rch, pl.chunks, (float*)ws, rows, cols);
+        else hipLaunchKernelGGL((rc_gemm_kernel<false, false, LA, LB>), grid, dim3(256), lds, st, la, lb, R, pl.rch, pl.chunks, (float*)ws, rows, cols);
+    } else {
+        hipLaunchKernelGGL((rc_gemm_kernel<false, false, LA, LB>), grid, dim3(256), lds, st, la, lb, R, pl.rch, pl.chunks, (float*)ws, rows, cols);
+    }
     const long long elems = (long long)rows * cols;
     const int per_group = reduce_z ? Z * pl.chunks : pl.chunks;
     const long long total = reduce_z ? elems : elems * Z;
@@ -509,7 +571,8 @@ extern "C" int di2p_bmm_rc(const float* A, long long lda, long long a_batch_stri
     DI2P_CHECK_ARG(A && Bm && out && Z >= 1 && rows >= 1 && cols >= 1 && R >= 1, "bad args");
     RcStrided la{}; la.base = A; la.ld = lda; la.batch_stride = a_batch_stride; la.n = rows;
     RcStrided lb{}; lb.base = Bm; lb.ld = ldb; lb.batch_stride = b_batch_stride; lb.n = cols;
-    return rc_launch(__func__, la, lb, Z, rows, cols, R, alpha, reduce_z != 0, out, workspace, workspace_bytes, (hipStream_t)stream);
+    return rc_launch(__func__, la, lb, Z, rows, cols, R, alpha, reduce_z != 0, out, workspace, workspace_bytes, (hipStream_t)stream,
+                     rc_vec_ok(A, lda, a_batch_stride, R), rc_vec_ok(Bm, ldb, b_batch_stride, R));
 }
 
 extern "C" int di2p_bmm_km(const float* A, int lda, long long a_batch_stride, const float* Bm, int ldb, long long b_batch_stride, float* out, int Z,
@@ -552,7 +615,8 @@ extern "C" int di2p_conv2d_wgrad(const float* x, const float* dy, float* dW, int
     DI2P_CHECK_ARG(OH >= 1 && OW >= 1, "empty output");
     RcStrided la{}; la.base = dy; la.ld = (long long)OH * OW; la.batch_stride = (long long)Cout * OH * OW; la.n = Cout;
     RcIm2col lb{}; lb.base = x; lb.Cin = Cin; lb.H = H; lb.W = W; lb.OW = OW; lb.KH = KH; lb.KW = KW; lb.stride = stride; lb.pad = pad; lb.ncols = Cin * KH * KW;
-    return rc_launch(__func__, la, lb, B, Cout, Cin * KH * KW, OH * OW, 1.0f, true, dW, workspace, workspace_bytes, (hipStream_t)stream);
+    return rc_launch(__func__, la, lb, B, Cout, Cin * KH * KW, OH * OW, 1.0f, true, dW, workspace, workspace_bytes, (hipStream_t)stream,
+                     rc_vec_ok(dy, (long long)OH * OW, (long long)Cout * OH * OW, OH * OW));
 }
 
 extern "C" int di2p_conv2d_dgrad(const float* dy, const float* Wgt, float* dx, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,

@@ -292,11 +292,11 @@ def conv_stem(x, Wp, scale, shift, relu=True):
 
 def winograd_weights(weight):
     """weight f32[Cout,Cin,3,3] -> U f32[16,Cin,Cout] = G g G^T per (ci, co): the operand of conv3x3_winograd."""
-    require_cuda(weight)
     Cout, Cin, KH, KW = weight.shape
     if (KH, KW) != (3, 3) or weight.dtype != _f32:
         raise RuntimeError("winograd_weights needs an f32 3x3 filter bank")
-    w = weight.detach().contiguous()
+    w = weight.detach().contiguous()          # (a flipped / transposed view is fine: the training path passes one)
+    require_cuda(w)
     U = torch.empty((16, Cin, Cout), dtype=_f32, device=w.device)
     call("di2p_winograd_weight_transform", ptr(w), ptr(U), Cin, Cout, stream())
     return U

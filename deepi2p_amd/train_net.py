@@ -37,6 +37,12 @@ BN_EPS = 1e-5
 _f32, _i32 = torch.float32, torch.int32
 
 
+def _sink(param):
+    """Where a Function's backward writes the gradient of `param` DIRECTLY (ClassifierTrainer points every parameter at its slice
+    of the flat gradient buffer): the Function then returns None for it and autograd launches no accumulation kernel."""
+    return getattr(param, "_di2p_grad", None)
+
+
 def _ws(nbytes, device):
     return torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=device)
 
@@ -59,6 +65,7 @@ class _Linear(Function):
         ctx.save_for_backward(x, W2)
         ctx.has_bias = bias is not None
         ctx.wshape = W.shape
+        ctx.sinks = (_sink(W), _sink(bias) if bias is not None else None)
         return y
 
     @staticmethod
@@ -72,15 +79,16 @@ class _Linear(Function):
         if ctx.needs_input_grad[0]:
             dx = ops.pointwise_gemm([Src(dy)], _c(W2), K, N)          # W[m][k] is the k-major operand of the reduction over m
         if ctx.needs_input_grad[1]:
-            dW = torch.empty((M, K), dtype=_f32, device=x.device)
+            dW = ctx.sinks[0] if ctx.sinks[0] is not None else torch.empty((M, K), dtype=_f32, device=x.device)
             nb = lib.di2p_bmm_rc_workspace_bytes(B, M, K, N)
             ws = _ws(nb, x.device)
             call("di2p_bmm_rc", ptr(dy), N, M * N, ptr(x), N, K * N, ptr(dW), B, M, K, N, 1.0, 1, ptr(ws), nb, stream())
-            dW = dW.view(ctx.wshape)
+            dW = None if ctx.sinks[0] is not None else dW.view(ctx.wshape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty((M,), dtype=_f32, device=x.device)
+            db = ctx.sinks[1] if ctx.sinks[1] is not None else torch.empty((M,), dtype=_f32, device=x.device)
             ws = _ws(lib.di2p_channel_reduce_workspace_bytes(B, M, N), x.device)
             call("di2p_channel_sum", ptr(dy), ptr(db), B, M, N, ptr(ws), stream())
+            db = None if ctx.sinks[1] is not None else db
         return dx, dW, db
 
 
@@ -106,6 +114,9 @@ def _conv_forward(x, W, stride, pad):
     """conv2d through the inference engine with an identity epilogue; Cin % 16 == 0 takes its tap-major (16-byte staged) path."""
     Cout, Cin, KH, KW = W.shape
     one, zero = _unit_affine(Cout, x.device)
+    if (KH, KW, stride, pad) == (3, 3, 1, 1) and Cin % 16 == 0 and Cout % 32 == 0 and x.shape[3] % 2 == 0 and x.shape[3] >= 4:
+        # the fused Winograd kernel (the filters change every step: their transform is one small launch per call)
+        return ops.conv3x3_winograd(x, ops.winograd_weights(W), one, zero, False)
     if Cin % 16 == 0:
         return ops.conv2d(x, W.permute(2, 3, 1, 0).reshape(-1, Cout).contiguous(), one, zero, KH, KW, stride, pad, False, tap_major=True)
     return ops.conv2d(x, W.reshape(Cout, -1).t().contiguous(), one, zero, KH, KW, stride, pad, False)
@@ -119,6 +130,7 @@ class _Conv2d(Function):
         y = _conv_forward(x, W, stride, pad)
         ctx.save_for_backward(x, W)
         ctx.cfg = (stride, pad)
+        ctx.sink = _sink(W)
         return y
 
     @staticmethod
@@ -139,10 +151,12 @@ class _Conv2d(Function):
                 dx = torch.empty_like(x)
                 call("di2p_conv2d_dgrad", ptr(dy), ptr(_c(W)), ptr(dx), B, Cin, H, Wd, Cout, KH, KW, stride, pad, stream())
         if ctx.needs_input_grad[1]:
-            dW = torch.empty_like(W, memory_format=torch.contiguous_format)
+            dW = ctx.sink if ctx.sink is not None else torch.empty_like(W, memory_format=torch.contiguous_format)
             nb = lib.di2p_conv2d_wgrad_workspace_bytes(B, Cin, H, Wd, Cout, KH, KW, stride, pad)
             ws = _ws(nb, x.device)
             call("di2p_conv2d_wgrad", ptr(x), ptr(dy), ptr(dW), B, Cin, H, Wd, Cout, KH, KW, stride, pad, ptr(ws), nb, stream())
+            if ctx.sink is not None:
+                dW = None
         return dx, dW, None, None
 
 
@@ -162,6 +176,7 @@ class _BatchNorm(Function):
              ptr(running_var), float(momentum), BN_EPS, int(bool(relu)), B, C, N, ptr(ws), stream())
         ctx.save_for_backward(x, y, gamma, mean, invstd)
         ctx.relu, ctx.has_res = bool(relu), residual is not None
+        ctx.sinks = (_sink(gamma), _sink(beta))
         return y
 
     @staticmethod
@@ -172,12 +187,13 @@ class _BatchNorm(Function):
         N = x.numel() // (B * C)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
-        dgamma = torch.empty_like(gamma)
-        dbeta = torch.empty_like(gamma)
+        sunk = ctx.sinks[0] is not None and ctx.sinks[1] is not None
+        dgamma = ctx.sinks[0] if sunk else torch.empty_like(gamma)
+        dbeta = ctx.sinks[1] if sunk else torch.empty_like(gamma)
         ws = _ws(_lib.load().di2p_channel_reduce_workspace_bytes(B, C, N), x.device)
         call("di2p_bn_train_backward", ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(mean), ptr(invstd), int(ctx.relu), ptr(dx), ptr(dres),
              ptr(dgamma), ptr(dbeta), B, C, N, ptr(ws), stream())
-        return dx, dgamma, dbeta, None, None, None, None, dres
+        return dx, (None if sunk else dgamma), (None if sunk else dbeta), None, None, None, None, dres
 
 
 def batch_norm(P, key, x, relu, residual=None, momentum=0.1):

@@ -85,6 +85,7 @@ class ClassifierTrainer:
                 p.data = self.flat[off:off + k].view(p.shape)
                 p.requires_grad_(True)
                 p.grad = self.flat_grad[off:off + k].view(p.shape)
+                p._di2p_grad = p.grad          # the backward kernels write here directly (train_net._sink): no accumulation launches
                 off += k
         self.adam = FlatAdam(self.flat, lr=getattr(opt, "lr", 1e-3) if lr is None else lr, betas=betas)
 

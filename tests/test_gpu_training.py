@@ -225,3 +225,37 @@ def test_trainer_optimises_and_eval_path_follows():
     ev = tr.test_model(t["pc"], t["intensity"], t["sn"], t["node_a"], t["node_b"], t["img"], K, Pgt)
     assert np.isfinite(float(ev["loss"])) and 0.0 <= float(ev["coarse_accuracy"]) <= 1.0
     print("losses", ["%.3f" % v for v in losses], "eval loss %.3f coarse acc %.3f" % (float(ev["loss"]), float(ev["coarse_accuracy"])))
+
+
+def test_gradient_sinks_equal_autograd_accumulation():
+    """ClassifierTrainer makes the backward kernels write each parameter's gradient straight into its slice of the flat buffer;
+    the result must equal what autograd hands back for the same kernels (to round-off only: the max-pool backward adds its <= 4
+    overlapping windows with float atomics, whose order varies from run to run)."""
+    from deepi2p_amd import networks, synthetic, train_net as tn
+    from deepi2p_amd.training import ClassifierTrainer, classifier_loss
+    B, N, H, W = 2, 1024, 64, 128
+    opt = synthetic.OptLike(N, H, W, True)
+    sd = synthetic.random_state_dict(opt, 9)
+    b = synthetic.make_batch(5, B, N=N, H=H, W=W)
+    t = [torch.from_numpy(np.ascontiguousarray(b[k])).to(DEV) for k in ("pc", "intensity", "sn", "node_a", "node_b", "img")]
+    K = torch.from_numpy(b["K"]).float().to(DEV)
+    Pgt = torch.from_numpy(np.ascontiguousarray(b["P_gt"][:, :3, :])).float().to(DEV)
+    masks = [tn.dropout_mask((B, 256, N), 0.5, 77, i, DEV) for i in range(2)]
+    det = networks.KeypointDetector(opt)
+    det.load_state_dict(sd)
+    tr = ClassifierTrainer(det.to(DEV), opt)
+    tr.flat_grad.zero_()
+    scores, L = tr.forward_pass(*t, K, Pgt, True, masks)
+    scores.backward(torch.cat((L["d_coarse"], L["d_fine"]), dim=1))
+    P = {k: v.to(DEV) for k, v in sd.items()}
+    for k, v in P.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    s2 = tn.keypoint_detector(P, opt, *t, dropouts=masks)
+    assert torch.equal(s2, scores)
+    s2.backward(torch.cat((L["d_coarse"], L["d_fine"]), dim=1))
+    for name, p in det.named_parameters():
+        if P[name].grad is None:
+            assert float(p.grad.abs().max()) == 0.0, name
+        else:
+            _close(p.grad, P[name].grad, 1e-5, name)
