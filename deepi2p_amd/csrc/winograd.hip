@@ -263,6 +263,144 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(const float* __restrict_
     }
 }
 
+
+// ----------------------------------------------------------------------------------------------------------------------------------
+// Register-resident variant on v_mfma_f32_16x16x4_f32 (same rate as 32x32x2).  Its B operand -- lane l holds B[k = l>>4][n = l&15] --
+// is EXACTLY what a lane that transforms tile (l & 15), input channel k0 + (l >> 4) has in its registers: the 16 values of B^T d B are
+// the B fragments of 16 MFMAs (one per xi), with no LDS round trip and no panel.  A wave owns 16 tiles x COB = 32 output channels for
+// ALL sixteen xi (2 x 16 accumulators of 4 VGPRs = 128), so the inverse transform A^T M A also happens in the lane's own registers
+// (accumulator register r of lane l = channel 4*(l>>4) + r, tile l & 15): no exchange through LDS, no barrier in the epilogue.
+// Only the filter panel U[xi][4 channels][32 co] (8 KB per K-step of 4 channels, shared by the NW waves = NW*16 tiles of the
+// workgroup) goes through LDS, double buffered, one barrier per K-step; layout [xi][co half][k][16 co]: the 32 lanes of an LDS access
+// group hit 32 different banks.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void wino_reg_kernel(const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ residual, float* __restrict__ y,
+                                                           int Cin, int H, int W, int Cout, int TH, int TW, int total_tiles, int n_tb, int n_cb, int relu) {
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    constexpr int NT = NW * 64, KC = 4, PANEL = 16 * KC * 32;         // floats per U panel
+    constexpr int UP = PANEL / 4 / NT;                                 // 16-byte U loads per thread and K-step (2 at 256 threads, 4 at 128)
+    __shared__ __attribute__((aligned(16))) float Us[2][PANEL];
+    const int lin = blockIdx.x, xcd = lin & 7, seq = lin >> 3;
+    const int cb = seq % n_cb, tb = (seq / n_cb) * 8 + xcd;
+    if (tb >= n_tb) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int co_blk = cb * 32;
+    // this lane's tile and channel-of-the-K-step
+    const int gt = tb * (NW * 16) + wave * 16 + l15;
+    const bool tvalid = gt < total_tiles;
+    const int gtc = tvalid ? gt : total_tiles - 1;
+    const int b = gtc / (TH * TW), rem = gtc - b * TH * TW, ty = rem / TW, tx = rem - ty * TW;
+    const int c0 = 2 * tx - 1, cs = min(max(c0, 0), W - 4);
+    const bool left = c0 < cs, right = c0 > cs;
+    bool rowok[4];
+    const float* rp[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int iy = 2 * ty - 1 + r;
+        rowok[r] = tvalid && iy >= 0 && iy < H;
+        rp[r] = x + ((long long)b * Cin + kq) * H * W + (long long)min(max(iy, 0), H - 1) * W + cs;
+    }
+    const long long x_step = (long long)KC * H * W, u_step = (long long)KC * Cout;
+    const float* up[UP];
+    int udst[UP];
+#pragma unroll
+    for (int p = 0; p < UP; ++p) {
+        const int f = tid + NT * p, co4 = f & 7, row = f >> 3;           // row = xi*4 + k ; 8 x 16-byte words per 32-co row
+        up[p] = U + ((long long)(row >> 2) * Cin + (row & 3)) * Cout + co_blk + co4 * 4;
+        udst[p] = (row >> 2) * 128 + (co4 >> 2) * 64 + (row & 3) * 16 + (co4 & 3) * 4;      // [xi][half][k][16]
+    }
+    F4u drow[4];
+    f32x4v ureg[UP];
+    float bv[16];
+    auto gload = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) drow[r] = *reinterpret_cast<const F4u*>(rp[r] + t * x_step);
+#pragma unroll
+        for (int p = 0; p < UP; ++p) ureg[p] = *reinterpret_cast<const f32x4v*>(up[p] + t * u_step);
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {           // U panel -> LDS, input tile -> B fragments
+#pragma unroll
+        for (int p = 0; p < UP; ++p) *reinterpret_cast<f32x4v*>(&Us[buf][udst[p]]) = ureg[p];
+        float v[16], t[16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float l0 = rowok[r] ? drow[r].x : 0.0f, l1 = rowok[r] ? drow[r].y : 0.0f, l2 = rowok[r] ? drow[r].z : 0.0f,
+                        l3 = rowok[r] ? drow[r].w : 0.0f;
+            v[r * 4 + 0] = left ? 0.0f : (right ? l1 : l0);
+            v[r * 4 + 1] = left ? l0 : (right ? l2 : l1);
+            v[r * 4 + 2] = left ? l1 : (right ? l3 : l2);
+            v[r * 4 + 3] = left ? l2 : (right ? 0.0f : l3);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            t[0 * 4 + c] = v[0 * 4 + c] - v[2 * 4 + c];
+            t[1 * 4 + c] = v[1 * 4 + c] + v[2 * 4 + c];
+            t[2 * 4 + c] = v[2 * 4 + c] - v[1 * 4 + c];
+            t[3 * 4 + c] = v[1 * 4 + c] - v[3 * 4 + c];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bv[r * 4 + 0] = t[r * 4 + 0] - t[r * 4 + 2];
+            bv[r * 4 + 1] = t[r * 4 + 1] + t[r * 4 + 2];
+            bv[r * 4 + 2] = t[r * 4 + 2] - t[r * 4 + 1];
+            bv[r * 4 + 3] = t[r * 4 + 1] - t[r * 4 + 3];
+        }
+    };
+    f32x4v acc[16][2];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) acc[xi][h] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int T = Cin / KC;
+    gload(0);
+    stage(0);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < T) gload(t + 1);
+        const float* Ab = &Us[buf][kq * 16 + l15];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            const float a0 = Ab[xi * 128], a1 = Ab[xi * 128 + 64];
+            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv[xi], acc[xi][0], 0, 0, 0);
+            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv[xi], acc[xi][1], 0, 0, 0);
+        }
+        if (t + 1 < T) stage(buf ^ 1);
+        __syncthreads();
+    }
+    // ---- epilogue, all in registers: lane = tile l15, channels co_blk + 16h + 4*kq + r
+    if (!tvalid) return;
+    const int oy = 2 * ty, ox = 2 * tx;
+    const bool row1 = oy + 1 < H;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co_blk + h * 16 + 4 * kq + r;
+            float m[16];
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) m[xi] = acc[xi][h][r];
+            float s0[4], s1[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { s0[c] = m[c] + m[4 + c] + m[8 + c]; s1[c] = m[4 + c] - m[8 + c] - m[12 + c]; }
+            float o00 = s0[0] + s0[1] + s0[2], o01 = s0[1] - s0[2] - s0[3];
+            float o10 = s1[0] + s1[1] + s1[2], o11 = s1[1] - s1[2] - s1[3];
+            const float sc = scale[co], sh = shift[co];
+            const long long o = (((long long)b * Cout + co) * H + oy) * W + ox;
+            o00 = o00 * sc + sh; o01 = o01 * sc + sh; o10 = o10 * sc + sh; o11 = o11 * sc + sh;
+            if (residual) {
+                const float2 q0 = *reinterpret_cast<const float2*>(residual + o);
+                o00 += q0.x; o01 += q0.y;
+                if (row1) { const float2 q1 = *reinterpret_cast<const float2*>(residual + o + W); o10 += q1.x; o11 += q1.y; }
+            }
+            if (relu) { o00 = fmaxf(o00, 0.0f); o01 = fmaxf(o01, 0.0f); o10 = fmaxf(o10, 0.0f); o11 = fmaxf(o11, 0.0f); }
+            *reinterpret_cast<float2*>(y + o) = make_float2(o00, o01);
+            if (row1) *reinterpret_cast<float2*>(y + o + W) = make_float2(o10, o11);
+        }
+}
+
 }  // namespace
 
 extern "C" int di2p_winograd_weight_transform(const float* weight, float* U, int Cin, int Cout, void* stream) {
@@ -299,6 +437,19 @@ extern "C" int di2p_conv3x3_winograd(const float* x, const float* U, const float
         hipLaunchKernelGGL((wino_conv_kernel<COBV, DBV, KCV>), dim3(grid), dim3(256), lds, st, x, U, scale, shift, residual, y, Cin, H, W, Cout, \
                            TH, TW, (int)total, n_tb, n_cb, relu, by_co);                                                                     \
     } while (0)
+    const long long reg_opt = di2p_opt(DI2P_OPT_WINO_REG);      // 0: automatic, 1: LDS-panel kernel, 2: register-resident, 4 waves, 3: 2 waves
+    // automatic: the register-resident kernel where its 64-tile workgroups still fill the chip four times over (ResNet stage 1:
+    // 82 vs 100 us); it holds 128 accumulator registers per lane (2 waves per SIMD), so on smaller grids the LDS-panel kernel's
+    // higher occupancy wins (stage 3: 89 vs 99 us)
+    const bool reg_auto = reg_opt == 0 && (long long)di2p_cdiv(total, 64) * (Cout / 32) >= 1024;
+    if ((reg_opt >= 2 || reg_auto) && Cin % 4 == 0 && ((uintptr_t)residual & 7) == 0) {
+        const int nw = reg_opt == 3 ? 2 : 4;
+        const int n_tb_r = di2p_cdiv(total, nw * 16), n_cb = Cout / 32;
+        const int grid = di2p_cdiv(n_tb_r, 8) * 8 * n_cb;
+        if (nw == 4) hipLaunchKernelGGL(wino_reg_kernel<4>, dim3(grid), dim3(256), 0, st, x, U, scale, shift, residual, y, Cin, H, W, Cout, TH, TW, (int)total, n_tb_r, n_cb, relu);
+        else hipLaunchKernelGGL(wino_reg_kernel<2>, dim3(grid), dim3(128), 0, st, x, U, scale, shift, residual, y, Cin, H, W, Cout, TH, TW, (int)total, n_tb_r, n_cb, relu);
+        DI2P_RETURN_LAUNCH();
+    }
     const long long kc_opt = di2p_opt(DI2P_OPT_WINO_KC);
     const bool kc4 = kc_opt ? kc_opt == 4 : Cin <= 256;      // measured in the pipeline: K-step 4 wins up to 256 input channels, 8 at 512
     if (cob64) {

@@ -183,8 +183,9 @@ def test_conv3x3_winograd(dev, B, Cin, H, W, Cout):
     U = ops.winograd_weights(w.to(dev))
     direct = ops.conv2d(x.to(dev), w.reshape(Cout, -1).t().contiguous().to(dev), scale.to(dev), shift.to(dev), 3, 3, 1, 1, True, residual=res.to(dev)).cpu()
     e_direct = float((direct.double() - ref).abs().max())
-    for cob, kc in ((32, 8), (64, 8), (32, 4), (64, 4)) if Cout % 64 == 0 else ((32, 8), (32, 4)):
-        with _lib.option("wino_cob", cob), _lib.option("wino_kc", kc):
+    variants = [(32, 8, 1), (32, 4, 1), (0, 0, 2), (0, 0, 3)] + ([(64, 8, 1), (64, 4, 1)] if Cout % 64 == 0 else [])
+    for cob, kc, reg in variants:       # reg 1: LDS-panel kernel (co-block, K-step), 2 / 3: register-resident kernel with 4 / 2 waves
+        with _lib.option("wino_cob", cob), _lib.option("wino_kc", kc), _lib.option("wino_reg", reg):
             y = ops.conv3x3_winograd(x.to(dev), U, scale.to(dev), shift.to(dev), True, residual=res.to(dev)).cpu()
             y2 = ops.conv3x3_winograd(x.to(dev), U, scale.to(dev), shift.to(dev), False).cpu()
         assert y.shape == ref.shape

@@ -31,13 +31,12 @@ for (C, H, W, calls) in ((64, 40, 128, 6), (128, 20, 64, 7), (256, 10, 32, 11), 
     fl = 2.0 * B * H * W * C * C * 9
     td = timeit(lambda: ops.conv2d(x, Wtap, sc, sh, 3, 3, 1, 1, True, residual=res, tap_major=True))
     out = []
-    for kc in (8, 4):
-        for cob in (32, 64):
-            with _lib.option("wino_cob", cob), _lib.option("wino_kc", kc):
-                out.append(timeit(lambda: ops.conv3x3_winograd(x, U, sc, sh, True, residual=res)))
+    for kc, cob, reg in ((8, 32, 1), (4, 32, 1), (0, 0, 2), (0, 0, 3)):
+        with _lib.option("wino_cob", cob), _lib.option("wino_kc", kc), _lib.option("wino_reg", reg):
+            out.append(timeit(lambda: ops.conv3x3_winograd(x, U, sc, sh, True, residual=res)))
     best = min(v for v in out if v == v)
     tot[0] += td * calls; tot[1] += best * calls
-    print("%-22s %10.1f %8.1f | K-step 8: cob32 %6.1f cob64 %6.1f | K-step 4: cob32 %6.1f cob64 %6.1f | best %.1f TF" % (
+    print("%-22s %10.1f %8.1f | LDS panels K-step 8 %6.1f K-step 4 %6.1f | register-resident 4 waves %6.1f 2 waves %6.1f | best %.1f TF" % (
         "%d,%d,%d,%d" % (C, H, W, C), td, fl / td / 1e6, out[0], out[1], out[2], out[3], fl / best / 1e6))
 print("26 layers per 32-frame step: direct %.3f ms, Winograd (better blocking per shape) %.3f ms" % (tot[0] / 1e3, tot[1] / 1e3))
 
