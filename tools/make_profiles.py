@@ -1,0 +1,134 @@
+"""Builds profiles/<tag>_* from the outputs of tools/final_round.sh in gpurun_out/ (run in the build container):
+copies the evidence files, derives <tag>_pmc_traffic.json from the counter passes and writes <tag>_README.md.
+    python tools/make_profiles.py r02"""
+import csv, json, os, shutil, sys
+
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G, P = os.path.join(ROOT, "gpurun_out") + "/", os.path.join(ROOT, "profiles") + "/"
+KEEP_OLD = ("%s_sweep_solver_cfg.txt" % TAG, "%s_winograd_counters.txt" % TAG)
+
+
+def rows(fn):
+    return list(csv.DictReader(open(G + fn)))
+
+
+for f in os.listdir(G):
+    if f.startswith(TAG + "_") and f.endswith((".csv", ".json", ".txt")) and f != TAG + "_sweep_cfg.txt":
+        shutil.copy(G + f, P + f)
+
+# ---- counter-derived HBM traffic
+passes = 13            # tools/bench_conv.py: 3 warm-up + 10 timed encoder passes
+conv_kernels = ("wino_conv_kernel", "wino_reg_kernel", "conv2d_vec_kernel", "conv2d_kernel", "conv2d_stem_kernel", "stem_conv_kernel", "conv_splitk_reduce_kernel")
+fetch16 = ("wino_conv_kernel", "wino_reg_kernel", "conv2d_vec_kernel", "conv_splitk_reduce_kernel")
+F = {r["kernel"]: r for r in rows(TAG + "_pmc_conv_FETCH_SIZE.csv")}
+Wr = {r["kernel"]: r for r in rows(TAG + "_pmc_conv_WRITE_SIZE.csv")}
+fr = fc = wr = launches = 0.0
+per_kernel = {}
+short = lambda k: k.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:60]
+for k, r in F.items():
+    if any(c in k for c in conv_kernels):
+        s = float(r["sum"]) / passes
+        fr += s; fc += s * (2 if any(c in k for c in fetch16) else 1); launches += int(r["launches"]) / passes
+        per_kernel[short(k)] = {"launches_per_pass": int(r["launches"]) / passes, "FETCH_KiB_per_pass": round(s, 1)}
+for k, r in Wr.items():
+    if any(c in k for c in conv_kernels):
+        s = float(r["sum"]) / passes; wr += s
+        per_kernel.setdefault(short(k), {})["WRITE_KiB_per_pass"] = round(s, 1)
+r1 = json.load(open(P + "r01_pmc_traffic.json"))
+sol_f = [r for r in rows(TAG + "_pmc_solver_FETCH_SIZE.csv") if "solve_kernel" in r["kernel"]][0]
+sol_w = [r for r in rows(TAG + "_pmc_solver_WRITE_SIZE.csv") if "solve_kernel" in r["kernel"]][0]
+fk, wk = float(sol_f["mean_per_launch"]), float(sol_w["mean_per_launch"])
+out = {"units": r1["units"] + "; solver records and the 16-byte staged convolution kernels corrected x2; WRITE_SIZE raw",
+       "commands": ["tools/profile_round.sh %s: rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python tools/bench_solver.py | tools/bench_conv.py (13 encoder passes)" % TAG],
+       "carried_over_from_r01": ["index_max_C64_B32_N20480_K128", "index_max_C32_B32_N20480_K128"],
+       "index_max_C64_B32_N20480_K128": r1["index_max_C64_B32_N20480_K128"], "index_max_C32_B32_N20480_K128": r1["index_max_C32_B32_N20480_K128"],
+       "solve_kernel_F32_R60_N20480": {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "fetch_bytes_corrected": fk * 2048, "hbm_bytes_corrected": fk * 2048 + wk * 1024,
+                                       "compulsory_bytes": 32 * 20480 * 16 + 32 * 320 * 32, "launches": int(sol_f["launches"]),
+                                       "note": "one launch = 32 frames x 60 hypotheses; a frame's records + boxes (338 KB) are read ~63 sweeps x 60 hypotheses times but stay cache resident; WRITE_SIZE ~= the kernel's private segment written back once"},
+       "conv2d_resnet34_B32_160x512": {"FETCH_SIZE_KiB_per_encoder_pass_raw": fr, "FETCH_SIZE_KiB_per_encoder_pass_corrected": fc, "WRITE_SIZE_KiB_per_encoder_pass_raw": wr,
+                                       "kernel_launches_per_pass": launches, "conv_calls_per_pass": 36, "hbm_bytes_per_call_corrected": (fc + wr) * 1024 / 36,
+                                       "hbm_bytes_per_call_raw": (fr + wr) * 1024 / 36, "per_kernel": per_kernel,
+                                       "note": "sum over the convolution kernels of one image-encoder pass (Winograd launches, implicit-GEMM launches + split-K reduce, the direct stem); FETCH x2 for the kernels that load 16 B per lane, stem raw (dword loads: uncalibrated)"}}
+json.dump(out, open(P + TAG + "_pmc_traffic.json", "w"), indent=1)
+
+
+# ---- README
+def table(path, n=14):
+    rr = list(csv.DictReader(open(path)))
+    o = ["| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
+    for r in rr[:n]:
+        name = r["Name"].replace("void ", "").replace("(anonymous namespace)::", "")[:80].replace("|", "/")
+        o.append("| `%s` | %s | %.2f | %.1f | %.1f |" % (name, r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+    return "\n".join(o)
+
+
+line, ser, s3 = (json.load(open(P + TAG + n)) for n in ("_bench_line.json", "_bench_line_serial.json", "_bench_line_streams3.json"))
+tr, pm = json.load(open(P + TAG + "_train_line.json")), out
+k = line["kernels"]; cv = k["conv2d_kernel"]; pw = k["pointwise_gemm_kernel(+point_head)"]
+srows = list(csv.DictReader(open(P + TAG + "_bench_kernel_stats_serial.csv")))
+
+
+def avg(sub):
+    r = [x for x in srows if sub in x["Name"]]
+    return sum(float(x["TotalDurationNs"]) for x in r) / max(1, sum(int(x["Calls"]) for x in r)) / 1e3
+
+
+gt = open(P + TAG + "_gputest_tail.txt").read().strip().splitlines()[-1]
+wl = open(P + TAG + "_winograd_layers.txt").read().strip().splitlines()
+cvp = pm["conv2d_resnet34_B32_160x512"]; sp = pm["solve_kernel_F32_R60_N20480"]
+txt = f"""# Round-2 profiles (1x MI355X, ROCm 7.2)
+
+Everything here was produced by ONE gpurun call of `tools/final_round.sh {TAG}` (GPU tests, `bench.py`, `bench.py --mode train`, the
+micro-benchmarks, `tools/profile_round.sh {TAG}`) at the end of the round and turned into this directory by `tools/make_profiles.py`;
+`{TAG}_sweep_solver_cfg.txt` and `{TAG}_winograd_counters.txt` come from earlier calls of the round.
+
+* `{TAG}_gputest_tail.txt` -- `python -m pytest tests -q -m gpu`: {gt}.
+* `{TAG}_bench_line.json` -- the JSON line of `python bench.py` (12 steps, 3 warm-up, 3 streams, one hipGraph per stream, CPU baseline
+  leg included): **{line['value']:.0f} frames/s** resident ({line['ms_per_step']:.2f} ms per 32-frame step), {line['value_with_h2d']:.0f} frames/s with the
+  host->device copy of every batch inside the step (round 1: 2225).  Roofline object = time-dominant family = `solve_kernel`:
+  {k['solve_kernel']['ms_per_step']:.2f} ms per step, {k['solve_kernel']['achieved']:.1f} TFLOP/s by SURVEY 8(d)'s unit = {k['solve_kernel']['frac']:.2f} of the 78.6 TFLOP/s fp64 vector peak.
+  Per family (`kernels`): convolution {cv['ms_per_step']:.2f} ms = {cv['achieved']:.1f} TFLOP/s algorithmic = **{cv['frac']:.2f}** of the fp32-MFMA peak (26 Winograd
+  launches {cv['winograd']['ms_per_step']:.2f} ms, whose MFMA units issue {cv['winograd']['executed_mfma_tflops']:.0f} TFLOP/s; 9 implicit-GEMM launches {cv['winograd']['direct_kernel_ms_per_step']:.2f} ms; stem
+  {cv['winograd']['stem_kernel_ms_per_step']:.2f} ms); pointwise {pw['ms_per_step']:.2f} ms ({pw['achieved']:.0f} TFLOP/s reference-algorithmic, {pw['achieved_executed']:.0f} executed); index_max
+  {k['index_max_kernel']['ms_per_step']*1e3:.0f} us in-pipeline ({k['index_max_kernel']['achieved']:.0f} GB/s).  CPU baseline: {line['cpu_baseline']['value']:.3f} frames/s on {line['cpu_baseline']['cores']} threads.
+* `{TAG}_bench_kernel_stats_streams3.csv` / `{TAG}_bench_line_streams3.json` -- `rocprofv3 --kernel-trace --stats --output-format csv --
+  python bench.py --no-cpu-baseline --no-h2d-pass` ({s3['value']:.0f} frames/s under the profiler); three batches in flight: durations include
+  contention.
+* `{TAG}_bench_kernel_stats_serial.csv` / `{TAG}_bench_line_serial.json` -- the same with `--streams 1` ({ser['value']:.0f} frames/s): durations without
+  contention.  `solve_kernel` averages {avg('solve_kernel')/1e3:.2f} ms (rocprof) against {ser['kernels']['solve_kernel']['ms_per_step']:.2f} ms from the HIP events of the same run's JSON
+  line; `wino_conv_kernel<32, true, 4>` {avg('wino_conv_kernel<32, true, 4>'):.1f} us, `<32, true, 8>` {avg('wino_conv_kernel<32, true, 8>'):.1f} us, `wino_reg_kernel<4>` {avg('wino_reg_kernel<4>'):.1f} us per call.
+* `{TAG}_pmc_{{solver,conv}}_{{FETCH,WRITE}}_SIZE.csv`, `{TAG}_pmc_traffic.json` -- separate `--pmc` passes (kernel-trace only) on
+  `tools/bench_solver.py` and `tools/bench_conv.py`.  solve_kernel: {sp['FETCH_SIZE_KiB']/1024:.1f} MiB fetched raw (x2 = {sp['fetch_bytes_corrected']/1e6:.1f} MB) per launch against 10.8 MB
+  of once-through records + boxes (the working set is cache resident), {sp['WRITE_SIZE_KiB']/1024:.1f} MiB written (scratch segment).  Convolution family of one
+  encoder pass: FETCH {cvp['FETCH_SIZE_KiB_per_encoder_pass_raw']/1024:.0f} MiB raw / {cvp['FETCH_SIZE_KiB_per_encoder_pass_corrected']/1024:.0f} MiB corrected, WRITE {cvp['WRITE_SIZE_KiB_per_encoder_pass_raw']/1024:.0f} MiB = {cvp['hbm_bytes_per_call_corrected']/1e6:.0f} MB per convolution call against
+  52 MB compulsory (the Winograd workgroups re-stream their slice of the transformed filters: under 1 TB/s over the family's time
+  -- not a limiter).  The index_max entries are carried over from round 1 (kernel unchanged).  (`{TAG}_bench_line.json` was written before
+  this file was rebuilt: its `traffic` fields show the previous counter file's values.)
+* `{TAG}_conv_layers.txt`, `{TAG}_winograd_layers.txt` -- per-layer timings: the remaining implicit-GEMM layers (stride-2 3x3, 1x1
+  downsample) and, for the four 3x3 stride-1 shapes at B = 32, direct vs the Winograd variants:
+```
+{chr(10).join(wl[-7:])}
+```
+* `{TAG}_winograd_counters.txt` -- `tools/prof_winograd.sh`: SQ / TA / TCP / TCC counters of `wino_conv_kernel` on the stage-3 shape.
+* `{TAG}_solver_phases.txt` -- `PROF=1 python tools/bench_solver.py`: clock64() phase counters, cluster / line-search statistics, sweep-count
+  percentiles.  `{TAG}_sweep_solver_cfg.txt` -- the headline with 4 / 2 / 1 waves per hypothesis (4 x 3 per SIMD stays).
+* `{TAG}_index_max_cold.txt` -- cache-cold index_max.
+* `{TAG}_train_line.json`, `{TAG}_train_kernel_stats.csv` -- `python bench.py --mode train` (reference training configuration: batch 8, 20480
+  points, 160x512, coarse+fine): **{tr['ms_per_step']:.1f} ms per step = {tr['value']:.0f} frames/s** (34.0 ms with every convolution on the generic kernels),
+  and `rocprofv3 --kernel-trace --stats` of the same command.
+
+Top kernels of the bench command (3 streams, durations include overlap):
+
+{table(P + TAG + '_bench_kernel_stats_streams3.csv')}
+
+Same, one batch at a time (`--streams 1`):
+
+{table(P + TAG + '_bench_kernel_stats_serial.csv')}
+
+Training step (`--mode train`, batch 8):
+
+{table(P + TAG + '_train_kernel_stats.csv', 12)}
+"""
+open(P + TAG + "_README.md", "w").write(txt)
+print("profiles/%s_* rebuilt: %.0f frames/s, conv frac %.2f, train %.1f ms" % (TAG, line["value"], cv["frac"], tr["ms_per_step"]))
