@@ -1526,6 +1526,7 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
         switch (cfg) {
             case 42: DI2P_LAUNCH_SOLVE(4, 2, 4, pend1, tier, 0); break;
             case 82: DI2P_LAUNCH_SOLVE(4, 2, 8, pend1, tier, 0); break;
+            case 44: DI2P_LAUNCH_SOLVE(4, 4, 4, pend1, tier, 0); break;
             case 22: DI2P_LAUNCH_SOLVE(4, 2, 2, pend1, tier, 0); break;
             case 23: DI2P_LAUNCH_SOLVE(4, 3, 2, pend1, tier, 0); break;
             case 12: DI2P_LAUNCH_SOLVE(4, 2, 1, pend1, tier, 0); break;
