@@ -467,8 +467,27 @@ class MMClassifer:
     def _trainer(self):
         if getattr(self, "_trainer_obj", None) is None:
             from .training import ClassifierTrainer
-            self._trainer_obj = ClassifierTrainer(self.detector, self.opt)
+            self._trainer_obj = ClassifierTrainer(self.detector, self.opt, lr=self._lr())
         return self._trainer_obj
+
+    def _lr(self):
+        if getattr(self, "old_lr_detector", None) is None:
+            self.old_lr_detector = float(getattr(self.opt, "lr", 1e-3))
+        return self.old_lr_detector
+
+    def save_network(self, network, save_filename):
+        """multimodal_classifier.py:263-265: the reference's 361-key state_dict (tensors copied out of the trainer's flat buffer)."""
+        import os
+        save_path = os.path.join(getattr(self.opt, "checkpoints_dir", "."), save_filename)
+        torch.save({k: v.detach().clone().cpu() for k, v in network.state_dict().items()}, save_path)
+
+    def update_learning_rate(self, ratio):
+        """multimodal_classifier.py:267-277: lr = max(old_lr * ratio, 1e-5) (kitti/train_classifier.py:95-101 calls it with lr_decay_scale)."""
+        lr_detector = max(self._lr() * ratio, 0.00001)
+        if getattr(self, "_trainer_obj", None) is not None:
+            self._trainer_obj.adam.lr = lr_detector
+        print('update detector learning rate: %f -> %f' % (self.old_lr_detector, lr_detector))
+        self.old_lr_detector = lr_detector
 
     def _record(self, L, prefix):
         setattr(self, prefix + "_loss_dict", {"loss": L["loss"], "coarse": L["coarse"], "fine": L["fine"]})

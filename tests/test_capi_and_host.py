@@ -119,3 +119,26 @@ def test_shard_ranges():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_classifier_checkpoint_and_lr_helpers(tmp_path):
+    """save_network / load_model / update_learning_rate of the MMClassifer mirror (multimodal_classifier.py:75-80,263-277): host logic
+    only -- the 361-key state_dict round-trips through a file, the learning-rate rule clips at 1e-5."""
+    import torch
+    from deepi2p_amd import synthetic
+    from deepi2p_amd.networks import MMClassifer
+    opt = synthetic.OptLike(256, 32, 64, True)
+    opt.device, opt.checkpoints_dir, opt.lr = torch.device("cpu"), str(tmp_path), 1e-3
+    m = MMClassifer(opt)
+    sd = synthetic.random_state_dict(opt, 1)
+    m.detector.load_state_dict(sd)
+    m.save_network(m.detector, "gpu0_0_net_detector.pth")
+    m2 = MMClassifer(opt)
+    m2.load_model(str(tmp_path / "gpu0_0_net_detector.pth"))
+    got = m2.detector.state_dict()
+    assert set(got) == set(sd) and len(got) == 361
+    assert all(torch.equal(got[k], sd[k]) for k in sd)
+    m.update_learning_rate(0.5)
+    assert abs(m.old_lr_detector - 5e-4) < 1e-12
+    m.update_learning_rate(1e-6)
+    assert m.old_lr_detector == 0.00001
