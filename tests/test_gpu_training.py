@@ -259,3 +259,30 @@ def test_gradient_sinks_equal_autograd_accumulation():
             assert float(p.grad.abs().max()) == 0.0, name
         else:
             _close(p.grad, P[name].grad, 1e-5, name)
+
+
+def test_mmclassifer_optimize_api():
+    """The reference's training entry points on the module mirror (multimodal_classifier.py:213-223,263-277): set_input -> optimize()
+    records train_loss_dict / train_accuracy, test_model() the eval-mode ones, update_learning_rate() reaches the optimiser."""
+    from deepi2p_amd import synthetic
+    from deepi2p_amd.networks import MMClassifer
+    B, N, H, W = 2, 1024, 64, 128
+    opt = synthetic.OptLike(N, H, W, True)
+    opt.device, opt.lr, opt.coarse_loss_alpha = torch.device(DEV), 1e-3, 50.0
+    m = MMClassifer(opt)
+    m.detector.load_state_dict(synthetic.random_state_dict(opt, 2))
+    b = synthetic.make_batch(8, B, N=N, H=H, W=W)
+    m.set_input(*[torch.from_numpy(np.ascontiguousarray(b[k])) for k in ("pc", "intensity", "sn", "node_a", "node_b")],
+                torch.from_numpy(np.ascontiguousarray(b["P_gt"][:, :3, :])).float(), torch.from_numpy(b["img"]), torch.from_numpy(b["K"]).float())
+    m.optimize()
+    first = float(m.train_loss_dict["loss"])
+    for _ in range(4):
+        m.optimize()
+    assert set(m.train_loss_dict) == {"loss", "coarse", "fine"} and set(m.train_accuracy) == {"coarse_accuracy", "fine_accuracy"}
+    assert np.isfinite(first) and float(m.train_loss_dict["loss"]) < first
+    m.update_learning_rate(0.5)
+    assert m._trainer_obj.adam.lr == 5e-4
+    m.test_model()
+    assert np.isfinite(float(m.test_loss_dict["loss"])) and 0.0 <= float(m.test_accuracy["coarse_accuracy"]) <= 1.0
+    labels = m.inference_pass()                      # the inference kernels pick up the updated weights
+    assert labels[0].shape == (B, N)
