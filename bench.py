@@ -521,8 +521,9 @@ def main_train(args):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         sync_all()
         e0.record()
+        from deepi2p_amd.training import allreduce_gradients
         for _ in range(5):
-            dist.all_reduce(tr.flat_grad)
+            allreduce_gradients(tr.flat_grad)
         e1.record()
         torch.cuda.synchronize()
         ar_ms = e0.elapsed_time(e1) / 5

@@ -55,7 +55,12 @@ def allreduce_gradients(flat_grads, group=None):
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return flat_grads
-    dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+    if flat_grads.is_cuda and dist.get_backend(group) == "gloo":      # test mode (no RCCL): through host memory
+        h = flat_grads.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        flat_grads.copy_(h)
+    else:
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
     flat_grads.div_(dist.get_world_size(group))
     return flat_grads
 

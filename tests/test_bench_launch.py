@@ -74,3 +74,16 @@ def test_two_ranks_full_path_on_one_device(mode):
     assert line["scaling"] == ("weak" if mode == "frames" else "strong")
     assert line["pose_check"]["frames_with_inside_points"] == line["pose_check"]["frames"]
     assert line["roofline"]["kernel"] in line["kernels"] and line["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_training_step_on_one_device():
+    """--mode train with 2 ranks (gloo, shared device): data-parallel optimisation steps with one all-reduce of the flat gradient
+    buffer per step; both ranks keep identical weights, the loss falls."""
+    args = [sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--mode", "train", "--batch", "2", "--points", "2048"]
+    r = subprocess.run(args, env=_env(DI2P_BENCH_ONE_DEVICE="1"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 2 and line["config"]["mode"] == "train" and line["value"] > 0
+    assert line["gradient_allreduce"]["bytes"] > 1e8 and line["gradient_allreduce"]["ms"] > 0
+    assert line["loss_first_last"][1] < line["loss_first_last"][0]
