@@ -441,7 +441,7 @@ extern "C" int di2p_conv3x3_winograd(const float* x, const float* U, const float
     // automatic: the register-resident kernel where its 64-tile workgroups still fill the chip four times over (ResNet stage 1:
     // 82 vs 100 us); it holds 128 accumulator registers per lane (2 waves per SIMD), so on smaller grids the LDS-panel kernel's
     // higher occupancy wins (stage 3: 89 vs 99 us)
-    const bool reg_auto = reg_opt == 0 && (long long)di2p_cdiv(total, 64) * (Cout / 32) >= 1024;
+    const bool reg_auto = reg_opt == 0 && (long long)di2p_cdiv(total, 64) * (Cout / 32) >= di2p_opt(DI2P_OPT_WINO_REG_MIN);
     if ((reg_opt >= 2 || reg_auto) && Cin % 4 == 0 && ((uintptr_t)residual & 7) == 0) {
         const int nw = reg_opt == 3 ? 2 : 4;
         const int n_tb_r = di2p_cdiv(total, nw * 16), n_cb = Cout / 32;
