@@ -27,6 +27,9 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# One hardware queue per HIP stream: the runtime's default of 4 makes stream counts above 3 share queues (4 streams are slower than 3,
+# see DESIGN.md section 4); must be set before the HIP runtime initialises (torch is imported inside main()).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
@@ -82,8 +85,8 @@ def conv_bytes_per_frame(H, W):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--mode", choices=("frames", "hyp", "train"), default="frames",
                     help="frames: the headline (BASELINE configs[1]); hyp: configs[4], hypotheses sharded over the ranks; "
                          "train: one optimisation step of the classifier (SURVEY 8f rank 4), data-parallel with one gradient all-reduce")
@@ -91,7 +94,9 @@ def parse_args(argv=None):
     ap.add_argument("--points", type=int, default=None)
     ap.add_argument("--restarts", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams = batches in flight (1 = fully serial)")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="HIP streams = batches in flight (1 = fully serial); default 8 for the frames mode (with GPU_MAX_HW_QUEUES=16, "
+                         "set below unless the environment already has it), 3 otherwise")
     ap.add_argument("--no-h2d-pass", action="store_true", help="skip the second timed loop with the H2D copy inside the step")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per stream")
     ap.add_argument("--launch-selftest", action="store_true",
@@ -227,7 +232,7 @@ def main():
     # S HIP streams, round-robin: whole steps (classifier -> pose solve of one batch) are independent, so several are
     # kept in flight; every step is still one full batch through the whole path on its own stream, and all K steps
     # complete inside the timed region.  Each stream owns a slot of input buffers for the H2D-inclusive pass.
-    n_streams = max(1, args.streams)
+    n_streams = max(1, args.streams if args.streams is not None else (3 if hyp else 8))
     streams = [torch.cuda.Stream() for _ in range(n_streams)]
     resident = {k: getattr(mm, k) for k in names}
     slots = [resident] + [{k: torch.empty_like(v) for k, v in resident.items()} for _ in range(n_streams - 1)]
@@ -315,7 +320,9 @@ def main():
     run_step = graph_step if use_graph else step
 
     def timed_loop(with_h2d):
-        for _ in range(max(args.warmup, n_streams if use_graph else 0)):
+        for _ in range(n_streams if use_graph else 0):      # set-up, not warm-up: first replay of every stream's graph (the H2D variants
+            run_step(with_h2d)                              # are captured here), so that the W warm-up steps below are exactly W
+        for _ in range(args.warmup):
             run_step(with_h2d)
         sync_all()
         t0 = time.perf_counter()
@@ -457,7 +464,7 @@ def main():
                                    ("BASELINE configs[1]: KITTI 20480-pt / 160x512, batch %d per GPU, coarse classification "
                                     "+ %d-restart 2D GN/LM solver, max_iter 500" % (B, R)),
                        "mode": args.mode, "frames_per_gpu_per_step": B, "points": N, "image": [H, W], "restarts": R,
-                       "parallelism": ("hyp%d" if hyp else "dp%d") % world, "streams": n_streams, "hip_graph": bool(use_graph),
+                       "parallelism": ("hyp%d" if hyp else "dp%d") % world, "streams": n_streams, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "hip_graph": bool(use_graph),
                        "weights_broadcast_bytes": bcast_bytes},
             "value_with_h2d": (frames / dt_h2d) if dt_h2d else None,
             "ms_per_step_with_h2d": (dt_h2d / args.steps * 1e3) if dt_h2d else None,

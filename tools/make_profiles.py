@@ -63,7 +63,7 @@ def table(path, n=14):
     return "\n".join(o)
 
 
-line, ser, s3 = (json.load(open(P + TAG + n)) for n in ("_bench_line.json", "_bench_line_serial.json", "_bench_line_streams3.json"))
+line, ser, s3 = (json.load(open(P + TAG + n)) for n in ("_bench_line.json", "_bench_line_serial.json", "_bench_line_pipelined.json"))
 tr, pm = json.load(open(P + TAG + "_train_line.json")), out
 k = line["kernels"]; cv = k["conv2d_kernel"]; pw = k["pointwise_gemm_kernel(+point_head)"]
 srows = list(csv.DictReader(open(P + TAG + "_bench_kernel_stats_serial.csv")))
@@ -84,7 +84,7 @@ micro-benchmarks, `tools/profile_round.sh {TAG}`) at the end of the round and tu
 `{TAG}_sweep_solver_cfg.txt` and `{TAG}_winograd_counters.txt` come from earlier calls of the round.
 
 * `{TAG}_gputest_tail.txt` -- `python -m pytest tests -q -m gpu`: {gt}.
-* `{TAG}_bench_line.json` -- the JSON line of `python bench.py` (12 steps, 3 warm-up, 3 streams, one hipGraph per stream, CPU baseline
+* `{TAG}_bench_line.json` -- the JSON line of `python bench.py` (12 steps, 3 warm-up, {line['config']['streams']} streams on {line['config']['hw_queues']} hardware queues, one hipGraph per stream, CPU baseline
   leg included): **{line['value']:.0f} frames/s** resident ({line['ms_per_step']:.2f} ms per 32-frame step), {line['value_with_h2d']:.0f} frames/s with the
   host->device copy of every batch inside the step (round 1: 2225).  Roofline object = time-dominant family = `solve_kernel`:
   {k['solve_kernel']['ms_per_step']:.2f} ms per step, {k['solve_kernel']['achieved']:.1f} TFLOP/s by SURVEY 8(d)'s unit = {k['solve_kernel']['frac']:.2f} of the 78.6 TFLOP/s fp64 vector peak.
@@ -92,8 +92,8 @@ micro-benchmarks, `tools/profile_round.sh {TAG}`) at the end of the round and tu
   launches {cv['winograd']['ms_per_step']:.2f} ms, whose MFMA units issue {cv['winograd']['executed_mfma_tflops']:.0f} TFLOP/s; 9 implicit-GEMM launches {cv['winograd']['direct_kernel_ms_per_step']:.2f} ms; stem
   {cv['winograd']['stem_kernel_ms_per_step']:.2f} ms); pointwise {pw['ms_per_step']:.2f} ms ({pw['achieved']:.0f} TFLOP/s reference-algorithmic, {pw['achieved_executed']:.0f} executed); index_max
   {k['index_max_kernel']['ms_per_step']*1e3:.0f} us in-pipeline ({k['index_max_kernel']['achieved']:.0f} GB/s).  CPU baseline: {line['cpu_baseline']['value']:.3f} frames/s on {line['cpu_baseline']['cores']} threads.
-* `{TAG}_bench_kernel_stats_streams3.csv` / `{TAG}_bench_line_streams3.json` -- `rocprofv3 --kernel-trace --stats --output-format csv --
-  python bench.py --no-cpu-baseline --no-h2d-pass` ({s3['value']:.0f} frames/s under the profiler); three batches in flight: durations include
+* `{TAG}_bench_kernel_stats_pipelined.csv` / `{TAG}_bench_line_pipelined.json` -- `rocprofv3 --kernel-trace --stats --output-format csv --
+  python bench.py --no-cpu-baseline --no-h2d-pass` ({s3['value']:.0f} frames/s under the profiler); several batches in flight: durations include
   contention.
 * `{TAG}_bench_kernel_stats_serial.csv` / `{TAG}_bench_line_serial.json` -- the same with `--streams 1` ({ser['value']:.0f} frames/s): durations without
   contention.  `solve_kernel` averages {avg('solve_kernel')/1e3:.2f} ms (rocprof) against {ser['kernels']['solve_kernel']['ms_per_step']:.2f} ms from the HIP events of the same run's JSON
@@ -118,9 +118,9 @@ micro-benchmarks, `tools/profile_round.sh {TAG}`) at the end of the round and tu
   points, 160x512, coarse+fine): **{tr['ms_per_step']:.1f} ms per step = {tr['value']:.0f} frames/s** (34.0 ms with every convolution on the generic kernels),
   and `rocprofv3 --kernel-trace --stats` of the same command.
 
-Top kernels of the bench command (3 streams, durations include overlap):
+Top kernels of the bench command (default streams, durations include overlap):
 
-{table(P + TAG + '_bench_kernel_stats_streams3.csv')}
+{table(P + TAG + '_bench_kernel_stats_pipelined.csv')}
 
 Same, one batch at a time (`--streams 1`):
 

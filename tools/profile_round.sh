@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
 #   tools/profile_round.sh r02
-# Writes gpurun_out/<tag>_*.csv (kernel-trace statistics of the bench command, 3 streams and serial; separate --pmc passes
+# Writes gpurun_out/<tag>_*.csv (kernel-trace statistics of the bench command, default streams ("pipelined") and serial; separate --pmc passes
 # for the solver and index_max -- counters are never combined with other trace domains).  Copy what should be judged into profiles/.
 set -u
 TAG=${1:-r02}
@@ -18,7 +18,7 @@ stats() {  # name, args...
   [ -n "$f" ] && cp $f $OUT/${TAG}_bench_kernel_stats_$name.csv
   grep '^{' $OUT/prof_$TAG/$name.log | tail -1 > $OUT/${TAG}_bench_line_$name.json
 }
-stats streams3 --no-h2d-pass
+stats pipelined --no-h2d-pass
 stats serial --streams 1 --no-h2d-pass
 pmc() {  # counter, tool
   local c=$1 tool=$2 name=$3
