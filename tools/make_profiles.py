@@ -84,7 +84,7 @@ micro-benchmarks, `tools/profile_round.sh {TAG}`) at the end of the round and tu
 `{TAG}_sweep_solver_cfg.txt` and `{TAG}_winograd_counters.txt` come from earlier calls of the round.
 
 * `{TAG}_gputest_tail.txt` -- `python -m pytest tests -q -m gpu`: {gt}.
-* `{TAG}_bench_line.json` -- the JSON line of `python bench.py` (12 steps, 3 warm-up, {line['config']['streams']} streams on {line['config']['hw_queues']} hardware queues, one hipGraph per stream, CPU baseline
+* `{TAG}_bench_line.json` -- the JSON line of `python bench.py` ({line['steps']} steps, {line['warmup']} warm-up, {line['config']['streams']} streams on {line['config']['hw_queues']} hardware queues, one hipGraph per stream, CPU baseline
   leg included): **{line['value']:.0f} frames/s** resident ({line['ms_per_step']:.2f} ms per 32-frame step), {line['value_with_h2d']:.0f} frames/s with the
   host->device copy of every batch inside the step (round 1: 2225).  Roofline object = time-dominant family = `solve_kernel`:
   {k['solve_kernel']['ms_per_step']:.2f} ms per step, {k['solve_kernel']['achieved']:.1f} TFLOP/s by SURVEY 8(d)'s unit = {k['solve_kernel']['frac']:.2f} of the 78.6 TFLOP/s fp64 vector peak.
