@@ -64,52 +64,66 @@ struct LoaderConcat {
 // otherwise four dword loads at per-source column offsets (dense n, gathered gidx[n], group n/group).
 template <bool DENSE>
 struct LoaderConcat4 {
-    const float* base[DI2P_MAX_SRC];
-    int rs[DI2P_MAX_SRC];
-    int off[DENSE ? 1 : DI2P_MAX_SRC][4];
-    int c0, c1, K;          // channel range ends of source 0 / 1 (== K when absent)
+    // Per-source state as NAMED SCALARS: with arrays (base[3], rs[3], off[3][4]) the source select of load4() -- s2 ? base[2] : ... --
+    // was canonicalised by hipcc into a load from a dynamically indexed private array, i.e. the whole loader lived in scratch
+    // (208-240 B per lane, 16 scratch loads per K-step) although nothing was ever spilled.
+    // Source 0's values plus the INCREMENTS to source 1 and from source 1 to source 2: load4() picks the source of a row as
+    // v0 + (s1 ? d1 : 0) + (s2 ? d2 : 0).  A select whose arms are two loaded members (s2 ? b2 : b1) is rewritten by hipcc into a
+    // load from a select of the members' addresses -- a dynamic index that keeps the loader object in private memory.
+    const float* b0;
+    long long db1, db2;          // byte increments of the base pointer
+    int r0, dr1, dr2;            // row strides
+    int o0[4], do1[4], do2[4];   // !DENSE: column offsets of the lane's 4 columns (static indices only)
+    int c0, c1, K;               // channel range ends of source 0 / 1 (== K when absent)
     SrcDev s;
     int b, N;
-    __device__ __forceinline__ void column4(int n) {
-        const int nc = min(n, N - 4);
+    __device__ __forceinline__ void one_source(int i, int nc, const float*& base, int& rs, int* q) const {
+        // i is a compile-time constant at every call site.  Absent sources were filled in on the host as aliases of source 0 with an
+        // empty channel range (alias_absent_sources), so they are valid to address and never selected.
+        base = s.ptr[i] + (long long)b * s.batch_stride[i] + (DENSE ? nc : 0);
+        rs = s.row_stride[i];
+        if (!DENSE) {
+            const int mode = s.mode[i];
+            const int* gi = s.gidx[i];
+            const int grp = s.group[i];
 #pragma unroll
-        for (int i = 0; i < DI2P_MAX_SRC; ++i) {
-            // static indices + selects (a runtime index into the kernel-argument arrays would push them to scratch);
-            // absent sources alias source 0 and are never selected
-            const bool on = i < s.n_src;
-            const float* pp = on ? s.ptr[i] : s.ptr[0];
-            const long long bs = on ? s.batch_stride[i] : s.batch_stride[0];
-            base[i] = pp + (long long)b * bs + (DENSE ? nc : 0);
-            rs[i] = on ? s.row_stride[i] : s.row_stride[0];
-            if (!DENSE) {
-                const int mode = on ? s.mode[i] : s.mode[0];
-                const int* gi = on ? s.gidx[i] : s.gidx[0];
-                const int grp = on ? s.group[i] : s.group[0];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int o = nc + q;
-                    if (mode == DI2P_SRC_GATHER) o = gi[(long long)b * N + nc + q];
-                    else if (mode == DI2P_SRC_GROUP) o = (nc + q) / grp;
-                    off[DENSE ? 0 : i][q] = o;
-                }
+            for (int c = 0; c < 4; ++c) {
+                int o = nc + c;
+                if (mode == DI2P_SRC_GATHER) o = gi[(long long)b * N + nc + c];
+                else if (mode == DI2P_SRC_GROUP) o = (nc + c) / grp;
+                q[c] = o;
             }
         }
+    }
+    __device__ __forceinline__ void column4(int n) {
+        const int nc = min(n, N - 4);
+        const float *p0, *p1, *p2;
+        int s0, s1, s2, q0[4] = {0, 0, 0, 0}, q1[4] = {0, 0, 0, 0}, q2[4] = {0, 0, 0, 0};
+        one_source(0, nc, p0, s0, q0);
+        one_source(1, nc, p1, s1, q1);
+        one_source(2, nc, p2, s2, q2);
+        b0 = p0;
+        db1 = (long long)(reinterpret_cast<uintptr_t>(p1) - reinterpret_cast<uintptr_t>(p0));
+        db2 = (long long)(reinterpret_cast<uintptr_t>(p2) - reinterpret_cast<uintptr_t>(p1));
+        r0 = s0; dr1 = s1 - s0; dr2 = s2 - s1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { o0[c] = q0[c]; do1[c] = q1[c] - q0[c]; do2[c] = q2[c] - q1[c]; }
         c0 = s.c_end[0];
-        c1 = s.n_src > 1 ? s.c_end[1] : K;
+        c1 = s.c_end[1];        // == K when source 1 is absent (prefix ends, filled on the host)
     }
     __device__ __forceinline__ void begin_tile(int) {}
     __device__ __forceinline__ float4 load4(int k) const {
         const int kc = min(k, K - 1);
-        const bool s1 = kc >= c0, s2 = kc >= c1;
-        const float* p = s2 ? base[2] : (s1 ? base[1] : base[0]);
-        const int kk = kc - (s2 ? c1 : (s1 ? c0 : 0));
-        const int r = s2 ? rs[2] : (s1 ? rs[1] : rs[0]);
-        p += kk * r;                                                  // kk*r < 2^31 (host-checked)
+        const bool s1 = kc >= c0, s2 = kc >= c1;          // s2 implies s1 (c1 >= c0)
+        const int kk = kc - (s1 ? c0 : 0) - (s2 ? c1 - c0 : 0);
+        const int r = r0 + (s1 ? dr1 : 0) + (s2 ? dr2 : 0);
+        const long long byte_off = (s1 ? db1 : 0ll) + (s2 ? db2 : 0ll) + (long long)(kk * r) * 4;      // kk*r < 2^31 (host-checked)
+        const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(b0) + byte_off);
         if (DENSE) return *reinterpret_cast<const float4*>(p);
-        constexpr int L = DENSE ? 0 : 1, H = DENSE ? 0 : 2;
-        const int o0 = s2 ? off[H][0] : (s1 ? off[L][0] : off[0][0]), o1 = s2 ? off[H][1] : (s1 ? off[L][1] : off[0][1]);
-        const int o2 = s2 ? off[H][2] : (s1 ? off[L][2] : off[0][2]), o3 = s2 ? off[H][3] : (s1 ? off[L][3] : off[0][3]);
-        return make_float4(p[o0], p[o1], p[o2], p[o3]);
+        int q[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[c] = o0[c] + (s1 ? do1[c] : 0) + (s2 ? do2[c] : 0);
+        return make_float4(p[q[0]], p[q[1]], p[q[2]], p[q[3]]);
     }
     __device__ __forceinline__ void fix(float4&, int) const {}
     struct Info {};
@@ -130,6 +144,7 @@ struct EpiDev {
     int group_max;
     int transpose_out;
     float* gmax_out;          // with group_max > 1: Y is stored in full AND the group maxima go here ([B,M,N/group_max])
+    float* gmax_dst;          // where the group maxima go: gmax_out, or Y itself when only the maxima are stored (resolved on the host)
 };
 
 // The accumulator tile of a lane is 16 rows of ONE column: rows mrow0 + 8g + {0..3}, g = 0..3.  All per-row operands
@@ -202,7 +217,7 @@ struct EpiPointwise {
                     const float ot = __shfl_xor(mx, o);
                     mx = (mx != mx || ot != ot) ? __builtin_nanf("") : fmaxf(mx, ot);
                 }
-                if (ok && (n % e.group_max) == 0) (e.gmax_out ? e.gmax_out : Y)[((long long)b * M + m) * (N / e.group_max) + n / e.group_max] = mx;
+                if (ok && (n % e.group_max) == 0) e.gmax_dst[((long long)b * M + m) * (N / e.group_max) + n / e.group_max] = mx;
             }
         } else if (e.transpose_out) {        // Y[b][n][m]: one float4 per row group (M % 4 == 0)
 #pragma unroll
@@ -408,6 +423,14 @@ void launch_pw_vec(bool dense, const SrcDev& s, const float* Wt, float* Y, int B
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Sources i >= n_src become aliases of source 0 with an empty channel range [K, K): addressable, never selected.
+inline void alias_absent_sources(SrcDev& s, int n_src) {
+    for (int i = n_src; i < DI2P_MAX_SRC; ++i) {
+        s.ptr[i] = s.ptr[0]; s.gidx[i] = s.gidx[0]; s.batch_stride[i] = s.batch_stride[0]; s.row_stride[i] = s.row_stride[0];
+        s.mode[i] = s.mode[0]; s.group[i] = s.group[0];
+    }
+}
+
 }  // namespace
 
 using Cfg128x128 = TileCfg<2, 2, 2, 2>;
@@ -436,6 +459,7 @@ extern "C" int di2p_pointwise_gemm(const di2p_src_t* srcs, int n_src, const floa
         s.c_end[i] = ctot;
     }
     s.n_src = n_src;
+    alias_absent_sources(s, n_src);
     DI2P_CHECK_ARG(ctot == K, "source channels do not sum to K");
     EpiDev e{};
     e.group_max = 1;
@@ -445,6 +469,7 @@ extern "C" int di2p_pointwise_gemm(const di2p_src_t* srcs, int n_src, const floa
         for (int t = 0; t < 2; ++t) { e.g_table[t] = epi->g_table[t]; e.g_idx[t] = epi->g_idx[t]; e.g_w[t] = epi->g_w[t]; e.g_nodes[t] = epi->g_nodes[t]; }
         e.transpose_out = epi->transpose_out;
         e.gmax_out = epi->group_max > 1 ? epi->group_max_out : nullptr;
+        e.gmax_dst = e.gmax_out ? e.gmax_out : Y;
         for (int t = 0; t < 2; ++t) {
             e.g_k[t] = e.g_table[t] ? epi->g_k[t] : 0;
             DI2P_CHECK_ARG(e.g_k[t] >= 0 && e.g_k[t] <= DI2P_MAX_GK, "g_k must be in [0, DI2P_MAX_GK]");
@@ -504,6 +529,7 @@ extern "C" int di2p_point_head(const di2p_src_t* srcs, int n_src, const float* W
         s.c_end[i] = ctot;
     }
     s.n_src = n_src;
+    alias_absent_sources(s, n_src);
     DI2P_CHECK_ARG(ctot == K0, "source channels do not sum to K0");
     DI2P_CHECK_ARG(aligned16(W0t) && aligned16(W1t), "weights must be 16-byte aligned");
     EpiDev e{};

@@ -23,6 +23,14 @@
 #include <math.h>
 #include <stdlib.h>
 
+// default instantiation of the 2-D solver: <min waves per SIMD> x <waves per hypothesis> (override for experiments: -D...)
+#ifndef DI2P_SOLVER_DEFAULT_MINW
+#define DI2P_SOLVER_DEFAULT_MINW 3
+#endif
+#ifndef DI2P_SOLVER_DEFAULT_WPH
+#define DI2P_SOLVER_DEFAULT_WPH 4
+#endif
+
 namespace {
 
 enum { T_MAX_ITER = 0, T_GRADIENT = 1, T_PARAMETER = 2, T_FUNCTION = 3, T_RADIUS = 4, T_INVALID = 5, T_EVAL_FAIL = 6 };
@@ -277,13 +285,20 @@ __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ po
 //   reduction: xor-butterfly inside each wave, then the 4 wave partials are combined through LDS in a FIXED
 //     order by every thread, so all 256 threads hold bit-identical sums and the LM control flow that
 //     follows is workgroup-uniform.
-constexpr int QCAP = 512;        // per-wave queue capacity (ids); phase B drains it when fewer than 4 clusters' worth of room is left
+constexpr int QCAP = 384;        // per-wave queue capacity (ids); phase B drains it when fewer than 4 clusters' worth of room is left
 
+constexpr int BOXTEST_WORDS = 16;   // sizeof(BoxAbs) / 4 (the table is fetched as 16-byte LDS reads)
 template <int NP, int WPH>   // WPH = waves per hypothesis (workgroup = WPH*64 threads)
 struct SweepShared {
     double red[WPH][Tri<NP>::N + NP + 2];
     double comb[Tri<NP>::N + NP + 2];      // the WPH partials combined in a fixed order (lane i of wave 0 sums value i)
     int queue[WPH][QCAP];
+    // Per-lane running sums {cost mantissa, g[NP], A[tri]} and the cost exponent.  They are only touched by phase B, so they live
+    // HERE between drains (one conflict-free 8-byte LDS access per value and lane at the start and at the end of a drain) instead of
+    // occupying 2 * (1 + NP + tri) + 1 VGPRs through the cluster walk -- with them in registers the kernel spilled at 3 waves per SIMD.
+    double acc[WPH][1 + NP + Tri<NP>::N][64];
+    int acc_e[WPH][64];
+    alignas(16) float btest[WPH][BOXTEST_WORDS];   // the wave's box-test table of the current sweep (wave-uniform, re-read per cluster round)
 };
 
 // v_rcp_f64 + two Newton steps: <= 1 ulp for finite non-zero inputs; 0 / inf / NaN give inf / 0 / NaN-like values that the
@@ -430,63 +445,10 @@ struct Planes { double nL, nR, nT, nB; };
 //   label 0: active   iff all five are positive, else every point is inactive (and cannot raise `bad`).
 // NaN/inf anywhere fails every comparison and falls back to the per-point path.
 // Returns 0: skip, 1: classify per point, 2: all active, 3 (label 0 only): no point is active, guard against exact zeros only.
-struct BoxTest {           // per sweep: |n_i^T R|_j * (1 + 1e-5) and the margin factors (wave-uniform)
-    float R[9], t[3], T1;
-    float aL[3], aR[3], aT[3], aB[3], aZ[3];
-    float fx, cx, wcx, fy, cy, hcy, mL, mR, mT, mB, mZ;
+struct Pre32;
+struct alignas(16) BoxAbs {        // per sweep: |n_i^T R|_j * (1 + 1e-5) of the five planes and |t|_1 (wave-uniform; 16 words, kept in LDS)
+    float aL[3], aR[3], aT[3], aB[3], aZ[3], T1;
 };
-template <int NP>
-__device__ __forceinline__ void make_box_test(const Rot<NP>& rot, double tx, double ty, double tz, const Cam& k, BoxTest& q) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) q.R[i] = (float)rot.R[i];
-    q.t[0] = (float)tx; q.t[1] = (float)ty; q.t[2] = (float)tz;
-    q.T1 = fabsf(q.t[0]) + fabsf(q.t[1]) + fabsf(q.t[2]);
-    q.fx = (float)k.fx; q.cx = (float)k.cx; q.wcx = (float)(k.W1 - k.cx);
-    q.fy = (float)k.fy; q.cy = (float)k.cy; q.hcy = (float)(k.H1 - k.cy);
-    const float g = 1.0f + 1e-5f;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {      // (n^T R)_j = a R0j + b R1j + c R2j
-        q.aL[j] = fabsf(q.fx * q.R[j] + q.cx * q.R[6 + j]) * g;
-        q.aR[j] = fabsf(-q.fx * q.R[j] + q.wcx * q.R[6 + j]) * g;
-        q.aT[j] = fabsf(q.fy * q.R[3 + j] + q.cy * q.R[6 + j]) * g;
-        q.aB[j] = fabsf(-q.fy * q.R[3 + j] + q.hcy * q.R[6 + j]) * g;
-        q.aZ[j] = fabsf(q.R[6 + j]) * g;
-    }
-    const float rel = 4e-6f;
-    q.mL = rel * (fabsf(q.fx) + fabsf(q.cx)); q.mR = rel * (fabsf(q.fx) + fabsf(q.wcx));
-    q.mT = rel * (fabsf(q.fy) + fabsf(q.cy)); q.mB = rel * (fabsf(q.fy) + fabsf(q.hcy));
-    q.mZ = rel;
-}
-template <int NP, int LAB>
-__device__ __forceinline__ int cluster_status(const Box& bx, const BoxTest& q) {
-    const float S = ((fabsf(bx.cx) + fabsf(bx.cy)) + (fabsf(bx.cz) + q.T1)) + ((bx.hx + bx.hy) + bx.hz);
-    float p0, p1, p2;
-    if (NP == 4) {
-        p0 = fmaf(q.R[0], bx.cx, fmaf(q.R[2], bx.cz, q.t[0])); p1 = bx.cy + q.t[1]; p2 = fmaf(q.R[6], bx.cx, fmaf(q.R[8], bx.cz, q.t[2]));
-    } else {
-        p0 = fmaf(q.R[0], bx.cx, fmaf(q.R[1], bx.cy, fmaf(q.R[2], bx.cz, q.t[0])));
-        p1 = fmaf(q.R[3], bx.cx, fmaf(q.R[4], bx.cy, fmaf(q.R[5], bx.cz, q.t[1])));
-        p2 = fmaf(q.R[6], bx.cx, fmaf(q.R[7], bx.cy, fmaf(q.R[8], bx.cz, q.t[2])));
-    }
-    const float fL = fmaf(q.fx, p0, q.cx * p2), fR = fmaf(-q.fx, p0, q.wcx * p2);
-    const float fT = fmaf(q.fy, p1, q.cy * p2), fB = fmaf(-q.fy, p1, q.hcy * p2);
-    auto bound = [&](const float* a, float m) { return fmaf(a[0], bx.hx, fmaf(a[1], bx.hy, fmaf(a[2], bx.hz, m * S))); };
-    const float tL = bound(q.aL, q.mL), tR = bound(q.aR, q.mR), tT = bound(q.aT, q.mT), tB = bound(q.aB, q.mB), tZ = bound(q.aZ, q.mZ);
-    // all five decided positive <=> min_i (f_i - t_i) > 0 ; all five decided <=> min_i (|f_i| - t_i) > 0
-    const float lo = fminf(fminf(fminf(fL - tL, fR - tR), fminf(fT - tT, fB - tB)), p2 - tZ);
-    const float cm = fminf(fminf(fminf(fabsf(fL) - tL, fabsf(fR) - tR), fminf(fabsf(fT) - tT, fabsf(fB) - tB)), fabsf(p2) - tZ);
-    const bool inside = lo > 0.0f;
-    if (cm > 0.0f) return (LAB == 1) ? (inside ? 0 : 2) : (inside ? 2 : 0);
-    // a decided-negative plane already decides every point: not inside.  Label 1: all active.  Label-0 points of such a
-    // cluster may still sit exactly on one of the undecided planes (dx, dy or p2 == 0 is an evaluation failure in the
-    // reference): status 3 = no point can be active, but every point is still checked against exact zeros (fp32 guard,
-    // exact test when the guard cannot certify) -- without the ballot / queue work of a real classification.
-    const float hi = fminf(fminf(fminf(fL + tL, fR + tR), fminf(fT + tT, fB + tB)), p2 + tZ);
-    if (hi < 0.0f) return LAB == 1 ? 2 : 3;      // label 0: nothing is active, but an exact zero on an undecided plane must still be found
-    return 1;
-}
-
-
 // fp32 PRE-FILTER of the per-point classification (phase A).  The exact test costs ~55 fp64 instructions per 64 points
 // (rotation, reciprocal, projection, pixel-form comparisons); most points it is run on are nowhere near a frustum plane.
 // Here the five plane functions f_i(p) = n_i . (R x + t) are evaluated in fp32 and compared with a margin
@@ -559,6 +521,48 @@ __device__ __forceinline__ bool zero_guard32(const Pre32& q, float X, float Y, f
     return unc;
 }
 
+// The box-test table of an iterate, from the pre-filter's table (same fp32 R, t, intrinsics and margin factors).
+__device__ __forceinline__ void make_box_abs(const Pre32& p, BoxAbs& q) {
+    const float g = 1.0f + 1e-5f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {      // (n^T R)_j = a R0j + b R1j + c R2j
+        q.aL[j] = fabsf(p.fx * p.R[j] + p.cx * p.R[6 + j]) * g;
+        q.aR[j] = fabsf(-p.fx * p.R[j] + p.wcx * p.R[6 + j]) * g;
+        q.aT[j] = fabsf(p.fy * p.R[3 + j] + p.cy * p.R[6 + j]) * g;
+        q.aB[j] = fabsf(-p.fy * p.R[3 + j] + p.hcy * p.R[6 + j]) * g;
+        q.aZ[j] = fabsf(p.R[6 + j]) * g;
+    }
+    q.T1 = fabsf(p.t[0]) + fabsf(p.t[1]) + fabsf(p.t[2]);
+}
+template <int NP, int LAB>
+__device__ __forceinline__ int cluster_status(const Box& bx, const Pre32& q, const BoxAbs& ab) {
+    const float S = ((fabsf(bx.cx) + fabsf(bx.cy)) + (fabsf(bx.cz) + ab.T1)) + ((bx.hx + bx.hy) + bx.hz);
+    float p0, p1, p2;
+    if (NP == 4) {
+        p0 = fmaf(q.R[0], bx.cx, fmaf(q.R[2], bx.cz, q.t[0])); p1 = bx.cy + q.t[1]; p2 = fmaf(q.R[6], bx.cx, fmaf(q.R[8], bx.cz, q.t[2]));
+    } else {
+        p0 = fmaf(q.R[0], bx.cx, fmaf(q.R[1], bx.cy, fmaf(q.R[2], bx.cz, q.t[0])));
+        p1 = fmaf(q.R[3], bx.cx, fmaf(q.R[4], bx.cy, fmaf(q.R[5], bx.cz, q.t[1])));
+        p2 = fmaf(q.R[6], bx.cx, fmaf(q.R[7], bx.cy, fmaf(q.R[8], bx.cz, q.t[2])));
+    }
+    const float fL = fmaf(q.fx, p0, q.cx * p2), fR = fmaf(-q.fx, p0, q.wcx * p2);
+    const float fT = fmaf(q.fy, p1, q.cy * p2), fB = fmaf(-q.fy, p1, q.hcy * p2);
+    auto bound = [&](const float* a, float m) { return fmaf(a[0], bx.hx, fmaf(a[1], bx.hy, fmaf(a[2], bx.hz, m * S))); };
+    const float tL = bound(ab.aL, q.mL), tR = bound(ab.aR, q.mR), tT = bound(ab.aT, q.mT), tB = bound(ab.aB, q.mB), tZ = bound(ab.aZ, q.mZ);
+    // all five decided positive <=> min_i (f_i - t_i) > 0 ; all five decided <=> min_i (|f_i| - t_i) > 0
+    const float lo = fminf(fminf(fminf(fL - tL, fR - tR), fminf(fT - tT, fB - tB)), p2 - tZ);
+    const float cm = fminf(fminf(fminf(fabsf(fL) - tL, fabsf(fR) - tR), fminf(fabsf(fT) - tT, fabsf(fB) - tB)), fabsf(p2) - tZ);
+    const bool inside = lo > 0.0f;
+    if (cm > 0.0f) return (LAB == 1) ? (inside ? 0 : 2) : (inside ? 2 : 0);
+    // a decided-negative plane already decides every point: not inside.  Label 1: all active.  Label-0 points of such a
+    // cluster may still sit exactly on one of the undecided planes (dx, dy or p2 == 0 is an evaluation failure in the
+    // reference): status 3 = no point can be active, but every point is still checked against exact zeros (fp32 guard,
+    // exact test when the guard cannot certify) -- without the ballot / queue work of a real classification.
+    const float hi = fminf(fminf(fminf(fL + tL, fR + tR), fminf(fT + tT, fB + tB)), p2 + tZ);
+    if (hi < 0.0f) return LAB == 1 ? 2 : 3;      // label 0: nothing is active, but an exact zero on an undecided plane must still be found
+    return 1;
+}
+
 // One label-uniform block of records [recs, recs+cnt) = nc clusters of CL records.  Cluster c belongs to wave
 // c % WPH (neighbouring clusters -- which tend to share their status -- spread over the waves).  Per round a lane
 // tests one cluster; the wave then walks the flagged ones:
@@ -567,10 +571,10 @@ __device__ __forceinline__ bool zero_guard32(const Pre32& q, float X, float Y, f
 // Active ids go to the per-wave LDS queue and are evaluated densely (phase B) 64 at a time.  The queue sequence is the
 // same as if every cluster had been classified per point, so the sums are bit-identical to the unculled sweep
 // (nocull != 0 forces status 1 everywhere: tests compare the two).
-template <int NP, typename PT, int WPH, int LAB, int MODE>
+template <int NP, typename PT, int WPH, int LAB, int MODE, bool PROFILE>
 __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs, int cnt, const Box* __restrict__ boxes, int nc,
-                                               const Cam& k, const Planes& pl, const double* x, const Rot<NP>& rot, int nocull,
-                                               int* queue, LogProd& cost, double* lg, double* lA, bool& bad, int* n_active) {
+                                               const Cam& k, const double* x, const Rot<NP>& rot, int nocull,
+                                               int* queue, double (*acc)[64], int* acc_e, const Pre32& pre, const float* btest_lds, bool& bad, int* n_active) {
     constexpr int TOFF = NP == 4 ? 1 : 3;
     const double tx = x[TOFF], ty = x[TOFF + 1], tz = x[TOFF + 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -587,14 +591,29 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
     auto drain = [&](bool flush) {
         const int total = flush ? qn : (qn & ~63);
         __builtin_amdgcn_wave_barrier();          // LDS ops of one wave retire in order; only the compiler must not reorder them
-        int n_cur = queue[lane];
-        Rec<PT> r_cur = recs[min(max(n_cur, 0), cnt - 1)];
-        for (int pos = 0; pos < total; pos += 64) {
-            const int n_nxt = queue[min(pos + 64 + lane, QCAP - 1)];
-            const Rec<PT> r_nxt = recs[min(max(n_nxt, 0), cnt - 1)];          // unconditional, clamped (the last one is wasted)
-            if (pos + lane < total) eval_active<NP, PT, LAB, MODE>(r_cur, rot, x, k, cost, lg, lA, bad);
-            n_active[0] += min(64, total - pos);
-            n_cur = n_nxt; r_cur = r_nxt;
+        if (total > 0) {                          // wave-uniform
+            int n_cur = queue[lane];
+            Rec<PT> r_cur = recs[min(max(n_cur, 0), cnt - 1)];
+            // the lane's running sums come out of LDS for the duration of the drain
+            LogProd cost;
+            double lg[NP], lA[Tri<NP>::N];
+            cost.m = acc[0][lane]; cost.e = acc_e[lane];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) lg[i] = acc[1 + i][lane];
+#pragma unroll
+            for (int i = 0; i < Tri<NP>::N; ++i) lA[i] = acc[1 + NP + i][lane];
+            for (int pos = 0; pos < total; pos += 64) {
+                const int n_nxt = queue[min(pos + 64 + lane, QCAP - 1)];
+                const Rec<PT> r_nxt = recs[min(max(n_nxt, 0), cnt - 1)];          // unconditional, clamped (the last one is wasted)
+                if (pos + lane < total) eval_active<NP, PT, LAB, MODE>(r_cur, rot, x, k, cost, lg, lA, bad);
+                if (PROFILE) n_active[0] += min(64, total - pos);
+                n_cur = n_nxt; r_cur = r_nxt;
+            }
+            acc[0][lane] = cost.m; acc_e[lane] = cost.e;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) acc[1 + i][lane] = lg[i];
+#pragma unroll
+            for (int i = 0; i < Tri<NP>::N; ++i) acc[1 + NP + i][lane] = lA[i];
         }
         const int rem = qn - total;               // < 64 ids stay queued (0 after a flush)
         const int carry = queue[min(total + lane, QCAP - 1)];
@@ -618,10 +637,6 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
     };
     const bool use_pre = (nocull & 2) == 0;
     nocull &= 1;
-    Pre32 pre;
-    make_pre32<NP>(rot, tx, ty, tz, k, pre);
-    BoxTest btest;
-    make_box_test<NP>(rot, tx, ty, tz, k, btest);
     // phase A of one flagged cluster: classify its 64 records (status 1) or take them all (status 2), append the active ids
     auto classify = [&](int c, bool isA, bool guard_only, const Rec<PT>& rec) {
         const bool valid = c * CL + lane < cnt;                                     // padding lanes of a partial cluster
@@ -648,9 +663,23 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
     for (int j0 = 0; j0 < mine; j0 += 64) {
         const int j = j0 + lane;
         int status = 0;
-        if (j < mine) status = nocull ? 1 : cluster_status<NP, LAB>(boxes[j * WPH + wave], btest);
+        if (j < mine) {
+            if (nocull) {
+                status = 1;
+            } else {
+                // the table is wave-uniform and only needed here (<= 2 rounds per label block): fetched from LDS per round instead of
+                // staying in ~40 VGPRs through the cluster walk
+                BoxAbs ab;
+                asm volatile("" ::: "memory");
+                const float4* bt4 = reinterpret_cast<const float4*>(btest_lds);
+                float4* dst4 = reinterpret_cast<float4*>(&ab);
+#pragma unroll
+                for (int i = 0; i < (int)(sizeof(BoxAbs) / 16); ++i) dst4[i] = bt4[i];
+                status = cluster_status<NP, LAB>(boxes[j * WPH + wave], pre, ab);
+            }
+        }
         const unsigned long long mA = __ballot(status == 1), mB = __ballot(status == 2), mC = __ballot(status == 3);
-        n_active[1] += __popcll(mA); n_active[2] += __popcll(mB); n_active[3] += __popcll(mC);
+        if (PROFILE) { n_active[1] += __popcll(mA); n_active[2] += __popcll(mB); n_active[3] += __popcll(mC); }
         // The flagged clusters are walked in index order with PF records in flight (a cluster's 64 records are one 16-byte load
         // per lane; the L2 latency is several times the ~40 instructions a cluster costs).  Slot i of the ring holds the
         // (bit index, record) of a cluster; exhausted slots carry bit = -1 (and a harmless clamped load).
@@ -685,24 +714,49 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
 // Leaves the WPH wave partials {cost, g[NP], A[tri], bad} in sh.red[wave][*]; the caller combines them after a
 // barrier.  Records are sorted by label (prepare_kernel): the label-1 block and the label-0 block are swept by two
 // specialised loops.
-template <int NP, typename PT, int WPH, int MODE>
+template <int NP, typename PT, int WPH, int MODE, bool PROFILE>
 __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Box* __restrict__ boxes, int cnt1, int cnt0, int nc1,
-                                     int nc0, const Cam& k, const Planes& pl, const double* x, int nocull, SweepShared<NP, WPH>& sh, int* n_active) {
+                                     int nc0, const Cam& k, const double* x, int nocull, SweepShared<NP, WPH>& sh, int* n_active) {
     constexpr int NV = Tri<NP>::N + NP + 2;
+    constexpr int TOFF = NP == 4 ? 1 : 3;
+    static_assert(sizeof(BoxAbs) == BOXTEST_WORDS * 4, "box-test table is copied as float4s");
     Rot<NP> rot;
     make_rot<NP>(x, rot);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int* queue = sh.queue[wave];
+    double (*acc)[64] = sh.acc[wave];
+    int* acc_e = sh.acc_e[wave];
+    {   // the lane's running sums start at zero (cost product: 0.5 * 2^1)
+        LogProd c0;
+        c0.init();
+        acc[0][lane] = c0.m; acc_e[lane] = c0.e;
+#pragma unroll
+        for (int i = 1; i < 1 + NP + Tri<NP>::N; ++i) acc[i][lane] = 0.0;
+    }
+    Pre32 pre;        // fp32 table of the iterate (SGPRs), shared by the cluster test and the per-point pre-filter of both label blocks
+    make_pre32<NP>(rot, x[TOFF], x[TOFF + 1], x[TOFF + 2], k, pre);
+    if (!(nocull & 1)) {   // box-test table of this iterate: every lane computes the same values, lane 0 stores them
+        BoxAbs ab;
+        make_box_abs(pre, ab);
+        if (lane == 0) {
+            const float4* w = reinterpret_cast<const float4*>(&ab);
+            float4* d = reinterpret_cast<float4*>(sh.btest[wave]);
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(BoxAbs) / 16); ++i) d[i] = w[i];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    bool bad = false;
+    sweep_clusters<NP, PT, WPH, 1, MODE, PROFILE>(recs, cnt1, boxes, nc1, k, x, rot, nocull, queue, acc, acc_e, pre, sh.btest[wave], bad, n_active);
+    sweep_clusters<NP, PT, WPH, 0, MODE, PROFILE>(recs + cnt1, cnt0, boxes + nc1, nc0, k, x, rot, nocull, queue, acc, acc_e, pre, sh.btest[wave], bad, n_active);
+    __builtin_amdgcn_wave_barrier();
     LogProd cost;
-    cost.init();
+    cost.m = acc[0][lane]; cost.e = acc_e[lane];
     double lg[NP], lA[Tri<NP>::N];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) lg[i] = 0.0;
+    for (int i = 0; i < NP; ++i) lg[i] = acc[1 + i][lane];
 #pragma unroll
-    for (int i = 0; i < Tri<NP>::N; ++i) lA[i] = 0.0;
-    bool bad = false;
-    sweep_clusters<NP, PT, WPH, 1, MODE>(recs, cnt1, boxes, nc1, k, pl, x, rot, nocull, queue, cost, lg, lA, bad, n_active);
-    sweep_clusters<NP, PT, WPH, 0, MODE>(recs + cnt1, cnt0, boxes + nc1, nc0, k, pl, x, rot, nocull, queue, cost, lg, lA, bad, n_active);
+    for (int i = 0; i < Tri<NP>::N; ++i) lA[i] = acc[1 + NP + i][lane];
 
     // a non-finite Jacobian entry (evaluation failure in the reference) makes a sum non-finite: tested once per sweep
     if (MODE >= 1) {
@@ -763,38 +817,40 @@ __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Bo
     if (lane == 0) mine[NV - 1] = anybad ? 1.0 : 0.0;
 }
 
+// Cholesky solve of M y = rhs IN PLACE: M (lower triangle, row-major) is overwritten by its factor L, y holds rhs on entry and the
+// solution on return (forward substitution, then backward substitution, both in place).  Same operations in the same order as the
+// oracle's chol_solve; written in place because the LM update runs on one lane of a kernel whose register budget is set by the sweep --
+// separate M / L / z arrays pushed it into scratch.
 template <int NP>
-__device__ __forceinline__ bool chol_solve(const double* Mtri, const double* rhs, double* y) {
-    double L[Tri<NP>::N];
+__device__ __forceinline__ bool chol_solve_inplace(double* M, double* y) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
 #pragma unroll
         for (int j = 0; j <= i; ++j) {
-            double s = Mtri[i * (i + 1) / 2 + j];
+            double s = M[i * (i + 1) / 2 + j];
 #pragma unroll
-            for (int q = 0; q < j; ++q) s -= L[i * (i + 1) / 2 + q] * L[j * (j + 1) / 2 + q];
+            for (int q = 0; q < j; ++q) s -= M[i * (i + 1) / 2 + q] * M[j * (j + 1) / 2 + q];
             if (i == j) {
                 if (!(s > 0.0) || !isfinite(s)) return false;
-                L[i * (i + 1) / 2 + i] = sqrt(s);
+                M[i * (i + 1) / 2 + i] = sqrt(s);
             } else {
-                L[i * (i + 1) / 2 + j] = s / L[j * (j + 1) / 2 + j];
+                M[i * (i + 1) / 2 + j] = s / M[j * (j + 1) / 2 + j];
             }
         }
     }
-    double z[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        double s = rhs[i];
+        double s = y[i];
 #pragma unroll
-        for (int q = 0; q < i; ++q) s -= L[i * (i + 1) / 2 + q] * z[q];
-        z[i] = s / L[i * (i + 1) / 2 + i];
+        for (int q = 0; q < i; ++q) s -= M[i * (i + 1) / 2 + q] * y[q];
+        y[i] = s / M[i * (i + 1) / 2 + i];
     }
 #pragma unroll
     for (int i = NP - 1; i >= 0; --i) {
-        double s = z[i];
+        double s = y[i];
 #pragma unroll
-        for (int q = i + 1; q < NP; ++q) s -= L[q * (q + 1) / 2 + i] * y[q];
-        y[i] = s / L[i * (i + 1) / 2 + i];
+        for (int q = i + 1; q < NP; ++q) s -= M[q * (q + 1) / 2 + i] * y[q];
+        y[i] = s / M[i * (i + 1) / 2 + i];
     }
     bool ok = true;
 #pragma unroll
@@ -1045,29 +1101,28 @@ __device__ __forceinline__ void lm_begin_iteration(LMState<NP>& st) {
     for (;;) {
         if (st.iter >= st.max_iter || st.gmax <= kGradTol || st.radius <= kMinRadius) { st.done = 1; return; }
         ++st.iter;
-        double As[NT], gs[NP], M[NT], rhs[NP], ds[NP];
+        // scaled system (S A S + D^2) ds = -S g.  The scaled matrix S A S is needed twice (the system, the model change) and is
+        // RECOMPUTED from the LDS-resident A and S the second time (same expression, same bits) instead of being kept in registers.
+        double M[NT], ds[NP];
+        auto scaled_A = [&](int a, int b) { const int hi = a >= b ? a : b, lo = a >= b ? b : a; return st.S[hi] * st.A[hi * (hi + 1) / 2 + lo] * st.S[lo]; };
 #pragma unroll
-        for (int a = 0; a < NP; ++a) {
-            gs[a] = st.S[a] * st.g[a];
+        for (int a = 0; a < NP; ++a)
 #pragma unroll
-            for (int b = 0; b <= a; ++b) As[a * (a + 1) / 2 + b] = st.S[a] * st.A[a * (a + 1) / 2 + b] * st.S[b];
-        }
+            for (int b = 0; b <= a; ++b) M[a * (a + 1) / 2 + b] = scaled_A(a, b);
         if (!st.reuse_diag)
 #pragma unroll
-            for (int a = 0; a < NP; ++a) st.diag[a] = fmin(fmax(As[a * (a + 1) / 2 + a], kMinDiag), kMaxDiag);
+            for (int a = 0; a < NP; ++a) st.diag[a] = fmin(fmax(M[a * (a + 1) / 2 + a], kMinDiag), kMaxDiag);
 #pragma unroll
-        for (int i = 0; i < NT; ++i) M[i] = As[i];
-#pragma unroll
-        for (int a = 0; a < NP; ++a) { M[a * (a + 1) / 2 + a] += st.diag[a] / st.radius; rhs[a] = -gs[a]; }
-        bool valid = chol_solve<NP>(M, rhs, ds);
+        for (int a = 0; a < NP; ++a) { M[a * (a + 1) / 2 + a] += st.diag[a] / st.radius; ds[a] = -(st.S[a] * st.g[a]); }
+        bool valid = chol_solve_inplace<NP>(M, ds);
         double model_change = 0.0;
         if (valid) {
             double q = 0.0, l = 0.0;
 #pragma unroll
             for (int a = 0; a < NP; ++a) {
-                l += ds[a] * gs[a];
+                l += ds[a] * (st.S[a] * st.g[a]);
 #pragma unroll
-                for (int b = 0; b < NP; ++b) q += ds[a] * As[tri<NP>(a, b)] * ds[b];
+                for (int b = 0; b < NP; ++b) q += ds[a] * scaled_A(a, b) * ds[b];
             }
             model_change = -(l + 0.5 * q);
             valid = model_change > 0.0;
@@ -1093,16 +1148,22 @@ __device__ __forceinline__ void lm_begin_iteration(LMState<NP>& st) {
     }
 }
 
-// candidate (xe, cand_cost, ge, Ae) against the current iterate: tolerance tests, accept / reject
+// The LM update is a chain of STAGES, each instantiated exactly once in the kernel (lm_decide -> [wave-wide minimiser] ->
+// lm_trial_next_decide -> lm_apply = {lm_finish_iteration, lm_begin_iteration}); a stage hands the next one an action code.  (As
+// mutually calling inline functions the iteration start was instantiated five times: 13 k instructions, and the register allocator
+// spilled inside the sweep loops.)
+enum { ACT_NONE = 0, ACT_BEGIN = 1, ACT_FINISH_CUR = 2, ACT_FINISH_FIRST = 3, ACT_TRIAL_NEXT = 4, ACT_POLY = 5 };
+
+// candidate (xe, cand_cost, ge, Ae) against the current iterate: tolerance tests, accept / reject.  -> true: start the next iteration
 template <int NP>
-__device__ __forceinline__ void lm_finish_iteration(LMState<NP>& st, double cand_cost, const double* ge, const double* Ae) {
+__device__ __forceinline__ bool lm_finish_iteration(LMState<NP>& st, double cand_cost, const double* ge, const double* Ae) {
     const double kMaxRadius = 1e16, kMinRelDec = 1e-3, kFuncTol = 1e-6, kParamTol = 1e-8;
     double step_norm = 0.0, x_norm = 0.0;
 #pragma unroll
     for (int a = 0; a < NP; ++a) { step_norm += (st.x[a] - st.xe[a]) * (st.x[a] - st.xe[a]); x_norm += st.x[a] * st.x[a]; }
     step_norm = sqrt(step_norm); x_norm = sqrt(x_norm);
-    if (step_norm <= kParamTol * (x_norm + kParamTol)) { st.done = 1; return; }
-    if (fabs(st.cost - cand_cost) <= kFuncTol * st.cost) { st.done = 1; return; }
+    if (step_norm <= kParamTol * (x_norm + kParamTol)) { st.done = 1; return false; }
+    if (fabs(st.cost - cand_cost) <= kFuncTol * st.cost) { st.done = 1; return false; }
     const double rel = (st.cost - cand_cost) / st.model_change;
     if (rel > kMinRelDec) {
 #pragma unroll
@@ -1117,20 +1178,30 @@ __device__ __forceinline__ void lm_finish_iteration(LMState<NP>& st, double cand
     } else {
         st.radius /= st.decrease; st.decrease *= 2.0; st.reuse_diag = 1;
     }
-    lm_begin_iteration<NP>(st);
+    return true;
 }
 
-// Second half of a failed line-search trial: the next step size is known (or the search gives up).
+// Second half of a failed line-search trial: the next step size st.tn is known.  -> ACT_FINISH_FIRST when the search gives up
+// (the candidate is then the first trial point, whose sums were kept), ACT_NONE when the next sweep evaluates the new trial point.
 template <int NP>
-__device__ __forceinline__ void lm_trial_next(LMState<NP>& st, double tn, bool give_up) {
-    if (!give_up && tn * st.dmax < 1e-9) give_up = true;
-    if (give_up) {   // delta stays unscaled: the candidate is the first trial point, whose sums were kept
-        plus_proj<NP>(st.x, st.delta, 1.0, st.lb, st.ub, st.xe);
-        lm_finish_iteration<NP>(st, st.f1, st.g1, st.A1);
-        return;
-    }
+__device__ __forceinline__ int lm_trial_next_decide(LMState<NP>& st) {
+    const double tn = st.tn;
+    if (tn * st.dmax < 1e-9) return ACT_FINISH_FIRST;
     st.t = tn;
     plus_proj<NP>(st.x, st.delta, tn, st.lb, st.ub, st.xe);
+    return ACT_NONE;
+}
+
+// Last stage: finish the iteration with the chosen candidate (the point just swept, or the first trial point) and start the next one.
+template <int NP>
+__device__ __forceinline__ void lm_apply(LMState<NP>& st, int action, double fe, const double* ge, const double* Ae) {
+    bool begin = action == ACT_BEGIN;
+    if (action == ACT_FINISH_CUR || action == ACT_FINISH_FIRST) {
+        const bool first = action == ACT_FINISH_FIRST;
+        if (first) plus_proj<NP>(st.x, st.delta, 1.0, st.lb, st.ub, st.xe);     // delta stays unscaled: back to the first trial point
+        begin = lm_finish_iteration<NP>(st, first ? st.f1 : fe, first ? st.g1 : ge, first ? st.A1 : Ae);
+    }
+    if (begin) lm_begin_iteration<NP>(st);
 }
 
 // Wave 0, all lanes: minimise the pending interpolant (MinimizePolynomial over u in [1e-3 t, 0.6 t] / t).
@@ -1144,20 +1215,19 @@ __device__ __forceinline__ void lm_poly_wave(LMState<NP>& st) {
     if ((threadIdx.x & 63) == 0) st.tn = u * t;
 }
 
-// Called by thread 0 after every sweep with the combined sums of the point just evaluated (st.xe).
+// First stage, called by thread 0 after every sweep with the combined sums of the point just evaluated (st.xe).  -> action code
 template <int NP>
-__device__ __forceinline__ void lm_after_sweep(LMState<NP>& st, bool ok, double fe, const double* ge, const double* Ae) {
+__device__ __forceinline__ int lm_decide(LMState<NP>& st, bool ok, double fe, const double* ge, const double* Ae) {
     ++st.nsweep;
     if (st.phase == PH_INIT) {
         st.cost = fe;
-        if (!ok) { st.done = 1; return; }
+        if (!ok) { st.done = 1; return ACT_NONE; }
 #pragma unroll
         for (int a = 0; a < NP; ++a) { st.g[a] = ge[a]; st.S[a] = 1.0 / (1.0 + sqrt(Ae[a * (a + 1) / 2 + a])); }
 #pragma unroll
         for (int i = 0; i < Tri<NP>::N; ++i) st.A[i] = Ae[i];
         st.gmax = grad_max_norm<NP>(st.x, st.g, st.lb, st.ub);
-        lm_begin_iteration<NP>(st);
-        return;
+        return ACT_BEGIN;
     }
     // PH_TRIAL: projected Armijo search along delta (Ceres ArmijoLineSearch, CUBIC interpolation: every trial needs its
     // gradient).  Every sweep also carries the normal equations (10 more fma per Jacobian row, ~3 % of a sweep), so whichever
@@ -1174,10 +1244,9 @@ __device__ __forceinline__ void lm_after_sweep(LMState<NP>& st, bool ok, double 
     }
     if (ok && fe <= st.cost + 1e-4 * st.gd * st.t) {
         if (st.ls_it > 0) ++st.n_ls_late_accept;
-        lm_finish_iteration<NP>(st, fe, ge, Ae);       // every sweep carries its normal equations: an accepted trial needs no second sweep
-        return;
+        return ACT_FINISH_CUR;       // every sweep carries its normal equations: an accepted trial needs no second sweep
     }
-    if (++st.ls_it >= 20) { lm_trial_next<NP>(st, 0.0, true); return; }
+    if (++st.ls_it >= 20) return ACT_FINISH_FIRST;      // the search gives up
     LsSample cur{st.t, fe, 0.0, ok, false}, prev{st.prev_t, st.prev_f, st.prev_g, st.prev_vok != 0, st.prev_gok != 0};
     if (ok) {
         double gdir = 0.0;
@@ -1189,59 +1258,83 @@ __device__ __forceinline__ void lm_after_sweep(LMState<NP>& st, bool ok, double 
     st.prev_t = cur.x; st.prev_f = cur.value; st.prev_g = cur.gradient; st.prev_vok = cur.value_ok; st.prev_gok = cur.grad_ok;
     double p[6];
     if (interpolating_fit(st.cost, st.gd, cur, prev, p)) {
-        // the minimiser of the interpolant over [1e-3, 0.6] x t is found by the whole wavefront (lm_poly_wave), then lm_trial_next
+        // the minimiser of the interpolant over [1e-3, 0.6] x t is found by the whole wavefront (lm_poly_wave), then lm_trial_next_decide
 #pragma unroll
         for (int j = 0; j < 6; ++j) st.poly[j] = p[j];
         st.poly_req = 1;
-        return;
+        return ACT_POLY;
     }
-    lm_trial_next<NP>(st, fmin(fmax(st.t * 0.5, 1e-3 * st.t), 0.6 * st.t), false);
+    st.tn = fmin(fmax(st.t * 0.5, 1e-3 * st.t), 0.6 * st.t);
+    return ACT_TRIAL_NEXT;
 }
 
-template <int NP, typename PT, int MINW, int WPH>
-__global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __restrict__ packed, const Box* __restrict__ boxes_all,
-                                                       int NCMAX, int nocull, const int* __restrict__ counts,
-                                                       const double* __restrict__ Kmat, const double* __restrict__ init_y,
-                                                       const double* __restrict__ init_T, const double* __restrict__ yaw0,
-                                                       double H, double W, Bounds bnd, int max_iter, int F, int R, int N,
-                                                       double* __restrict__ params_out, double* __restrict__ cost_out,
-                                                       int* __restrict__ iters_out, int* __restrict__ sweeps_out, long long* __restrict__ prof,
-                                                       unsigned long long* __restrict__ state_buf, int* __restrict__ pending,
-                                                       int budget, int resume) {
+// Kernel arguments as ONE struct: the kernel reads every field through the kernarg segment pointer (scalar loads from constant
+// memory at the point of use), so the fields that are only needed before / after the sweep loop (outputs, start values, the
+// diagnostics buffers) do not sit in SGPRs through it -- as plain kernel parameters hipcc loaded all 30 of them at entry and kept
+// them live, which was a third of the kernel's SGPR spills.
+template <typename PT>
+struct SolveArgs {
+    const Rec<PT>* packed;
+    const Box* boxes_all;
+    const int* counts;
+    const double* Kmat;
+    const double* init_y;
+    const double* init_T;
+    const double* yaw0;
+    double* params_out;
+    double* cost_out;
+    int* iters_out;
+    int* sweeps_out;
+    long long* prof;
+    unsigned long long* state_buf;
+    int* pending;
+    double H, W;
+    Bounds bnd;
+    int NCMAX, nocull, max_iter, F, R, N, budget, resume;
+};
+
+template <int NP, typename PT, int MINW, int WPH, bool PROFILE>
+__global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<PT> args_by_value) {
     constexpr int TOFF = NP == 4 ? 1 : 3;
     constexpr int NT = Tri<NP>::N;
     constexpr int NV = NT + NP + 2;
+    (void)args_by_value;
+    typedef const SolveArgs<PT> __attribute__((address_space(4))) * KernArgPtr;
+    const KernArgPtr a = (KernArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     // 1-D grid, frame = block % F: the dispatcher places block b on XCD b % 8, so (for F % 8 == 0) all the
     // hypotheses of a frame share one XCD's L2 and the frame's records are fetched from HBM once.
+    const int F = a->F, R = a->R;
     const int f = blockIdx.x % F;
     const int r = blockIdx.x / F;            // one WPH-wave workgroup per hypothesis
     __shared__ SweepShared<NP, WPH> sh;
     __shared__ LMState<NP> st;
-    const Rec<PT>* recs = packed + (long long)f * N;
-    const Box* boxes = boxes_all + (long long)f * NCMAX;
+    const Rec<PT>* recs = a->packed + (long long)f * a->N;
+    const Box* boxes = a->boxes_all + (long long)f * a->NCMAX;
+    const int* counts = a->counts;
     const int cnt1 = counts[4 * f], cnt0 = counts[4 * f + 1], nc1 = counts[4 * f + 2], nc0 = counts[4 * f + 3];
-    const double* Kf = Kmat + (long long)f * 9;
-    const Cam k{Kf[0], Kf[4], Kf[2], Kf[5], H - 1.0, W - 1.0};
-    const Planes pl{sqrt(k.fx * k.fx + k.cx * k.cx), sqrt(k.fx * k.fx + (k.W1 - k.cx) * (k.W1 - k.cx)),
-                    sqrt(k.fy * k.fy + k.cy * k.cy), sqrt(k.fy * k.fy + (k.H1 - k.cy) * (k.H1 - k.cy))};
+    const double* Kf = a->Kmat + (long long)f * 9;
+    const Cam k{Kf[0], Kf[4], Kf[2], Kf[5], a->H - 1.0, a->W - 1.0};
+    const int nocull = a->nocull;
     const long long hr = (long long)f * R + r;
     constexpr int ST_WORDS = (int)(sizeof(LMState<NP>) / 8);
     static_assert(sizeof(LMState<NP>) % 8 == 0, "LMState is copied as 8-byte words");
     // Two-tier launch (see launch_solve): the first launch stops a hypothesis after `budget` sweeps and parks its LM state;
     // the second launch (more waves per hypothesis) resumes the parked ones and leaves the finished ones alone.
-    if (resume) {
-        if (pending[hr] == 0) return;            // finished in the first tier (workgroup-uniform)
+    if (a->resume) {
+        if (a->pending[hr] == 0) return;            // finished in the first tier (workgroup-uniform)
         unsigned long long* dst = reinterpret_cast<unsigned long long*>(&st);
-        for (int i = threadIdx.x; i < ST_WORDS; i += WPH * 64) dst[i] = state_buf[hr * ST_WORDS + i];
+        const unsigned long long* src = a->state_buf;
+        for (int i = threadIdx.x; i < ST_WORDS; i += WPH * 64) dst[i] = src[hr * ST_WORDS + i];
     } else if (threadIdx.x == 0) {
         for (int i = 0; i < NP; ++i) { st.lb[i] = -DBL_MAX; st.ub[i] = DBL_MAX; }
-        for (int i = 0; i < 3; ++i) { st.lb[TOFF + i] = bnd.lb[i]; st.ub[TOFF + i] = bnd.ub[i]; }
-        const double y0 = init_y[hr] + (yaw0 ? yaw0[f] : 0.0);
+        for (int i = 0; i < 3; ++i) { st.lb[TOFF + i] = a->bnd.lb[i]; st.ub[TOFF + i] = a->bnd.ub[i]; }
+        const double* yaw0 = a->yaw0;
+        const double y0 = a->init_y[hr] + (yaw0 ? yaw0[f] : 0.0);
         if (NP == 4) { st.x[0] = y0; } else { st.x[0] = 0.0; st.x[1] = y0; st.x[2] = 0.0; }
-        for (int i = 0; i < 3; ++i) st.x[TOFF + i] = init_T[hr * 3 + i];
+        for (int i = 0; i < 3; ++i) st.x[TOFF + i] = a->init_T[hr * 3 + i];
         for (int i = 0; i < NP; ++i) { st.x[i] = fmin(fmax(st.x[i], st.lb[i]), st.ub[i]); st.xe[i] = st.x[i]; }
         st.radius = 1e4; st.decrease = 2.0; st.reuse_diag = 0; st.invalid_run = 0; st.iter = 0; st.nsweep = 0;
-        st.phase = PH_INIT; st.done = 0; st.max_iter = max_iter; st.cost = 0.0; st.gmax = 0.0;
+        st.phase = PH_INIT; st.done = 0; st.max_iter = a->max_iter; st.cost = 0.0; st.gmax = 0.0;
         st.n_ls_extra = 0; st.n_ls_late_accept = 0; st.n_resweep = 0; st.want_j = 2; st.poly_req = 0;
     }
     __syncthreads();
@@ -1251,11 +1344,11 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
         double xe[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) xe[i] = st.xe[i];
-        const long long t0 = prof ? clock64() : 0;
-        sweep<NP, PT, WPH, 2>(recs, boxes, cnt1, cnt0, nc1, nc0, k, pl, xe, nocull, sh, n_act);
-        const long long t1 = prof ? clock64() : 0;
+        const long long t0 = PROFILE ? clock64() : 0;
+        sweep<NP, PT, WPH, 2, PROFILE>(recs, boxes, cnt1, cnt0, nc1, nc0, k, xe, nocull, sh, n_act);
+        const long long t1 = PROFILE ? clock64() : 0;
         __syncthreads();
-        const long long t2 = prof ? clock64() : 0;
+        const long long t2 = PROFILE ? clock64() : 0;
         if (threadIdx.x < NV) {                 // fixed-order combination of the wave partials, one value per lane
             double t = sh.red[0][threadIdx.x];
 #pragma unroll
@@ -1263,44 +1356,55 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const Rec<PT>* __
             sh.comb[threadIdx.x] = t;
         }
         __builtin_amdgcn_wave_barrier();        // same wave: its LDS operations retire in order
-        const long long t2b = prof ? clock64() : 0;
+        const long long t2b = PROFILE ? clock64() : 0;
+        int action = ACT_NONE;
         if (threadIdx.x == 0) {
             const bool ok = sh.comb[NV - 1] == 0.0 && isfinite(sh.comb[0]);
-            lm_after_sweep<NP>(st, ok, sh.comb[0], sh.comb + 1, sh.comb + 1 + NP);
+            action = lm_decide<NP>(st, ok, sh.comb[0], sh.comb + 1, sh.comb + 1 + NP);
         }
         if (threadIdx.x < 64) {                 // wave 0: a failed trial left an interpolant to minimise (wave-uniform branch)
             __builtin_amdgcn_wave_barrier();
             if (st.poly_req) {
                 lm_poly_wave<NP>(st);
                 __builtin_amdgcn_wave_barrier();
-                if (threadIdx.x == 0) { st.poly_req = 0; lm_trial_next<NP>(st, st.tn, false); }
+                if (threadIdx.x == 0) { st.poly_req = 0; action = ACT_TRIAL_NEXT; }
             }
         }
-        const long long t3 = prof ? clock64() : 0;
+        if (threadIdx.x == 0) {
+            if (action == ACT_TRIAL_NEXT) action = lm_trial_next_decide<NP>(st);
+            lm_apply<NP>(st, action, sh.comb[0], sh.comb + 1, sh.comb + 1 + NP);
+        }
+        const long long t3 = PROFILE ? clock64() : 0;
         c_comb += t2b - t2;
         __syncthreads();
         c_sweep += t1 - t0; c_wait += t2 - t1; c_lm += t3 - t2;
         if (st.done) break;
+        const int budget = a->budget;
         if (budget > 0 && st.nsweep >= budget) break;       // parked for the wide tier (workgroup-uniform: st is in LDS)
     }
+    int* pending = a->pending;
     if (pending) {
         if (threadIdx.x == 0) pending[hr] = st.done ? 0 : 1;
         if (!st.done) {
             const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&st);
+            unsigned long long* state_buf = a->state_buf;
             for (int i = threadIdx.x; i < ST_WORDS; i += WPH * 64) state_buf[hr * ST_WORDS + i] = src[i];
         }
     }
-    if (prof && threadIdx.x == 0) {   // diagnostics: shader-clock cycles of wave 0 per phase, phase-B evaluations of wave 0
-        if (resume) { c_sweep += prof[hr * 8 + 0]; c_wait += prof[hr * 8 + 1]; c_lm += prof[hr * 8 + 2]; c_comb += prof[hr * 8 + 6];
-                      n_act[0] += (int)prof[hr * 8 + 3]; n_act[1] += (int)prof[hr * 8 + 4]; n_act[2] += (int)prof[hr * 8 + 5]; }
+    if (PROFILE && threadIdx.x == 0) {   // diagnostics: shader-clock cycles of wave 0 per phase, phase-B evaluations of wave 0
+        long long* prof = a->prof;
+        if (a->resume) { c_sweep += prof[hr * 8 + 0]; c_wait += prof[hr * 8 + 1]; c_lm += prof[hr * 8 + 2]; c_comb += prof[hr * 8 + 6];
+                         n_act[0] += (int)prof[hr * 8 + 3]; n_act[1] += (int)prof[hr * 8 + 4]; n_act[2] += (int)prof[hr * 8 + 5]; }
         prof[hr * 8 + 0] = c_sweep; prof[hr * 8 + 1] = c_wait; prof[hr * 8 + 2] = c_lm; prof[hr * 8 + 3] = n_act[0];
         prof[hr * 8 + 4] = n_act[1]; prof[hr * 8 + 5] = n_act[2]; prof[hr * 8 + 6] = c_comb;
         prof[hr * 8 + 7] = (long long)st.n_ls_extra | ((long long)st.n_ls_late_accept << 20) | ((long long)st.n_resweep << 40);
     }
     if (threadIdx.x == 0 && st.done) {
+        double* params_out = a->params_out;
         for (int i = 0; i < NP; ++i) params_out[hr * NP + i] = st.x[i];
-        cost_out[hr] = st.cost;
-        iters_out[hr] = st.iter;
+        a->cost_out[hr] = st.cost;
+        a->iters_out[hr] = st.iter;
+        int* sweeps_out = a->sweeps_out;
         if (sweeps_out) sweeps_out[hr] = st.nsweep;
     }
 }
@@ -1520,28 +1624,44 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
     int* pending = (int*)(base + ws.off_pending);
     unsigned long long* state = (unsigned long long*)(base + ws.off_state);
     const int tier = (int)di2p_opt(DI2P_OPT_SOLVER_TIER_SWEEPS);
-#define DI2P_LAUNCH_SOLVE(NPV, MW, WP, PEND, BUDGET, RESUME) hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP>), grid, dim3(WP * 64), 0, st, packed, boxes, ws.NCMAX, nocull, counts, K, init_y, init_T, yaw0, H, W, b, max_iter, F, R, N, params, cost, iters, sweeps, g_prof, state, PEND, BUDGET, RESUME)
+    SolveArgs<PT> ka;
+    ka.packed = packed; ka.boxes_all = boxes; ka.counts = counts; ka.Kmat = K; ka.init_y = init_y; ka.init_T = init_T; ka.yaw0 = yaw0;
+    ka.params_out = params; ka.cost_out = cost; ka.iters_out = iters; ka.sweeps_out = sweeps; ka.prof = g_prof; ka.state_buf = state;
+    ka.H = H; ka.W = W; ka.bnd = b; ka.NCMAX = ws.NCMAX; ka.nocull = nocull; ka.max_iter = max_iter; ka.F = F; ka.R = R; ka.N = N;
+    // the diagnostics (phase clocks, cluster / evaluation counters) are a separate instantiation: the production kernel carries none of it
+#define DI2P_LAUNCH_SOLVE_P(NPV, MW, WP, PEND, BUDGET, RESUME)                                                                   \
+    do {                                                                                                                         \
+        ka.pending = PEND; ka.budget = BUDGET; ka.resume = RESUME;                                                               \
+        if (g_prof) hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP, true>), grid, dim3(WP * 64), 0, st, ka);                   \
+        else hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP, false>), grid, dim3(WP * 64), 0, st, ka);                         \
+    } while (0)
+#define DI2P_LAUNCH_SOLVE(NPV, MW, WP, PEND, BUDGET, RESUME)                                                                     \
+    do {                                                                                                                         \
+        ka.pending = PEND; ka.budget = BUDGET; ka.resume = RESUME;                                                               \
+        hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP, false>), grid, dim3(WP * 64), 0, st, ka);                              \
+    } while (0)
     int* pend1 = tier > 0 ? pending : nullptr;
     if (is_2d) {
         switch (cfg) {
+#ifndef DI2P_SOLVER_MIN_INSTANCES
+            // variants kept for measurements (DESIGN.md section 4 lists what each one measured); the diagnostics build exists for the default only
             case 42: DI2P_LAUNCH_SOLVE(4, 2, 4, pend1, tier, 0); break;
-            case 82: DI2P_LAUNCH_SOLVE(4, 2, 8, pend1, tier, 0); break;
             case 44: DI2P_LAUNCH_SOLVE(4, 4, 4, pend1, tier, 0); break;
-            case 22: DI2P_LAUNCH_SOLVE(4, 2, 2, pend1, tier, 0); break;
             case 23: DI2P_LAUNCH_SOLVE(4, 3, 2, pend1, tier, 0); break;
-            case 12: DI2P_LAUNCH_SOLVE(4, 2, 1, pend1, tier, 0); break;
-            case 13: DI2P_LAUNCH_SOLVE(4, 3, 1, pend1, tier, 0); break;
-            default: DI2P_LAUNCH_SOLVE(4, 3, 4, pend1, tier, 0); break;
+            case 83: DI2P_LAUNCH_SOLVE(4, 3, 8, pend1, tier, 0); break;
+            case 84: DI2P_LAUNCH_SOLVE(4, 4, 8, pend1, tier, 0); break;
+#endif
+            default: DI2P_LAUNCH_SOLVE_P(4, DI2P_SOLVER_DEFAULT_MINW, DI2P_SOLVER_DEFAULT_WPH, pend1, tier, 0); break;
         }
-        if (tier > 0) {
-            if (cfg % 100 / 10 == 8 && cfg >= 100) DI2P_LAUNCH_SOLVE(4, 2, 8, pending, 0, 1);      // cfg 18x: 8-wave tail (experiments)
-            else DI2P_LAUNCH_SOLVE(4, 3, 12, pending, 0, 1);
-        }
+#ifndef DI2P_SOLVER_MIN_INSTANCES
+        if (tier > 0) DI2P_LAUNCH_SOLVE(4, 3, 12, pending, 0, 1);
     } else {
-        DI2P_LAUNCH_SOLVE(6, 2, 4, pend1, tier, 0);
+        DI2P_LAUNCH_SOLVE_P(6, 2, 4, pend1, tier, 0);
         if (tier > 0) DI2P_LAUNCH_SOLVE(6, 2, 8, pending, 0, 1);
+#endif
     }
 #undef DI2P_LAUNCH_SOLVE
+#undef DI2P_LAUNCH_SOLVE_P
     return 0;
 }
 
