@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdeepi2p_hip.so")
+# DI2P_LIB: development knob -- load another build of the SAME library (A/B runs of kernel variants on one GPU box); still no fallback
+LIB_PATH = os.environ.get("DI2P_LIB") or os.path.join(_HERE, "lib", "libdeepi2p_hip.so")
 _lib = None
 
 c_void_p, c_int, c_float, c_double, c_ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_longlong

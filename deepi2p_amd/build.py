@@ -18,6 +18,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"] 
 # (pnp.hip / prep.hip are not hot, and their fp32 label / inlier arithmetic is compared with numpy value for value: without the
 # vectoriser hipcc contracts other multiply-add pairs into FMAs there and two parity tests see different roundings at cell borders.)
 SLP_ON = set(os.environ.get("DI2P_SLP_ON", "pnp.hip prep.hip").split())
+# Per-file flags.  solver.hip: hipcc's machine-level LICM hoists the fp64 constants of the LM update (tolerances, series coefficients) out
+# of the sweep loop into VGPRs and the register allocator then SPILLS them -- every use became a scratch reload with a full wait, on
+# the one lane whose latency the whole workgroup waits for.  Without that pass the kernel has no scratch at all (tools/kernel_resources.py)
+# and measures 7.8 vs 8.2 ms per launch; `-mllvm -sink-insts-to-avoid-spills` (the targeted fix) measures 7.95.  IR-level LICM is unaffected.
+PER_FILE_FLAGS = {"solver.hip": os.environ.get("DI2P_SOLVER_FLAGS", "-mllvm -disable-machine-licm").split()}
 
 
 def _stale(out, deps):
@@ -27,7 +32,11 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, variant=None, extra_flags=(), csrc=None):
+    """variant: build into lib/variants/<name>/ with extra hipcc flags (A/B experiments, loaded through DI2P_LIB); csrc: other source tree"""
+    global LIBDIR, LIB, CSRC
+    if variant:
+        return _build_variant(variant, list(extra_flags), csrc)
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
@@ -41,7 +50,7 @@ def build(force=False, verbose=True):
         objs.append(obj)
         if force or _stale(obj, [sp] + headers):
             slp = [] if (src in SLP_ON or not src.endswith(".hip")) else ["-fno-slp-vectorize"]
-            cmd = [HIPCC] + FLAGS + slp + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", sp, "-o", obj]
+            cmd = [HIPCC] + FLAGS + slp + PER_FILE_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))
@@ -54,6 +63,26 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     return LIB
+
+
+def _build_variant(name, extra_flags, csrc):
+    vdir = os.path.join(HERE, "lib", "variants", name)
+    os.makedirs(os.path.join(vdir, "obj"), exist_ok=True)
+    src_dir = csrc or CSRC
+    objs, procs = [], []
+    for src in SOURCES:
+        sp = os.path.join(src_dir, src)
+        obj = os.path.join(vdir, "obj", src.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        slp = [] if (src in SLP_ON or not src.endswith(".hip")) else ["-fno-slp-vectorize"]
+        cmd = [HIPCC] + FLAGS + extra_flags + slp + PER_FILE_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", sp, "-o", obj]
+        procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on " + src)
+    lib = os.path.join(vdir, "libdeepi2p_hip.so")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
 
 
 if __name__ == "__main__":

@@ -30,6 +30,9 @@
 #ifndef DI2P_SOLVER_DEFAULT_WPH
 #define DI2P_SOLVER_DEFAULT_WPH 4
 #endif
+#ifndef DI2P_SOLVER_PF
+#define DI2P_SOLVER_PF 4          // clusters classified per straight-line batch of the cluster walk
+#endif
 
 namespace {
 
@@ -122,6 +125,23 @@ __device__ __forceinline__ unsigned spread10(unsigned v) {
     return v;
 }
 
+// Index of cell (x, y) of a 1024 x 1024 grid along the Hilbert curve.  Unlike the Z-order (Morton) curve it has no jumps: 64 consecutive
+// records always form one connected patch of the ground plane, so the cluster boxes are tighter (modelled on the config-2 scene,
+// tools/model_cluster_keys.py: 145 instead of 168 of 321 clusters per frame touch a frustum plane).
+__device__ __forceinline__ unsigned hilbert10(unsigned x, unsigned y) {
+    unsigned d = 0;
+#pragma unroll
+    for (unsigned s = 512; s > 0; s >>= 1) {
+        const unsigned rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+        d += s * s * ((3u * rx) ^ ry);
+        if (ry == 0) {
+            if (rx == 1) { x = s - 1 - x; y = s - 1 - y; }
+            const unsigned t = x; x = y; y = t;
+        }
+    }
+    return d;
+}
+
 template <typename PT>
 __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ points, const int* __restrict__ labels, int N, int P,
                                                        int NCMAX, unsigned long long* __restrict__ keys_all,
@@ -137,7 +157,7 @@ __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ po
     const PT* pz = px + 2 * (long long)N;
     const int* lab = labels + (long long)f * N;
     unsigned long long* keys = keys_all + (long long)f * P;
-    Rec<PT>* out = packed + (long long)f * N;
+    Rec<PT>* out = packed + (long long)f * (N + 2 * CL);      // frame stride: N records + the padding of the two label blocks
     Box* boxes = boxes_all + (long long)f * NCMAX;
 
     // 1. ground-plane bounding box of the valid points, label counts (fixed-order reductions)
@@ -176,7 +196,7 @@ __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ po
             if (l == 0 || l == 1) {
                 const float qx = fminf(fmaxf(((float)px[n] - mnx) * scale, 0.0f), 1023.0f);
                 const float qz = fminf(fmaxf(((float)pz[n] - mnz) * scale, 0.0f), 1023.0f);
-                const unsigned m = spread10((unsigned)qx) | (spread10((unsigned)qz) << 1);
+                const unsigned m = hilbert10((unsigned)qx, (unsigned)qz);
                 k = ((unsigned long long)((l == 1 ? 0u : 1u << 20) | m) << 32) | (unsigned)n;
             }
         }
@@ -226,10 +246,15 @@ __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ po
         }
     }
 
-    // 4. records in sorted order: label-1 block [0, n1), label-0 block [n1, n1+n0)
+    // 4. records in sorted order, every label block CLUSTER-ALIGNED: label-1 block [0, n1), padded to nc1 * CL, label-0 block
+    //    [nc1 * CL, nc1 * CL + n0), padded to (nc1 + nc0) * CL -- cluster c is always the records [c * CL, c * CL + CL), all of them
+    //    addressable (the padding repeats the block's last record; the sweeps mask those lanes out)
     const int nv = n1 + n0;
-    for (int i = tid; i < nv; i += 1024) {
-        const int n = (int)(unsigned)(keys[i] & 0xffffffffull);
+    const int nc1 = (n1 + CL - 1) / CL, nc0 = (n0 + CL - 1) / CL;
+    for (int i = tid; i < (nc1 + nc0) * CL; i += 1024) {
+        const bool first = i < nc1 * CL;
+        const int rank = first ? min(i, n1 - 1) : n1 + min(i - nc1 * CL, n0 - 1);       // position in the sorted key list
+        const int n = (int)(unsigned)(keys[rank] & 0xffffffffull);
         Rec<PT> r;
         r.x = px[n]; r.y = py[n]; r.z = pz[n]; r.lab = lab[n];
         out[i] = r;
@@ -237,10 +262,9 @@ __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ po
     __syncthreads();
 
     // 5. bounding boxes: one wavefront per cluster
-    const int nc1 = (n1 + CL - 1) / CL, nc0 = (n0 + CL - 1) / CL;
     for (int c = wave; c < nc1 + nc0; c += 16) {
-        const int start = c < nc1 ? c * CL : n1 + (c - nc1) * CL;
-        const int end = c < nc1 ? min(start + CL, n1) : min(start + CL, nv);
+        const int start = c * CL;
+        const int end = c < nc1 ? min(start + CL, n1) : min(start + CL, nc1 * CL + n0);
         const bool valid = start + lane < end;
         double x = 0, y = 0, z = 0;
         if (valid) { const Rec<PT> r = out[start + lane]; x = (double)r.x; y = (double)r.y; z = (double)r.z; }
@@ -285,12 +309,13 @@ __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ po
 //   reduction: xor-butterfly inside each wave, then the 4 wave partials are combined through LDS in a FIXED
 //     order by every thread, so all 256 threads hold bit-identical sums and the LM control flow that
 //     follows is workgroup-uniform.
-constexpr int QCAP = 384;        // per-wave queue capacity (ids); phase B drains it when fewer than 4 clusters' worth of room is left
+constexpr int QCAP = DI2P_SOLVER_PF * 64 + 128;        // per-wave queue capacity (ids); phase B drains it when a batch of the cluster walk (PF clusters) may not fit
 
 constexpr int BOXTEST_WORDS = 16;   // sizeof(BoxAbs) / 4 (the table is fetched as 16-byte LDS reads)
 template <int NP, int WPH>   // WPH = waves per hypothesis (workgroup = WPH*64 threads)
 struct SweepShared {
-    double red[WPH][Tri<NP>::N + NP + 2];
+    double red[WPH][Tri<NP>::N + NP + 2];  // per wave: {cost product mantissa, g[NP], A[tri], bad flag}
+    int red_e[WPH];                        // per wave: exponent of the cost product
     double comb[Tri<NP>::N + NP + 2];      // the WPH partials combined in a fixed order (lane i of wave 0 sums value i)
     int queue[WPH][QCAP];
     // Per-lane running sums {cost mantissa, g[NP], A[tri]} and the cost exponent.  They are only touched by phase B, so they live
@@ -327,6 +352,21 @@ __device__ __forceinline__ void project(const Rec<PT>& rc, const Rot<NP>& rot, d
     iz = FAST_RCP ? fast_rcp(p2) : 1.0 / p2;          // the one reciprocal per record
     pix_x = p0 * k.fx * iz + k.cx;
     pix_y = p1 * k.fy * iz + k.cy;
+}
+
+// ln(v) for finite v > 0 without libm: v = m * 2^e with m in [sqrt(1/2), sqrt(2)), ln(m) = 2 atanh(z), z = (m - 1) / (m + 1), |z| <= 0.1716,
+// odd series to z^23 (truncation < 2e-19), one reciprocal.  ~30 instructions instead of the ~600 cycles-deep libm log; absolute error
+// ~1e-16 * (1 + |e|), far below the 1e-6 relative function tolerance it feeds.  Used once per sweep, on the lane that advances the LM state.
+__device__ __forceinline__ double ln_pos(double v) {
+    int e = __builtin_amdgcn_frexp_exp(v);
+    double m = __builtin_amdgcn_frexp_mant(v);          // [0.5, 1)
+    if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }
+    const double z = (m - 1.0) * fast_rcp(m + 1.0), w = z * z;
+    double p = 1.0 / 23.0;
+    p = fma(p, w, 1.0 / 21.0); p = fma(p, w, 1.0 / 19.0); p = fma(p, w, 1.0 / 17.0); p = fma(p, w, 1.0 / 15.0); p = fma(p, w, 1.0 / 13.0);
+    p = fma(p, w, 1.0 / 11.0); p = fma(p, w, 1.0 / 9.0); p = fma(p, w, 1.0 / 7.0); p = fma(p, w, 1.0 / 5.0); p = fma(p, w, 1.0 / 3.0);
+    p = fma(p, w, 1.0);
+    return fma((double)e, 0.69314718055994530942, 2.0 * z * p);
 }
 
 // sum_i log(1 + s_i) of a lane, kept as the PRODUCT prod_i (1 + s_i) = m * 2^e with m in [0.5, 1): one multiply and two
@@ -574,21 +614,26 @@ __device__ __forceinline__ int cluster_status(const Box& bx, const Pre32& q, con
 template <int NP, typename PT, int WPH, int LAB, int MODE, bool PROFILE>
 __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs, int cnt, const Box* __restrict__ boxes, int nc,
                                                const Cam& k, const double* x, const Rot<NP>& rot, int nocull,
-                                               int* queue, double (*acc)[64], int* acc_e, const Pre32& pre, const float* btest_lds, bool& bad, int* n_active) {
+                                               int* queue, double (*acc)[64], int* acc_e, const Pre32& pre, const float* btest_lds, bool& bad, int* n_active, long long* tp) {
     constexpr int TOFF = NP == 4 ? 1 : 3;
     const double tx = x[TOFF], ty = x[TOFF + 1], tz = x[TOFF + 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const double hw = k.W1 * 0.5, hh = k.H1 * 0.5;
     int qn = 0;  // wave-uniform
+    // A cluster's 64 records: one load per lane at (wave-uniform cluster base) + (lane offset).  Label blocks are cluster-aligned and padded
+    // (prepare_kernel), so every lane of every cluster is addressable: no clamping.  Exhausted ring slots (c < 0) re-read cluster 0.
+    const char* rec_bytes = reinterpret_cast<const char*>(recs);
+    const unsigned lane_off = (unsigned)lane * (unsigned)sizeof(Rec<PT>);
     auto load_rec = [&](int c) {
-        // unconditional load from a clamped index (a load inside a branch is waited for on the spot)
-        return recs[min(max(c, 0) * CL + lane, cnt - 1)];
+        const char* base = rec_bytes + (size_t)(unsigned)max(c, 0) * (CL * sizeof(Rec<PT>));      // scalar
+        return *reinterpret_cast<const Rec<PT>*>(base + lane_off);
     };
     // Phase B over the queued ids: full rounds of 64 from the FRONT of the queue (position p of the wave's active sequence is
     // always evaluated by lane p % 64, so the per-lane sums do not depend on when the queue is drained); the records of the next
     // round are gathered while the current round is evaluated.  flush: also the last, partial round.
     auto drain = [&](bool flush) {
+        const long long td0 = PROFILE ? clock64() : 0;
         const int total = flush ? qn : (qn & ~63);
         __builtin_amdgcn_wave_barrier();          // LDS ops of one wave retire in order; only the compiler must not reorder them
         if (total > 0) {                          // wave-uniform
@@ -621,6 +666,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
         if (lane < rem) queue[lane] = carry;
         __builtin_amdgcn_wave_barrier();
         qn = rem;
+        if (PROFILE) tp[1] += clock64() - td0;
     };
     // exact classification of one record (the reference's pixel-form conditions)
     auto exact_active = [&](const Rec<PT>& rec, bool valid) {
@@ -637,30 +683,9 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
     };
     const bool use_pre = (nocull & 2) == 0;
     nocull &= 1;
-    // phase A of one flagged cluster: classify its 64 records (status 1) or take them all (status 2), append the active ids
-    auto classify = [&](int c, bool isA, bool guard_only, const Rec<PT>& rec) {
-        const bool valid = c * CL + lane < cnt;                                     // padding lanes of a partial cluster
-        if (LAB == 0 && guard_only) {            // status 3 (wave-uniform): nothing to queue
-            const bool unc = !use_pre || (valid && zero_guard32<NP>(pre, (float)rec.x, (float)rec.y, (float)rec.z));
-            if (__any(unc)) (void)exact_active(rec, valid);      // sets `bad` on an exact zero / non-finite value
-            return;
-        }
-        bool act = valid;
-        if (isA) {
-            bool unc = true;
-            if (use_pre) {
-                prefilter32<NP, LAB>(pre, (float)rec.x, (float)rec.y, (float)rec.z, act, unc);
-                act = act && valid;
-                unc = unc && valid;
-            }
-            if (__any(unc)) act = exact_active(rec, valid);      // wave-uniform: some lane is not certified -> exact test for the cluster
-        }
-        const unsigned long long bal = __ballot(act);
-        if (act) queue[qn + __popcll(bal & lt)] = c * CL + lane;
-        qn += __popcll(bal);
-    };
     const int mine = (nc - wave + WPH - 1) / WPH;        // clusters wave, wave+WPH, ... < nc
     for (int j0 = 0; j0 < mine; j0 += 64) {
+        const long long ts0 = PROFILE ? clock64() : 0;
         const int j = j0 + lane;
         int status = 0;
         if (j < mine) {
@@ -668,7 +693,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                 status = 1;
             } else {
                 // the table is wave-uniform and only needed here (<= 2 rounds per label block): fetched from LDS per round instead of
-                // staying in ~40 VGPRs through the cluster walk
+                // staying in VGPRs through the cluster walk
                 BoxAbs ab;
                 asm volatile("" ::: "memory");
                 const float4* bt4 = reinterpret_cast<const float4*>(btest_lds);
@@ -679,36 +704,112 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
             }
         }
         const unsigned long long mA = __ballot(status == 1), mB = __ballot(status == 2), mC = __ballot(status == 3);
-        if (PROFILE) { n_active[1] += __popcll(mA); n_active[2] += __popcll(mB); n_active[3] += __popcll(mC); }
-        // The flagged clusters are walked in index order with PF records in flight (a cluster's 64 records are one 16-byte load
-        // per lane; the L2 latency is several times the ~40 instructions a cluster costs).  Slot i of the ring holds the
-        // (bit index, record) of a cluster; exhausted slots carry bit = -1 (and a harmless clamped load).
-        unsigned long long mp = mA | mB | mC;            // clusters not yet requested
-        auto next_bit = [&]() { int b = -1; if (mp) { b = (int)__builtin_ctzll(mp); mp &= mp - 1; } return b; };
-        constexpr int PF = 4;
-        int bits[PF];
-        Rec<PT> ring[PF];
+        if (PROFILE) { n_active[1] += __popcll(mA); n_active[2] += __popcll(mB); n_active[3] += __popcll(mC); tp[0] += clock64() - ts0; }
+        // The flagged clusters are walked FOUR AT A TIME in straight-line code (a cluster's 64 records are one 16-byte load per lane):
+        // the four pre-filters are independent instruction streams, ONE wave-wide vote covers the "some lane is not certified" test
+        // of all four, and the records of the next four are in flight meanwhile.  Walked one by one (round 2) a cluster cost ~600
+        // cycles of dependent latency -- load, pre-filter, two votes, two scalar branches -- for ~40 instructions of work.
+        constexpr int PF = DI2P_SOLVER_PF;
+        auto take_bit = [](unsigned long long& m) { int b = -1; if (m) { b = (int)__builtin_ctzll(m); m &= m - 1; } return b; };
+        if (LAB == 0 && mC) {
+            // (1) zero-guard-only clusters (status 3): no point is active, nothing is queued; only an exact zero / non-finite value on
+            // an undecided plane must be found (sets `bad`).  Order does not matter, so the "not certified" flags of ALL of them are
+            // OR-ed per lane and voted on ONCE; the (practically never taken) slow path then repeats the list with the exact test.
+            unsigned uncb = 0;           // per lane: bit k = some record of this lane in batch k is not certified (<= 16 batches per round)
+            {
+                unsigned long long mg = mC;
+                int nb[PF];
+                Rec<PT> ring[PF];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) { bits[u] = next_bit(); ring[u] = load_rec((j0 + bits[u]) * WPH + wave); }
-        while (bits[0] >= 0) {
-            while (bits[0] >= 0 && qn <= QCAP - PF * 64) {
+                for (int u = 0; u < PF; ++u) { nb[u] = take_bit(mg); ring[u] = load_rec((j0 + nb[u]) * WPH + wave); }
+                for (unsigned batch = 1; nb[0] >= 0; batch <<= 1) {
+                    bool unc = false;
 #pragma unroll
-                for (int u = 0; u < PF; ++u) {
-                    if (bits[u] >= 0) {          // wave-uniform
-                        const Rec<PT> rec = ring[u];
-                        const int bit = bits[u];
-                        bits[u] = next_bit();
-                        ring[u] = load_rec((j0 + bits[u]) * WPH + wave);
-                        classify((j0 + bit) * WPH + wave, (mA >> bit) & 1ull, (mC >> bit) & 1ull, rec);
+                    for (int u = 0; u < PF; ++u) {
+                        const Rec<PT> cur = ring[u];
+                        const bool valid = nb[u] >= 0 && ((j0 + nb[u]) * WPH + wave) * CL + lane < cnt;      // exhausted slots / padding lanes
+                        nb[u] = take_bit(mg);
+                        ring[u] = load_rec((j0 + nb[u]) * WPH + wave);
+                        const bool g = !use_pre | zero_guard32<NP>(pre, (float)cur.x, (float)cur.y, (float)cur.z);     // no short circuit: branch-free
+                        unc = unc | (valid & g);
+                    }
+                    uncb |= unc ? batch : 0u;
+                }
+            }
+            if (__any(uncb != 0)) {      // rare: some record the fp32 guard cannot certify -> exact test of the clusters of ITS batch only
+                unsigned long long mg = mC;
+                for (unsigned batch = 1; mg; batch <<= 1) {
+                    const bool hit = __any((uncb & batch) != 0);        // wave-uniform
+#pragma unroll 1
+                    for (int u = 0; u < PF; ++u) {
+                        const int b = take_bit(mg);
+                        if (b >= 0 && hit) {
+                            const int c = (j0 + b) * WPH + wave;
+                            (void)exact_active(load_rec(c), c * CL + lane < cnt);      // sets `bad` on a zero
+                        }
                     }
                 }
-                // slots are consumed in order 0..PF-1 and refilled in the same order, so after a full pass slot 0 again holds the
-                // oldest cluster; a pass that met an exhausted slot leaves only exhausted slots behind it
             }
-            if (bits[0] >= 0) drain(false);      // queue nearly full: evaluate the full rounds, keep the remainder queued
+        }
+        {
+            // (2) clusters classified per point (status 1) and all-active clusters (status 2), in cluster order: their active ids are
+            // appended to the queue in the order a per-point classification of every cluster would produce
+            unsigned long long mo = mA | mB;
+            int nb[PF];
+            Rec<PT> ring[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) { nb[u] = take_bit(mo); ring[u] = load_rec((j0 + nb[u]) * WPH + wave); }
+            while (nb[0] >= 0) {
+                while (nb[0] >= 0 && qn <= QCAP - PF * 64) {
+                    Rec<PT> cur[PF];
+                    int cid[PF];
+                    bool valid[PF], isA[PF], act[PF], unc[PF];
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) {
+                        cur[u] = ring[u];
+                        cid[u] = (j0 + nb[u]) * WPH + wave;
+                        valid[u] = nb[u] >= 0 && cid[u] * CL + lane < cnt;
+                        isA[u] = nb[u] >= 0 && ((mA >> (nb[u] & 63)) & 1ull);                  // wave-uniform
+                        nb[u] = take_bit(mo);
+                        ring[u] = load_rec((j0 + nb[u]) * WPH + wave);
+                    }
+                    bool any_unc = false;
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) {          // no short circuits: four independent, branch-free instruction streams
+                        bool pa = true, pu = true;
+                        prefilter32<NP, LAB>(pre, (float)cur[u].x, (float)cur[u].y, (float)cur[u].z, pa, pu);
+                        pa = pa | !use_pre; pu = pu | !use_pre;
+                        act[u] = valid[u] & (!isA[u] | pa);               // status 2: every (valid) record is active
+                        unc[u] = valid[u] & isA[u] & pu;
+                        any_unc = any_unc | unc[u];
+                    }
+                    if (__any(any_unc)) {        // rare: some lane of some cluster is not certified -> exact test for THAT cluster
+#pragma unroll
+                        for (int u = 0; u < PF; ++u)
+                            if (__any(unc[u])) act[u] = exact_active(cur[u], valid[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) {      // exhausted slots: act is false on every lane, the append is a no-op
+                        const unsigned long long bal = __ballot(act[u]);
+                        if (act[u]) queue[qn + __popcll(bal & lt)] = cid[u] * CL + lane;
+                        qn += __popcll(bal);
+                    }
+                }
+                if (nb[0] >= 0) drain(false);      // queue nearly full: evaluate the full rounds, keep the remainder queued
+            }
         }
     }
     drain(true);
+}
+
+// Lane exchange inside rows of 16 lanes by DPP (no LDS round trip): CTRL 0xB1 = quad_perm [1,0,3,2] (lane ^ 1), 0x4E = [2,3,0,1]
+// (lane ^ 2), 0x141 = row_half_mirror (lane ^ 7), 0x140 = row_mirror (lane ^ 15).  Applied in this order to a value that is already
+// uniform inside the groups joined so far, they combine 2, 4, 8 and 16 lanes.
+template <int CTRL> __device__ __forceinline__ int dpp_int(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ double dpp_double(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = dpp_int<CTRL>((int)b), hi = dpp_int<CTRL>((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
 
 // Leaves the WPH wave partials {cost, g[NP], A[tri], bad} in sh.red[wave][*]; the caller combines them after a
@@ -716,8 +817,9 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
 // specialised loops.
 template <int NP, typename PT, int WPH, int MODE, bool PROFILE>
 __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Box* __restrict__ boxes, int cnt1, int cnt0, int nc1,
-                                     int nc0, const Cam& k, const double* x, int nocull, SweepShared<NP, WPH>& sh, int* n_active) {
+                                     int nc0, const Cam& k, const double* x, int nocull, SweepShared<NP, WPH>& sh, int* n_active, long long* tp) {
     constexpr int NV = Tri<NP>::N + NP + 2;
+    const long long tq0 = PROFILE ? clock64() : 0;
     constexpr int TOFF = NP == 4 ? 1 : 3;
     static_assert(sizeof(BoxAbs) == BOXTEST_WORDS * 4, "box-test table is copied as float4s");
     Rot<NP> rot;
@@ -747,74 +849,37 @@ __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Bo
     }
     __builtin_amdgcn_wave_barrier();
     bool bad = false;
-    sweep_clusters<NP, PT, WPH, 1, MODE, PROFILE>(recs, cnt1, boxes, nc1, k, x, rot, nocull, queue, acc, acc_e, pre, sh.btest[wave], bad, n_active);
-    sweep_clusters<NP, PT, WPH, 0, MODE, PROFILE>(recs + cnt1, cnt0, boxes + nc1, nc0, k, x, rot, nocull, queue, acc, acc_e, pre, sh.btest[wave], bad, n_active);
+    if (PROFILE) tp[2] += clock64() - tq0;          // set-up: rotation, fp32 tables, zeroed sums
+    sweep_clusters<NP, PT, WPH, 1, MODE, PROFILE>(recs, cnt1, boxes, nc1, k, x, rot, nocull, queue, acc, acc_e, pre, sh.btest[wave], bad, n_active, tp);
+    sweep_clusters<NP, PT, WPH, 0, MODE, PROFILE>(recs + nc1 * CL, cnt0, boxes + nc1, nc0, k, x, rot, nocull, queue, acc, acc_e, pre, sh.btest[wave], bad, n_active, tp);
     __builtin_amdgcn_wave_barrier();
-    LogProd cost;
-    cost.m = acc[0][lane]; cost.e = acc_e[lane];
-    double lg[NP], lA[Tri<NP>::N];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) lg[i] = acc[1 + i][lane];
-#pragma unroll
-    for (int i = 0; i < Tri<NP>::N; ++i) lA[i] = acc[1 + NP + i][lane];
-
-    // a non-finite Jacobian entry (evaluation failure in the reference) makes a sum non-finite: tested once per sweep
-    if (MODE >= 1) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) if (!isfinite(lg[i])) bad = true;
-    }
-    if (MODE == 2) {
-#pragma unroll
-        for (int i = 0; i < Tri<NP>::N; ++i) if (!isfinite(lA[i])) bad = true;
-    }
+    const long long tq1 = PROFILE ? clock64() : 0;
+    // Wave totals of the 1 + NP + tri running values, read back from LDS TRANSPOSED: 16 lanes per value (4 values per round), each
+    // lane takes 4 consecutive lanes' entries (two 16-byte reads), then four DPP steps join the 16 partial results.  Value 0 is the
+    // cost PRODUCT (mantissas multiply, exponents add; the single log is taken by the LM lane after the waves' products are
+    // combined), the others are sums.  Fixed association: deterministic, and the same whichever shortcut built the per-lane values.
+    // (Replaces a 16-value butterfly over ds_bpermute + one log per lane: 4.1 k cycles per wave and sweep.)
+    constexpr int NVAL = 1 + NP + Tri<NP>::N;
+    const int grp = lane >> 4, q = lane & 15;
     double* mine = sh.red[wave];
+#pragma unroll
+    for (int r = 0; r * 4 < NVAL; ++r) {
+        const int i = r * 4 + grp;
+        const int ic = i < NVAL ? i : NVAL - 1;
+        const double4 v = *reinterpret_cast<const double4*>(&acc[ic][q * 4]);
+        const bool is_cost = r == 0 && grp == 0;
+        double val = is_cost ? (v.x * v.y) * (v.z * v.w) : (v.x + v.y) + (v.z + v.w);
+        int ex = 0;
+        if (r == 0) { const int4 e4 = *reinterpret_cast<const int4*>(&acc_e[q * 4]); ex = (e4.x + e4.y) + (e4.z + e4.w); }
+#define DI2P_JOIN(CTRL) { const double o = dpp_double<CTRL>(val); val = is_cost ? val * o : val + o; if (r == 0) ex += dpp_int<CTRL>(ex); }
+        DI2P_JOIN(0xB1) DI2P_JOIN(0x4E) DI2P_JOIN(0x141) DI2P_JOIN(0x140)
+#undef DI2P_JOIN
+        if (q == 0 && i < NVAL) mine[i] = val;          // >= 2^-64 for the product of 64 mantissas in [0.5, 1): no underflow
+        if (r == 0 && lane == 0) sh.red_e[wave] = ex;
+    }
     const bool anybad = __any(bad) != 0;        // evaluated by the whole wave (a ballot inside `if (lane == 0)` sees lane 0 only)
-    // Wave reduction of NV - 1 values per lane.  Butterfly with value halving: at step k a lane keeps the values whose index
-    // has bit k equal to its own lane bit k, sends the other half to lane ^ (1 << k) and adds what it receives, so the number
-    // of live values halves per step (16 -> 8 -> 4 -> 2 -> 1, then plain butterflies): ~2x(NV-1) exchanges instead of
-    // 6x(NV-1).  The pairing, hence the summation order, is fixed: deterministic and identical on every path.
-    double vals[16];
-    vals[0] = 0.5 * cost.log_value();
-#pragma unroll
-    for (int i = 0; i < NP; ++i) vals[1 + i] = lg[i];
-#pragma unroll
-    for (int i = 0; i < Tri<NP>::N; ++i) vals[1 + NP + i] = lA[i];
-    static_assert(1 + NP + Tri<NP>::N <= 16 || NP == 6, "value count");
-    if (NP == 4) {
-#pragma unroll
-        for (int i = 1 + NP + Tri<NP>::N; i < 16; ++i) vals[i] = 0.0;
-        int nlive = 16;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bool up = (lane >> k) & 1;
-            nlive >>= 1;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (i < nlive) {
-                    const double keep = up ? vals[2 * i + 1] : vals[2 * i];
-                    const double send = up ? vals[2 * i] : vals[2 * i + 1];
-                    vals[i] = keep + __shfl_xor(send, 1 << k);
-                }
-        }
-        double r = vals[0];
-        r += __shfl_xor(r, 16);
-        r += __shfl_xor(r, 32);
-        // step k consumed bit k of the value index together with lane bit k: lane l < 16 now holds the wave total of value l
-        if (lane < 1 + NP + Tri<NP>::N) mine[lane] = r;
-        if (lane == 0) mine[NV - 1] = anybad ? 1.0 : 0.0;
-        return;
-    }
-    double v = wave_sum(vals[0]);
-    if (lane == 0) mine[0] = v;
-    if (MODE >= 1) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) { v = wave_sum(lg[i]); if (lane == 0) mine[1 + i] = v; }
-    }
-    if (MODE == 2) {
-#pragma unroll
-        for (int i = 0; i < Tri<NP>::N; ++i) { v = wave_sum(lA[i]); if (lane == 0) mine[1 + NP + i] = v; }
-    }
     if (lane == 0) mine[NV - 1] = anybad ? 1.0 : 0.0;
+    if (PROFILE) tp[3] += clock64() - tq1;      // wave totals
 }
 
 // Cholesky solve of M y = rhs IN PLACE: M (lower triangle, row-major) is overwritten by its factor L, y holds rhs on entry and the
@@ -1308,7 +1373,7 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
     const int r = blockIdx.x / F;            // one WPH-wave workgroup per hypothesis
     __shared__ SweepShared<NP, WPH> sh;
     __shared__ LMState<NP> st;
-    const Rec<PT>* recs = a->packed + (long long)f * a->N;
+    const Rec<PT>* recs = a->packed + (long long)f * (a->N + 2 * CL);
     const Box* boxes = a->boxes_all + (long long)f * a->NCMAX;
     const int* counts = a->counts;
     const int cnt1 = counts[4 * f], cnt0 = counts[4 * f + 1], nc1 = counts[4 * f + 2], nc0 = counts[4 * f + 3];
@@ -1339,21 +1404,35 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
     }
     __syncthreads();
     long long c_sweep = 0, c_wait = 0, c_lm = 0, c_comb = 0;
-    int n_act[4] = {0, 0, 0, 0};   // wave 0: phase-B evaluations, clusters classified per point / all active / tested
+    int n_act[4] = {0, 0, 0, 0};   // wave 0: phase-B evaluations, clusters classified per point / all active / guard-only
+    long long tp[4] = {0, 0, 0, 0}; // wave 0, inside the sweep: cluster-test rounds, drains (phase B), set-up, reduction
+    long long c_decide = 0, c_poly = 0, c_apply = 0;
     for (;;) {
         double xe[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) xe[i] = st.xe[i];
         const long long t0 = PROFILE ? clock64() : 0;
-        sweep<NP, PT, WPH, 2, PROFILE>(recs, boxes, cnt1, cnt0, nc1, nc0, k, xe, nocull, sh, n_act);
+        sweep<NP, PT, WPH, 2, PROFILE>(recs, boxes, cnt1, cnt0, nc1, nc0, k, xe, nocull, sh, n_act, tp);
         const long long t1 = PROFILE ? clock64() : 0;
         __syncthreads();
         const long long t2 = PROFILE ? clock64() : 0;
-        if (threadIdx.x < NV) {                 // fixed-order combination of the wave partials, one value per lane
-            double t = sh.red[0][threadIdx.x];
+        if (threadIdx.x < 64) {                 // wave 0: fixed-order combination of the wave partials, one value per lane
+            const int i = threadIdx.x < NV ? threadIdx.x : NV - 1;
+            double part[WPH];
+            int ex = 0;
 #pragma unroll
-            for (int w = 1; w < WPH; ++w) t += sh.red[w][threadIdx.x];
-            sh.comb[threadIdx.x] = t;
+            for (int w = 0; w < WPH; ++w) { part[w] = sh.red[w][i]; ex += sh.red_e[w]; }       // all reads in flight together
+            double sum = part[0], prod = part[0];
+#pragma unroll
+            for (int w = 1; w < WPH; ++w) { sum += part[w]; prod *= part[w]; }                 // branch-free: both forms, then a select
+            // value 0: the waves' cost products multiply (>= 2^(-64 WPH): no underflow), rho sum = ln(product), halved; evaluated by every
+            // lane (no divergent branch; lanes > 0 feed it their harmless sums); a non-finite / non-positive product gives NaN, caught below
+            const double cost = 0.5 * (ln_pos(i == 0 ? prod : 1.0) + (double)ex * 0.69314718055994530942);
+            double t = i == 0 ? cost : sum;
+            // a non-finite Jacobian entry or residual (evaluation failure in the reference) makes a sum non-finite: one vote per sweep
+            const bool nonfinite = __any(threadIdx.x < NV - 1 && !isfinite(t)) != 0;
+            if (threadIdx.x == NV - 1 && nonfinite) t = 1.0;
+            if (threadIdx.x < NV) sh.comb[threadIdx.x] = t;
         }
         __builtin_amdgcn_wave_barrier();        // same wave: its LDS operations retire in order
         const long long t2b = PROFILE ? clock64() : 0;
@@ -1362,6 +1441,7 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
             const bool ok = sh.comb[NV - 1] == 0.0 && isfinite(sh.comb[0]);
             action = lm_decide<NP>(st, ok, sh.comb[0], sh.comb + 1, sh.comb + 1 + NP);
         }
+        const long long t2c = PROFILE ? clock64() : 0;
         if (threadIdx.x < 64) {                 // wave 0: a failed trial left an interpolant to minimise (wave-uniform branch)
             __builtin_amdgcn_wave_barrier();
             if (st.poly_req) {
@@ -1370,12 +1450,13 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
                 if (threadIdx.x == 0) { st.poly_req = 0; action = ACT_TRIAL_NEXT; }
             }
         }
+        const long long t2d = PROFILE ? clock64() : 0;
         if (threadIdx.x == 0) {
             if (action == ACT_TRIAL_NEXT) action = lm_trial_next_decide<NP>(st);
             lm_apply<NP>(st, action, sh.comb[0], sh.comb + 1, sh.comb + 1 + NP);
         }
         const long long t3 = PROFILE ? clock64() : 0;
-        c_comb += t2b - t2;
+        c_comb += t2b - t2; c_decide += t2c - t2b; c_poly += t2d - t2c; c_apply += t3 - t2d;
         __syncthreads();
         c_sweep += t1 - t0; c_wait += t2 - t1; c_lm += t3 - t2;
         if (st.done) break;
@@ -1391,13 +1472,12 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
             for (int i = threadIdx.x; i < ST_WORDS; i += WPH * 64) state_buf[hr * ST_WORDS + i] = src[i];
         }
     }
-    if (PROFILE && threadIdx.x == 0) {   // diagnostics: shader-clock cycles of wave 0 per phase, phase-B evaluations of wave 0
-        long long* prof = a->prof;
-        if (a->resume) { c_sweep += prof[hr * 8 + 0]; c_wait += prof[hr * 8 + 1]; c_lm += prof[hr * 8 + 2]; c_comb += prof[hr * 8 + 6];
-                         n_act[0] += (int)prof[hr * 8 + 3]; n_act[1] += (int)prof[hr * 8 + 4]; n_act[2] += (int)prof[hr * 8 + 5]; }
-        prof[hr * 8 + 0] = c_sweep; prof[hr * 8 + 1] = c_wait; prof[hr * 8 + 2] = c_lm; prof[hr * 8 + 3] = n_act[0];
-        prof[hr * 8 + 4] = n_act[1]; prof[hr * 8 + 5] = n_act[2]; prof[hr * 8 + 6] = c_comb;
-        prof[hr * 8 + 7] = (long long)st.n_ls_extra | ((long long)st.n_ls_late_accept << 20) | ((long long)st.n_resweep << 40);
+    if (PROFILE && threadIdx.x == 0) {   // diagnostics, 16 int64 per hypothesis (wave 0's shader-clock cycles and counts; see di2p_solver_set_profile_buffer)
+        long long* prof = a->prof + hr * 16;
+        long long v[16] = {c_sweep, c_wait, c_lm, n_act[0], n_act[1], n_act[2], c_comb,
+                           (long long)st.n_ls_extra | ((long long)st.n_ls_late_accept << 20) | ((long long)st.n_resweep << 40),
+                           c_decide, c_poly, c_apply, n_act[3], tp[0], tp[1], tp[2], tp[3]};
+        for (int i = 0; i < 16; ++i) prof[i] = (a->resume && i != 7 ? prof[i] : 0) + v[i];
     }
     if (threadIdx.x == 0 && st.done) {
         double* params_out = a->params_out;
@@ -1589,7 +1669,7 @@ static SolveWs solve_ws_layout(int F, int R, int N) {
     w.NCMAX = (N + CL - 1) / CL + 2;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     w.off_recs = up((size_t)F * 4 * sizeof(int));
-    w.off_boxes = up(w.off_recs + (size_t)F * N * 32);
+    w.off_boxes = up(w.off_recs + (size_t)F * (N + 2 * CL) * 32);
     w.off_keys = up(w.off_boxes + (size_t)F * w.NCMAX * sizeof(Box));
     w.off_pending = up(w.off_keys + (size_t)F * w.P * 8);
     w.off_state = up(w.off_pending + (size_t)F * R * sizeof(int));
@@ -1722,7 +1802,9 @@ extern "C" long long di2p_solve_workspace_bytes(int F, int R, int N) {
     return (long long)solve_ws_layout(F, R, N).bytes;
 }
 
-// Diagnostics: when set to a device buffer of F*R*8 int64, every solve launch records per hypothesis the shader-clock
-// cycles wave 0 spent in {sweep, waiting at the reduction barrier, LM update}, its number of phase-B evaluations, and
-// its clusters {classified per point, taken as all-active, tested}.
+// Diagnostics: when set to a device buffer of F*R*16 int64, every solve launch (a separate instantiation of the kernel) records per
+// hypothesis: [0..2] shader-clock cycles wave 0 spent in {sweep, waiting at the reduction barrier, LM update}, [3] its phase-B
+// evaluations, [4..5] its clusters {classified per point, taken as all-active}, [6] cycles combining the wave partials, [7] packed
+// line-search counters, [8..10] LM stages {decide, wave-wide interpolant minimiser, finish + begin iteration}, [11] guard-only
+// clusters, [12..15] inside the sweep: {cluster-test rounds, drains = phase B, set-up, log + wave reduction}.
 extern "C" void di2p_solver_set_profile_buffer(void* buf) { g_prof = (long long*)buf; }

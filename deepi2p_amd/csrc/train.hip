@@ -441,27 +441,36 @@ RedPlan red_plan(int B, int C, int N) {
 
 // =============================================================================================== arg-max routers
 // 3x3 / stride 2 / pad 1 max-pool backward: the gradient of an output goes to the FIRST maximum of its window in (ky, kx)
-// scan order (max_pool2d keeps `val > maxval`); windows overlap, so the adds are atomic (<= 4 terms per input element).
+// scan order (max_pool2d keeps `val > maxval`).  GATHER form: one thread per INPUT pixel visits the <= 4 windows that cover it
+// (oy in {ceil((iy-1)/2) .. floor((iy+1)/2)}, likewise ox), recomputes each window's first arg-max and adds the gradients of the
+// windows it wins in a fixed (oy, ox) order -- deterministic, no float atomics, no memset of dx.
 __global__ __launch_bounds__(256) void maxpool_backward_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int H, int W,
                                                                int OH, int OW, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
-    const long long plane = i / ((long long)OW * OH);
+    const int ix = (int)(i % W), iy = (int)((i / W) % H);
+    const long long plane = i / ((long long)W * H);
     const float* xp = x + plane * H * W;
-    float best = 0.0f;
-    int arg = -1;
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy * 2 - 1 + ky;
-        if (iy < 0 || iy >= H) continue;
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox * 2 - 1 + kx;
-            if (ix < 0 || ix >= W) continue;
-            const float v = xp[iy * W + ix];
-            if (arg < 0 || v > best) { best = v; arg = iy * W + ix; }
+    const float* dyp = dy + plane * OH * OW;
+    float g = 0.0f;
+    for (int oy = max(iy / 2, 0); oy <= min((iy + 1) / 2, OH - 1); ++oy) {          // windows with oy*2-1 <= iy <= oy*2+1
+        for (int ox = max(ix / 2, 0); ox <= min((ix + 1) / 2, OW - 1); ++ox) {
+            float best = 0.0f;
+            int arg = -1;
+            for (int ky = 0; ky < 3; ++ky) {
+                const int yy = oy * 2 - 1 + ky;
+                if (yy < 0 || yy >= H) continue;
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int xx = ox * 2 - 1 + kx;
+                    if (xx < 0 || xx >= W) continue;
+                    const float v = xp[yy * W + xx];
+                    if (arg < 0 || v > best) { best = v; arg = yy * W + xx; }
+                }
+            }
+            if (arg == iy * W + ix) g += dyp[oy * OW + ox];
         }
     }
-    if (arg >= 0) atomicAdd(dx + plane * H * W + arg, dy[i]);
+    dx[i] = g;
 }
 
 // dX[b][c][max_idx[b][c][m]] += dV[b][c][m] * mask[b][m]   (index_max + gather + mask of networks_pc.py:88-93,101-104)
@@ -633,8 +642,7 @@ extern "C" int di2p_maxpool3x3s2_backward(const float* x, const float* dy, float
     DI2P_CHECK_ARG(x && dy && dx && B >= 1 && C >= 1 && H >= 1 && W >= 1, "bad args");
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(dx, 0, (size_t)B * C * H * W * 4, st) != hipSuccess) { di2p_set_error("%s: memset failed", __func__); return -1; }
-    const long long total = (long long)B * C * OH * OW;
+    const long long total = (long long)B * C * H * W;
     hipLaunchKernelGGL(maxpool_backward_kernel, dim3(di2p_cdiv(total, 256)), dim3(256), 0, st, x, dy, dx, H, W, OH, OW, total);
     DI2P_RETURN_LAUNCH();
 }

@@ -430,7 +430,8 @@ extern "C" int di2p_conv3x3_winograd(const float* x, const float* U, const float
 #define DI2P_WINO_LAUNCH(COBV, DBV, KCV)                                                                                                     \
     do {                                                                                                                                     \
         const int n_cb = Cout / COBV;                                                                                                        \
-        const int by_co = map_opt ? map_opt == 2 : (n_cb % 8 == 0 && (long long)16 * Cin * Cout * 4 > (2ll << 20));                         \
+        /* the co-block mapping needs n_cb % 8 == 0 (the kernel divides by n_cb / 8): the knob cannot force it elsewhere */                 \
+        const int by_co = n_cb % 8 == 0 && (map_opt ? map_opt == 2 : (long long)16 * Cin * Cout * 4 > (2ll << 20));                           \
         const int grid = by_co ? n_cb * n_tb : di2p_cdiv(n_tb, 8) * 8 * n_cb;                                                                \
         const size_t lds = WinoLds<COBV, DBV, KCV>::TOTAL * sizeof(float);                                                                        \
         (void)hipFuncSetAttribute((const void*)wino_conv_kernel<COBV, DBV, KCV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \

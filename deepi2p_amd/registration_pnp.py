@@ -29,11 +29,13 @@ def draw_samples(rng, F, iters):
 
 
 def pnp_ransac(pc, coarse, fine, K_scaled, W_fine, samples, reproj_err=0.6, refine_rounds=20, refine_iters=5, pixels=None,
-               method="dlt_lo"):
+               method="epnp"):
     """Batched device entry.  pc f32[F,3,N], coarse/fine i32[F,N], K_scaled f64[F,3,3], samples i32[F,iters,6]
     -> dict(P f64[F,4,4], outlier_ratio f64[F], n_inliers, n_corr, best i32[F]).
-    method "epnp": EPnP minimal-sample hypotheses (5 points, or 4 when a frame has only 4) + one EPnP re-fit on the inliers, the
-    estimator of cv2.solvePnPRansac(flags=SOLVEPNP_EPNP); "dlt_lo": 6-point DLT hypotheses + locally optimised best model."""
+    method "epnp" (default -- what the reference asks OpenCV for, registration_pnp.py:125-132): EPnP minimal-sample hypotheses (5 points,
+    or 4 when a frame has only 4) + one EPnP re-fit on the inliers, the estimator of cv2.solvePnPRansac(flags=SOLVEPNP_EPNP);
+    "dlt_lo": the builder's 6-point DLT hypotheses + locally optimised best model (more robust on cell-quantised observations, but not the
+    reference's algorithm; refine_rounds / refine_iters apply to it only)."""
     require_cuda(pc, coarse, fine, K_scaled, samples, pixels)
     F, _, N = pc.shape
     iters = samples.shape[1]

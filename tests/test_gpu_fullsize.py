@@ -127,15 +127,51 @@ def test_config2_stated_batch_64_fine_head_and_pnp(dev):
     coarse_gt, fine_gt = prep.project_labels(x[0], P_gt, K32, H, W, 32)
     Kf = torch.from_numpy(np.stack([camera_matrix_scaling(k, 1 / 32) for k in b["K"]])).to(dev)
     samples = torch.from_numpy(draw_samples(np.random.default_rng(0), B, 500)).to(dev)
-    out = pnp_ransac(x[0], coarse_gt, fine_gt, Kf, W // 32, samples)
-    out2 = pnp_ransac(x[0], coarse_gt, fine_gt, Kf, W // 32, samples)
-    assert torch.equal(out["P"], out2["P"])                      # deterministic given the draws
+    # The reference's estimator (EPnP RANSAC, the default) under two observation models:
+    #  (a) the reference's own front end (registration_pnp.py:107-109): the pixel of a correspondence is the top-left CORNER of its
+    #      32 x 32 cell -- a systematic half-cell bias of ~2.6 deg per axis at fx = 359 px, hence the 8 deg bound;
+    #  (b) cell-CENTRE observations, passed explicitly (the test controls them): unbiased, so the reference's 5 deg / 2 m success rule
+    #      applies.  In both cases EPnP's unconditional least-squares re-fit on the inliers (as cv2.solvePnPRansac does it) flips to a
+    #      mirrored solution on ~1 frame in 6 of this 5 m thick slab scene (oracle/epnp_np.py behaves identically: 20 of 24 frames pass
+    #      either bound there); such frames have |t| > 14.14 and come back as identity / outlier ratio 1, as in the reference.
+    py = torch.div(fine_gt, W // 32, rounding_mode="floor")
+    centre = torch.stack(((fine_gt - py * (W // 32)).float() + 0.5, py.float() + 0.5), dim=1).contiguous()
+    for name, pixels, r_max, in (("corner", None, 8.0), ("centre", centre, 5.0)):
+        out = pnp_ransac(x[0], coarse_gt, fine_gt, Kf, W // 32, samples, pixels=pixels)
+        out2 = pnp_ransac(x[0], coarse_gt, fine_gt, Kf, W // 32, samples, pixels=pixels)
+        assert torch.equal(out["P"], out2["P"])                      # deterministic given the draws
+        P = out["P"].cpu().numpy()
+        errs = [flm.get_P_diff(P[i], b["P_gt"][i]) for i in range(B)]
+        ok = sum(1 for t, r in errs if t < 2.0 and r < r_max)
+        assert ok >= 0.7 * B, (name, ok)
+        if name == "centre":
+            assert np.median([r for t, r in errs]) < 2.5
+    # the builder's DLT + local-optimisation variant stays available behind method="dlt_lo"
+    out = pnp_ransac(x[0], coarse_gt, fine_gt, Kf, W // 32, samples, method="dlt_lo")
     P = out["P"].cpu().numpy()
-    ok = 0
-    for i in range(B):
-        t, r = flm.get_P_diff(P[i], b["P_gt"][i])
-        ok += (t < 2.0 and r < 8.0)
+    ok = sum(1 for i in range(B) if (lambda tr: tr[0] < 2.0 and tr[1] < 8.0)(flm.get_P_diff(P[i], b["P_gt"][i])))
     assert ok >= 0.8 * B, ok
+
+
+def test_config3_shape_logits_vs_oracle(dev):
+    """BASELINE configs[3] at its frame shape (nuScenes: 30000 points, 896 x 1600 image, L = 28 x 50 = 1400 fine classes), B = 1:
+    every coarse and fine logit against the oracle restatement run here on the same frame (the 1402-output head and the 28 x 50
+    attention maps are exercised by no golden fixture)."""
+    N, H, W = 30000, 896, 1600
+    det, opt = _det(dev, N, H, W, True)
+    b = synthetic.make_batch(303, 1, N=N, H=H, W=W)
+    x = [torch.from_numpy(b[k]).to(dev) for k in fg.NAMES]
+    coarse, fine = det(*x)
+    assert coarse.shape == (1, 2, N) and fine.shape == (1, 1400, N)
+    torch.set_num_threads(32)
+    sd = nt.synthetic_state_dict(nt.OptLike(N, H, W, True))
+    with torch.no_grad():
+        rc, rf = nt.keypoint_detector(sd, nt.OptLike(N, H, W, True), *[torch.from_numpy(b[k]) for k in fg.NAMES])
+    coarse, fine = coarse.cpu(), fine.cpu()
+    assert float((coarse - rc).abs().max()) <= REL * float(rc.abs().max()) + 1e-7
+    assert float((fine - rf).abs().max()) <= REL * float(rf.abs().max()) + 1e-7
+    assert (coarse.argmax(1) != rc.argmax(1)).float().mean() < 1e-3
+    assert (fine.argmax(1) != rf.argmax(1)).float().mean() < 1e-3
 
 
 def test_config3_stated_batch_16_per_gpu(dev):

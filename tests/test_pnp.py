@@ -87,7 +87,7 @@ def test_hip_matches_oracle_on_identical_draws(dev):
     sm = torch.from_numpy(np.stack([fr[5] for fr in frames])).to(dev)
     Wf = frames[0][6]
     for use_pixels in (True, False):
-        out = rp.pnp_ransac(pc, co, fi, K, Wf, sm, pixels=px if use_pixels else None)
+        out = rp.pnp_ransac(pc, co, fi, K, Wf, sm, pixels=px if use_pixels else None, method="dlt_lo")      # vs the DLT oracle
         for i, fr in enumerate(frames):
             P, ratio, nin, cnt, best, counts = pnp_np.pnp_ransac(fr[0]["pc"], fr[2], fr[3], fr[1], Wf, fr[5],
                                                                  pixels=fr[4] if use_pixels else None)

@@ -33,18 +33,24 @@ for name, lab_np in (("noisy-gt", np.stack([f["labels"] for f in frames])),):
     kept = (lab_front >= 0).sum(1).float().mean().item()
     if os.environ.get("PROF"):
         from deepi2p_amd import _lib
-        prof = torch.zeros((F, R, 8), dtype=torch.int64, device=dev)
+        PW = 16 if _lib.load().di2p_version() >= 3 else 8       # int64 words per hypothesis (version 3: finer phases)
+        prof = torch.zeros((F, R, PW), dtype=torch.int64, device=dev)
         _lib.load().di2p_solver_set_profile_buffer(prof.data_ptr())
         ops.solve_batched(pc, lab_front, K, restarts[0], restarts[1], H, W, pipe.lb, pipe.ub, 500, True, yaw0=yaw0, sweeps=sweeps)
         torch.cuda.synchronize()
         _lib.load().di2p_solver_set_profile_buffer(None)
-        p = prof.double().cpu().numpy().reshape(-1, 8); sw = sweeps.cpu().numpy().reshape(-1)
+        p = prof.double().cpu().numpy().reshape(-1, PW); sw = sweeps.cpu().numpy().reshape(-1)
         tot = p[:, :3].sum(1)
         print("  per-sweep cycles (mean over hyps): sweep %.0f  barrier-wait %.0f  LM %.0f ; active evals/sweep (wave0) %.1f of %d records/wave"
               % ((p[:, 0] / sw).mean(), (p[:, 1] / sw).mean(), (p[:, 2] / sw).mean(), (p[:, 3] / sw).mean(), kept / 4))
-        print("  clusters per sweep (wave 0): per-point %.1f  all-active %.1f  (zero-guard only: see n_act[3]) ; partial-combine cycles per sweep %.0f (part of LM)" % ((p[:, 4] / sw).mean(), (p[:, 5] / sw).mean(), (p[:, 6] / sw).mean()))
+        print("  clusters per sweep (wave 0): per-point %.1f  all-active %.1f  guard-only %s ; partial-combine cycles per sweep %.0f (part of LM)" % (
+            (p[:, 4] / sw).mean(), (p[:, 5] / sw).mean(), ("%.1f" % (p[:, 11] / sw).mean()) if PW == 16 else "n/a", (p[:, 6] / sw).mean()))
+        if PW == 16:
+            print("  LM stages per sweep: combine %.0f  decide %.0f  wave minimiser %.0f  finish+begin %.0f" % tuple((p[:, i] / sw).mean() for i in (6, 8, 9, 10)))
+            print("  inside the sweep (wave 0, cycles per sweep): set-up %.0f  cluster-test rounds %.0f  phase B (drains) %.0f  log+reduction %.0f  -> cluster walk / phase A %.0f" % (
+                (p[:, 14] / sw).mean(), (p[:, 12] / sw).mean(), (p[:, 13] / sw).mean(), (p[:, 15] / sw).mean(), ((p[:, 0] - p[:, 12] - p[:, 13] - p[:, 14] - p[:, 15]) / sw).mean()))
         print("  sweeps per hypothesis: percentiles 50/75/90/95/99/100 = %s" % np.percentile(sw, [50, 75, 90, 95, 99, 100]).round(0).tolist())
-        q = prof.cpu().numpy().reshape(-1, 8)[:, 7]
+        q = prof.cpu().numpy().reshape(-1, PW)[:, 7]
         print("  line search: extra trials %.1f / hyp, of which accepted %.1f, re-sweeps %.1f (iterations %.1f, sweeps %.1f)" % (
             (q & 0xfffff).mean(), ((q >> 20) & 0xfffff).mean(), (q >> 40).mean(), iters.float().mean().item(), sw.mean()))
         X = np.stack([iters.cpu().numpy().reshape(-1).astype(float), (q & 0xfffff).astype(float), np.ones(sw.size)], axis=1)

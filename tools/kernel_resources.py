@@ -15,7 +15,7 @@ def main():
     filt = sys.argv[2] if len(sys.argv) > 2 else ""
     base = src.rsplit("/", 1)[-1]
     slp = [] if base in B.SLP_ON else ["-fno-slp-vectorize"]
-    cmd = [B.HIPCC] + B.FLAGS + slp + ["-x", "hip", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+    cmd = [B.HIPCC] + B.FLAGS + slp + B.PER_FILE_FLAGS.get(base, []) + ["-x", "hip", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
     err = subprocess.run(cmd, stderr=subprocess.PIPE, text=True).stderr
     cur = None
     rows = []

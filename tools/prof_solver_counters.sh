@@ -1,0 +1,37 @@
+#!/bin/bash
+# Hardware counters of the pose-solver kernel (GPU box; separate --pmc passes, kernel-trace only):  tools/prof_solver_counters.sh r03
+set -u
+TAG=${1:-r03}
+ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 -L 2>/dev/null | grep -oE "\b(TCP|TCC|TA|TD|SQ|SQC|GRBM)_[A-Za-z0-9_]+" | sort -u > $OUT/${TAG}_counter_names.txt
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
+           "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" \
+           "TCC_HIT_sum TCC_MISS_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1)); rm -rf /tmp/sc$i
+  timeout 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/sc$i -- python $ROOT/tools/bench_solver.py > /tmp/sc$i.log 2>&1
+  f=$(find /tmp/sc$i -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && cp $f /tmp/sc_pass$i.csv || { echo "pass $i ($set) failed"; tail -3 /tmp/sc$i.log; }
+done
+python - $OUT/${TAG}_solver_counters.json <<'PY'
+import csv, glob, json, sys, collections
+agg = collections.defaultdict(lambda: [0, 0.0])
+dur = []
+for f in sorted(glob.glob("/tmp/sc_pass*.csv")):
+    rows = list(csv.DictReader(open(f)))
+    # bench_solver: launches 1-6 run with solver_nocull = 1, launches 7-12 with the cluster test (then one more per PROF/tier option)
+    solves = [r for r in rows if "solve_kernel" in r.get("Kernel_Name", "")]
+    ids = sorted({int(r["Dispatch_Id"]) for r in solves})
+    keep = set(ids[6:12])
+    for r in solves:
+        if int(r["Dispatch_Id"]) in keep:
+            a = agg[r["Counter_Name"]]
+            a[0] += 1; a[1] += float(r["Counter_Value"])
+out = {k: v[1] / v[0] for k, v in agg.items()}
+out["_note"] = "per launch of solve_kernel<4,float,3,4,false> with the cluster test (bench_solver.py: 32 frames x 60 hypotheses x 20480 points), mean of 6 launches; SQ_* cycle counters are quad-cycles summed over the device; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them (FETCH_SIZE x2 on gfx950 for wide streaming reads, MI355X_MICROARCH.md)"
+json.dump(out, open(sys.argv[1], "w"), indent=1, sort_keys=True)
+print(json.dumps(out, indent=1, sort_keys=True))
+PY
