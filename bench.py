@@ -229,117 +229,69 @@ def main():
     # flips; the network forward + argmax still run in full inside the timed step and their output is kept.
     solver_labels = torch.from_numpy(batch["labels"]).to(dev)
 
-    # S HIP streams, round-robin: whole steps (classifier -> pose solve of one batch) are independent, so several are
-    # kept in flight; every step is still one full batch through the whole path on its own stream, and all K steps
-    # complete inside the timed region.  Each stream owns a slot of input buffers for the H2D-inclusive pass.
+    # The stream / graph executor is the product's (deepi2p_amd/pipeline.py): S HIP streams, one slot of input buffers per stream, a
+    # whole step (H2D copies -> classifier -> argmax -> initial guess -> R-restart solve -> argmin) captured once per slot as ONE
+    # hipGraph and replayed; every step is still one full batch through the whole path on its own stream, and all K steps complete
+    # inside the timed region.  This file only feeds it, times it and prices the kernels.
+    from deepi2p_amd.pipeline import RegistrationExecutor
     n_streams = max(1, args.streams if args.streams is not None else (3 if hyp else 8))
-    streams = [torch.cuda.Stream() for _ in range(n_streams)]
-    resident = {k: getattr(mm, k) for k in names}
-    slots = [resident] + [{k: torch.empty_like(v) for k, v in resident.items()} for _ in range(n_streams - 1)]
-    step_no = [0]
     coll_events = []
+    step_fn = post_fn = None
+    if hyp:
+        # hypothesis fan-out (BASELINE configs[4]): rank r solves restarts [lo, hi) of every frame -- that part is the captured graph --
+        # then ONE all_gather of (cost, params) and the identical argmin on every rank, launched eagerly behind the graph
+        lo, hi = shard_range(R, rank, world)
 
-    def solve(pc, labels):
-        if not hyp:
-            return pipe(pc, labels, K64, restarts)
-        # hypothesis fan-out: rank r solves restarts [lo, hi) of every frame; one all_gather + identical argmin
-        pts64 = torch.empty((B, 3, N), dtype=torch.float64, device=dev)
-        ops.call("di2p_f32_to_f64", ops.ptr(pc), ops.ptr(pts64), B * 3 * N, ops.stream())
-        yaw0, lab_front, has_inside = ops.initial_guess(pts64, labels)
-        iters_box = {}
+        def step_fn(slot, d):
+            pred = ops.argmax_channels(mm.detector(d["pc"], d["intensity"], d["sn"], d["node_a"], d["node_b"], d["img"]))
+            pts64 = torch.empty((B, 3, N), dtype=torch.float64, device=dev)
+            ops.call("di2p_f32_to_f64", ops.ptr(d["pc"]), ops.ptr(pts64), B * 3 * N, ops.stream())
+            yaw0, lab_front, has_inside = ops.initial_guess(pts64, solver_labels)
+            p, c, it = ops.solve_batched(d["pc"], lab_front, K64, restarts[0][:, lo:hi].contiguous(), restarts[1][:, lo:hi].contiguous(),
+                                         H, W, pipe.lb, pipe.ub, pipe.max_iter, True, yaw0=yaw0)
+            return dict(pred=pred, yaw0=yaw0, labels_front=lab_front, has_inside=has_inside, params_local=p, cost_local=c, iters=it)
 
-        def solve_fn(iy, iT):
-            p, c, it = ops.solve_batched(pc, lab_front, K64, iy, iT, H, W, pipe.lb, pipe.ub, pipe.max_iter, True, yaw0=yaw0)
-            iters_box["iters"] = it
-            return p, c
-        ev = None
-        if coll_events is not None and world > 1 and backend == "nccl":
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        best, bp, bc, allc = solve_hypotheses_sharded(solve_fn, restarts[0], restarts[1], gather_events=ev)
-        if ev is not None:
-            coll_events.append(ev)
-        _, P, _ = ops.select_best(bp.view(B, 1, -1).contiguous(), bc.view(B, 1).contiguous(), True, has_inside=has_inside)
-        return dict(P=P, cost=bc, best=best.int(), yaw0=yaw0, costs=allc, iters=iters_box["iters"], labels_front=lab_front)
+        def post_fn(slot, o):
+            ev = None
+            if coll_events is not None and world > 1 and backend == "nccl":
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            best, bp, bc, allc = solve_hypotheses_sharded(lambda iy, iT: (o["params_local"], o["cost_local"]), restarts[0], restarts[1],
+                                                          gather_events=ev)
+            if ev is not None:
+                coll_events.append(ev)
+            _, P, _ = ops.select_best(bp.view(B, 1, -1).contiguous(), bc.view(B, 1).contiguous(), True, has_inside=o["has_inside"])
+            return dict(o, P=P, cost=bc, best=best.int(), costs=allc)
+    ex = RegistrationExecutor(mm, pipe, K64, host, n_streams=n_streams, use_graph=not args.no_graph, restarts=restarts,
+                              labels_override=solver_labels, step_fn=step_fn, post_fn=post_fn)
 
-    def step(with_h2d=False, serial=False):
-        i = step_no[0] % n_streams
-        step_no[0] += 1
-        st = torch.cuda.current_stream() if serial else streams[i]
-        slot = slots[i] if with_h2d else resident
-        with torch.cuda.stream(st):
-            if with_h2d:        # a1: MMClassifer.set_input's copies (50 MB per 32-frame batch) from pinned host memory
-                for k in names:
-                    slot[k].copy_(host[k], non_blocking=True)
-            pred = ops.argmax_channels(mm.detector(slot["pc"], slot["intensity"], slot["sn"], slot["node_a"], slot["node_b"], slot["img"]))
-            o = solve(slot["pc"], solver_labels)    # same stream: the pose solve of a batch follows its classification
-        o["pred"] = pred
-        return o
-
-    def sync_all():
+    def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
-
-    graphs = {}
-
-    def graph_step(with_h2d):
-        """One step = one hipGraph replay: the ~150 launches of a step (network + argmax + solve) captured once per stream."""
-        i = step_no[0] % n_streams
-        key = (i, with_h2d)
-        if key not in graphs:
-            step_no[0] = i
-            step(with_h2d)                              # eager once on this stream: lazily created constants, allocator warm-up
-            streams[i].synchronize()
-            g = torch.cuda.CUDAGraph()
-            step_no[0] = i
-            with torch.cuda.graph(g, stream=streams[i]):
-                # inside capture torch.cuda.stream(streams[i]) is the capturing stream; step() launches on it
-                out_g = step(with_h2d)
-            graphs[key] = (g, out_g)
-            step_no[0] = i
-        g, out_g = graphs[key]
-        step_no[0] += 1
-        with torch.cuda.stream(streams[i]):
-            g.replay()
-        return out_g
-
-    # frames mode: a step is replayed as one hipGraph per stream (the ~150 launches are captured once); the hyp mode keeps
-    # eager launches (its all_gather is issued by torch.distributed).  A failed capture falls back to eager launches.
-    use_graph = not args.no_graph and not hyp
-    if use_graph:
-        try:
-            for i in range(n_streams):
-                step_no[0] = i
-                graph_step(False)
-            torch.cuda.synchronize()
-        except Exception as exc:          # noqa: BLE001 -- any capture problem: run eagerly, say so in the line
-            print("hipGraph capture failed (%s); running eagerly" % exc, file=sys.stderr)
-            use_graph = False
-            graphs.clear()
-        step_no[0] = 0
-    run_step = graph_step if use_graph else step
 
     def timed_loop(with_h2d):
-        for _ in range(n_streams if use_graph else 0):      # set-up, not warm-up: first replay of every stream's graph (the H2D variants
-            run_step(with_h2d)                              # are captured here), so that the W warm-up steps below are exactly W
-        for _ in range(args.warmup):
-            run_step(with_h2d)
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            o = run_step(with_h2d)
-        sync_all()
-        dt = time.perf_counter() - t0
+        dt, o, lat = ex.throughput(args.steps, args.warmup, with_h2d, barrier=barrier)
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        return dt, o
+        return dt, o, lat
 
-    dt, out = timed_loop(False)
-    dt_h2d = None
+    dt, out, lat = timed_loop(False)
+    dt_h2d = lat_h2d = None
     if not args.no_h2d_pass:
-        dt_h2d, _ = timed_loop(True)
+        dt_h2d, _, lat_h2d = timed_loop(True)
+    use_graph = ex.use_graph
+    if ex.graph_error:
+        print("hipGraph capture failed (%s); ran eagerly" % ex.graph_error, file=sys.stderr)
+    # per-batch latency with ONE step in flight (the other end of the throughput / latency trade: `value` keeps n_streams in flight)
+    lat1 = None
+    if not hyp and n_streams > 1:
+        ex.synchronize()
+        lat1 = []
+        for _ in range(3):
+            tk = ex.submit(None, with_h2d=False)
+            ex.result(tk)
+            lat1.append(ex.latency_ms(tk))
 
     # per-kernel-family durations: HIP events on the launch stream, in a SERIAL pass right after the timed region
     # (with several batches in flight, events inside the timed region would measure contention, not the kernels)
@@ -350,7 +302,7 @@ def main():
     _lib.WORK = {}
     coll_events = None
     for _ in range(prof_steps):
-        out = step(serial=True)
+        out = ex.step_eager(0, False)
     torch.cuda.synchronize()
     timed, work = _lib.TIMED, _lib.WORK
     _lib.TIMED = _lib.WORK = None
@@ -468,6 +420,11 @@ def main():
                        "weights_broadcast_bytes": bcast_bytes},
             "value_with_h2d": (frames / dt_h2d) if dt_h2d else None,
             "ms_per_step_with_h2d": (dt_h2d / args.steps * 1e3) if dt_h2d else None,
+            "latency_ms_per_batch": {"streams_%d" % n_streams: (sum(lat) / len(lat)) if lat else None,
+                                     "streams_%d_with_h2d" % n_streams: (sum(lat_h2d) / len(lat_h2d)) if lat_h2d else None,
+                                     "one_step_in_flight": (sum(lat1) / len(lat1)) if lat1 else None,
+                                     "note": "device time of one batch, first launch to last: with all streams busy (what `value` is measured "
+                                             "under) and with a single step in flight"},
             "roofline": roofline, "kernels": roofs, "cpu_baseline": cpu_baseline, "collective": collective,
             "pose_check": pose_check(out, batch),
         }
@@ -590,32 +547,102 @@ def pose_check(out, batch):
 
 
 def run_cpu_baseline(batch, sd, opt, H, W, R):
-    """The oracle ("port" of the reference's CPU path) timed on this box's host cores on a bounded sample."""
+    """The oracle ("port" of the reference's CPU path) timed on this box's host cores on a BOUNDED sample of the same workload, after
+    the protocol of BASELINE.md section 3: network 3 warm-up + 10 timed iterations, solver one thread per restart across the host
+    cores on the seeded hypothesis list -- in THROUGHPUT mode (several frames' restarts in flight together, so that all cores have
+    work: one frame's 60 restarts can occupy at most 60 threads) -- plus a single-thread figure of both parts."""
+    import threading
     import numpy as np
     import torch
     from oracle import frustum_lm as flm
     from oracle import network_torch as nt
+    names = ("pc", "intensity", "sn", "node_a", "node_b", "img")
     cores = os.cpu_count() or 1
-    net_threads = min(cores, 32)      # torch CPU ops stop scaling (and regress) far below the box's 256 threads
-    torch.set_num_threads(net_threads)
+    lb, ub = [-5, -0.1, -10], [5, 0.1, 10]
+
+    def net_time(nb, threads, warm, timed):
+        torch.set_num_threads(threads)
+        t = [torch.from_numpy(batch[k][:nb]) for k in names]
+        with torch.no_grad():
+            for _ in range(warm):
+                nt.keypoint_detector(sd, opt, *t)
+            t0 = time.perf_counter()
+            for _ in range(timed):
+                nt.keypoint_detector(sd, opt, *t)
+        return (time.perf_counter() - t0) / (timed * nb)
+
+    def restart_list(i, n):
+        pc = batch["pc"][i].astype(np.float64)
+        _, y0, pcf, labf = flm.get_initial_guess(pc, batch["labels"][i])          # same synthetic solver labels as the GPU leg
+        ys, Ts = flm.draw_restarts(np.random.default_rng(i), n, y0, 10 * math.pi / 180, 10)
+        return pcf, labf, ys, Ts
+
+    # network, all cores, two ways -- the better one counts: (a) one batch-2 forward on 32 intra-op threads (torch CPU ops stop scaling,
+    # and regress, far below the box's 256 threads), 3 warm-up + 10 timed; (b) throughput mode: `nt_conc` single-thread forwards of one
+    # frame each in flight together (the ops release the GIL)
+    net_threads = min(cores, 32)
     nb = 2
-    t = {k: torch.from_numpy(batch[k][:nb]) for k in ("pc", "intensity", "sn", "node_a", "node_b", "img")}
-    with torch.no_grad():
-        nt.keypoint_detector(sd, opt, *[t[k][:1] for k in ("pc", "intensity", "sn", "node_a", "node_b", "img")])   # warm-up
+    t_net_a = net_time(nb, net_threads, 3, 10)
+    nt_conc = min(cores, 32)
+    torch.set_num_threads(1)
+    frames1 = [[torch.from_numpy(batch[k][i % batch["pc"].shape[0]:i % batch["pc"].shape[0] + 1]) for k in names] for i in range(nt_conc)]
+
+    def fwd(i):
+        with torch.no_grad():
+            nt.keypoint_detector(sd, opt, *frames1[i])
+
+    def net_round():
+        th = [threading.Thread(target=fwd, args=(i,)) for i in range(nt_conc)]
         t0 = time.perf_counter()
-        nt.keypoint_detector(sd, opt, t["pc"], t["intensity"], t["sn"], t["node_a"], t["node_b"], t["img"])
-        t_net = (time.perf_counter() - t0) / nb
-    pc = batch["pc"][0].astype(np.float64)
-    lab = batch["labels"][0]          # same synthetic solver labels as the GPU leg
-    _, y0, pcf, labf = flm.get_initial_guess(pc, lab)
-    rng = np.random.default_rng(0)
-    ys, Ts = flm.draw_restarts(rng, R, y0, 10 * math.pi / 180, 10)
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        return time.perf_counter() - t0
+    net_round()
+    t_net_b = sum(net_round() for _ in range(3)) / (3 * nt_conc)
+    t_net = min(t_net_a, t_net_b)
+    # solver: one thread per restart across the host cores, two ways -- the better one counts: one frame at a time (R restarts on R
+    # threads), and throughput mode with `conc` frames' restarts in flight together
+    def solve_frames(conc, per, rounds):
+        jobs = [restart_list(i, R) for i in range(conc)]
+        its = [None] * conc
+
+        def one(i):
+            pcf, labf, ys, Ts = jobs[i]
+            its[i] = flm.solve_restarts(pcf, labf, batch["K"][i], ys, Ts, H, W, lb, ub, 500, True, nthreads=per)[2]
+
+        def rnd():
+            th = [threading.Thread(target=one, args=(i,)) for i in range(conc)]
+            t0 = time.perf_counter()
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            return time.perf_counter() - t0
+        rnd()                                                    # warm-up
+        return sum(rnd() for _ in range(rounds)) / (rounds * conc), float(np.mean([x.mean() for x in its]))
+    t_sol_1, mean_iters = solve_frames(1, min(cores, R), 3)
+    conc = max(1, min(4, cores // max(R, 1)))
+    t_sol_c = solve_frames(conc, max(1, cores // conc), 2)[0] if conc > 1 else t_sol_1
+    t_sol = min(t_sol_1, t_sol_c)
+    rounds, per = 3, min(cores, R)
+    # single-thread figures on a smaller sample: one frame through the network, two restarts of one frame (scaled to R)
+    t_net1 = net_time(1, 1, 0, 1)
+    pcf, labf, ys, Ts = restart_list(0, 2)
     t0 = time.perf_counter()
-    _, _, iters, _, _ = flm.solve_restarts(pcf, labf, batch["K"][0], ys, Ts, H, W, [-5, -0.1, -10], [5, 0.1, 10], 500, True, nthreads=cores)
-    t_sol = time.perf_counter() - t0
+    flm.solve_restarts(pcf, labf, batch["K"][0], ys, Ts, H, W, lb, ub, 500, True, nthreads=1)
+    t_sol1 = (time.perf_counter() - t0) / 2 * R
+    torch.set_num_threads(net_threads)
     return {"value": 1.0 / (t_net + t_sol), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "network: %d frames (torch fp32, %d threads, %.2f s/frame); solver: 1 frame x %d restarts over %d threads "
-                      "(%.2f s, mean %.1f LM iterations)" % (nb, net_threads, t_net, R, cores, t_sol, float(iters.mean()))}
+            "sample": "network: better of [batch %d on %d threads, 3 warm-up + 10 timed forwards: %.2f s/frame] and [%d single-thread forwards in "
+                      "flight, 1 warm-up + 3 timed rounds: %.2f s/frame]; solver (one thread per restart, %d restarts, 1 warm-up + timed rounds): better "
+                      "of [one frame at a time: %.2f s/frame] and [%d frames in flight: %.2f s/frame], mean %.1f LM iterations; "
+                      "value = 1 / (network + solver) seconds per frame" % (nb, net_threads, t_net_a, nt_conc, t_net_b, R, t_sol_1, conc, t_sol_c, mean_iters),
+            "network_s_per_frame": t_net, "solver_s_per_frame": t_sol,
+            "one_thread": {"value": 1.0 / (t_net1 + t_sol1), "unit": "frames/s", "cores": 1,
+                           "sample": "network: 1 frame, 1 forward on 1 thread (%.1f s); solver: 2 restarts of 1 frame on 1 thread, "
+                                     "scaled to %d restarts (%.1f s/frame)" % (t_net1, R, t_sol1)}}
 
 
 if __name__ == "__main__":

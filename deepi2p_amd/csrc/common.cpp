@@ -24,7 +24,7 @@ const OptDef kOpts[DI2P_OPT_COUNT] = {
     {"conv_nosplit", "DI2P_CONV_NOSPLIT", 0},        {"conv_split_blocks", "DI2P_CONV_SPLIT_BLOCKS", 32},
     {"conv_novec", "DI2P_CONV_NOVEC", 0},            {"conv_cfg", "DI2P_CONV_CFG", -1},
     {"conv_depth1", "DI2P_CONV_DEPTH1", 0},          {"index_max_rows", "DI2P_INDEX_MAX_ROWS", 1024},
-    {"pw_novec", "DI2P_PW_NOVEC", 0},                {"solver_cfg", "DI2P_SOLVER_CFG", 43},
+    {"pw_novec", "DI2P_PW_NOVEC", 0},                {"solver_cfg", "DI2P_SOLVER_CFG", 44},
     {"solver_nocull", "DI2P_SOLVER_NOCULL", 0},      {"solver_noprefilter", "DI2P_SOLVER_NOPREFILTER", 0},
     {"solver_tier_sweeps", "DI2P_SOLVER_TIER_SWEEPS", 0},
     {"wino_cob", "DI2P_WINO_COB", 0},               {"conv_nowinograd", "DI2P_CONV_NOWINOGRAD", 0},

@@ -40,7 +40,7 @@ enum Di2pOption {
     DI2P_OPT_CONV_DEPTH1,           // 1: depth-1 register prefetch in the vector convolution engine (default: depth 2; bit-identical)
     DI2P_OPT_INDEX_MAX_ROWS,        // index_max splits rows along N (3 launches) while B*C*S is below this many workgroups
     DI2P_OPT_PW_NOVEC,              // 1: scalar stager for the pointwise GEMMs
-    DI2P_OPT_SOLVER_CFG,            // <waves per hypothesis><min waves per SIMD>, default 43
+    DI2P_OPT_SOLVER_CFG,            // <waves per hypothesis><min waves per SIMD>, default 44
     DI2P_OPT_SOLVER_NOCULL,         // 1: classify every cluster per point (bit-identical by construction)
     DI2P_OPT_SOLVER_NOPREFILTER,    // 1: skip the fp32 pre-filter of the per-point classification (bit-identical by construction)
     DI2P_OPT_SOLVER_TIER_SWEEPS,    // sweeps after which a hypothesis is handed to the wide (16-wave) tail kernel; 0 = never

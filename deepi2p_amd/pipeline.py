@@ -1,0 +1,210 @@
+"""Stream / graph executor of the registration hot path: the replacement of the reference's evaluation driver
+(evaluation/visualize_and_save_data.py:69-97 -> evaluation/registration_lsq.py:291-345: per batch `set_input`, `inference_pass`,
+then per frame `get_initial_guess` + the 60-restart `solve_P_random_perturb` fan-out over worker processes).
+
+One STEP = one batch of frames through  H2D copies -> classifier -> argmax -> initial guess / front filter -> R-restart pose solve ->
+argmin.  Steps of different batches are independent, and a lone step cannot fill the chip (the pose solve is a chain of dependent
+sweeps with a heavy tail, several classifier kernels have fewer workgroups than CUs), so the executor keeps S steps in flight:
+
+  * S HIP streams, one SLOT per stream: device input tensors, pinned host staging buffers, device outputs;
+  * the ~150 launches of a step are captured ONCE per slot into a hipGraph (every entry point of the C-ABI library is
+    capture-safe: no allocation, no synchronisation) and replayed; the H2D copies are part of the graph, reading the slot's pinned
+    buffers, so `submit(host_batch)` is: memcpy into pinned memory + one graph launch;
+  * results stay on the device until `result()` is asked for them (one event per slot).
+
+`bench.py` is a thin caller of this class.  Environment: more than 3 streams need GPU_MAX_HW_QUEUES >= S (set before the HIP
+runtime starts; with the default of 4 hardware queues the streams share queues and 4 are slower than 3 -- DESIGN.md section 4).
+"""
+import time
+
+import torch
+
+from . import ops
+
+INPUT_NAMES = ("pc", "intensity", "sn", "node_a", "node_b", "img")
+
+
+class Slot:
+    """Per-stream state: device inputs, pinned staging, the captured graphs and their (static) outputs."""
+
+    def __init__(self, index, stream):
+        self.index, self.stream = index, stream
+        self.dev, self.host = {}, {}
+        self.graphs = {}          # with_h2d (bool) -> (hipGraph, outputs dict)
+        self.done = torch.cuda.Event(enable_timing=True)
+        self.start = torch.cuda.Event(enable_timing=True)
+        self.outputs = None
+        self.busy = False
+
+
+class RegistrationExecutor:
+    """mm: a deepi2p_amd.networks.MMClassifer(Coarse) with weights loaded; pipe: a deepi2p_amd.registration.RegistrationPipeline.
+
+    executor = RegistrationExecutor(mm, pipe, K, example_batch, n_streams=8)
+    ticket = executor.submit(host_batch)          # dict of CPU tensors pc/intensity/sn/node_a/node_b/img; returns at once
+    out = executor.result(ticket)                 # dict: pred i32[B,N], P f64[B,4,4], cost, best, iters, ... (device tensors of the slot)
+
+    labels_override: i32[B,N] device tensor fed to the solver INSTEAD of the network's argmax (the benchmark's synthetic labels,
+    SURVEY.md 8d: random-init weights predict nothing); default None = the network's own prediction, as the reference does."""
+
+    def __init__(self, mm, pipe, K, example_batch, n_streams=8, use_graph=True, restarts=None, labels_override=None, step_fn=None,
+                 post_fn=None):
+        self.mm, self.pipe = mm, pipe
+        self.device = mm.device
+        self.n_streams = max(1, int(n_streams))
+        self.use_graph = bool(use_graph)
+        self.labels_override = labels_override
+        self.K64 = K.to(self.device, torch.float64).contiguous()
+        B = int(example_batch["pc"].shape[0])
+        self.restarts = restarts if restarts is not None else pipe.draw(B, self.device)
+        self.step_fn = step_fn            # custom graph-capturable step: step_fn(slot, device_inputs) -> outputs dict
+        self.post_fn = post_fn            # launched EAGERLY on the slot's stream after the step (work that cannot be captured, e.g. a
+                                          # torch.distributed collective): post_fn(slot, outputs) -> outputs dict
+        self.graph_error = None
+        mm.detector.prepack()                 # derive the kernel operands now, on the current stream, before other streams use them
+        torch.cuda.synchronize(self.device)
+        self.slots = []
+        for i in range(self.n_streams):
+            s = Slot(i, torch.cuda.Stream(device=self.device))
+            for k in INPUT_NAMES:
+                t = example_batch[k]
+                s.host[k] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+                s.host[k].copy_(t)
+                s.dev[k] = t.to(self.device, non_blocking=False).contiguous()
+            self.slots.append(s)
+        self._next = 0
+        torch.cuda.synchronize(self.device)
+
+    # ------------------------------------------------------------------------------------------------------------ one step
+    def _step(self, slot, with_h2d):
+        """Enqueue one step on the CURRENT stream (the slot's stream, or the capturing stream)."""
+        if with_h2d:        # a1: MMClassifer.set_input's copies (multimodal_classifier.py:82-93), from the slot's pinned buffers
+            for k in INPUT_NAMES:
+                slot.dev[k].copy_(slot.host[k], non_blocking=True)
+        d = slot.dev
+        if self.step_fn is not None:
+            return self.step_fn(slot, d)
+        logits = self.mm.detector(d["pc"], d["intensity"], d["sn"], d["node_a"], d["node_b"], d["img"])
+        coarse = logits[0] if isinstance(logits, tuple) else logits
+        pred = ops.argmax_channels(coarse)                                   # inference_pass (:100-117): i32 [B,N]
+        labels = self.labels_override if self.labels_override is not None else pred
+        out = self.pipe(d["pc"], labels, self.K64, self.restarts)            # same stream: the pose solve follows its classification
+        out["pred"] = pred
+        if isinstance(logits, tuple):
+            out["fine_pred"] = ops.argmax_channels(logits[1])
+        return out
+
+    def _capture(self, slot, with_h2d):
+        with torch.cuda.stream(slot.stream):
+            self._step(slot, with_h2d)                                       # eager once: lazily created constants, allocator warm-up
+        slot.stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=slot.stream):
+            out = self._step(slot, with_h2d)
+        slot.graphs[with_h2d] = (g, out)
+
+    def warm_up(self, with_h2d=True):
+        """Capture (or run once) every slot's step so that the first timed submit pays nothing extra.  A failed capture switches the
+        executor to eager launches (and remembers why in `graph_error`)."""
+        for slot in self.slots:
+            if self.use_graph and with_h2d not in slot.graphs:
+                try:
+                    self._capture(slot, with_h2d)
+                except Exception as exc:          # noqa: BLE001 -- any capture problem: run eagerly, keep the reason
+                    self.graph_error = "%s: %s" % (type(exc).__name__, exc)
+                    self.use_graph = False
+                    for s in self.slots:
+                        s.graphs.clear()
+            if not self.use_graph:
+                with torch.cuda.stream(slot.stream):
+                    slot.outputs = self._step(slot, with_h2d)
+        torch.cuda.synchronize(self.device)
+
+    def step_eager(self, slot_index=0, with_h2d=False):
+        """One step launched eagerly on the CURRENT stream with slot `slot_index`'s buffers (profiling passes: events around every
+        C-ABI call need eager launches on one stream)."""
+        slot = self.slots[slot_index]
+        out = self._step(slot, with_h2d)
+        if self.post_fn is not None:
+            out = self.post_fn(slot, out)
+        return out
+
+    # ------------------------------------------------------------------------------------------------------------ submit / result
+    def submit(self, host_batch=None, with_h2d=None):
+        """Start one step on the next slot (round robin) and return its ticket.  host_batch: dict of CPU tensors (copied into the slot's
+        pinned buffers, then H2D inside the step); None: the slot's resident device inputs are used as they are (with_h2d=False) or
+        re-sent from its pinned buffers (with_h2d=True)."""
+        slot = self.slots[self._next]
+        self._next = (self._next + 1) % self.n_streams
+        if slot.busy and host_batch is not None:
+            slot.done.synchronize()               # new host data: the slot's previous H2D copies must have read the pinned buffers
+        if with_h2d is None:
+            with_h2d = host_batch is not None
+        if host_batch is not None:
+            for k in INPUT_NAMES:
+                slot.host[k].copy_(host_batch[k])
+        with torch.cuda.stream(slot.stream):
+            slot.start.record()
+            if self.use_graph:
+                if with_h2d not in slot.graphs:
+                    self._capture(slot, with_h2d)
+                g, out = slot.graphs[with_h2d]
+                g.replay()
+                slot.outputs = out
+            else:
+                slot.outputs = self._step(slot, with_h2d)
+            if self.post_fn is not None:
+                slot.outputs = self.post_fn(slot, slot.outputs)
+            slot.done.record()
+        slot.busy = True
+        return slot.index
+
+    def result(self, ticket, wait=True):
+        """Outputs of the step last submitted on slot `ticket` (device tensors owned by the slot: valid until it is reused)."""
+        slot = self.slots[ticket]
+        if wait:
+            slot.done.synchronize()
+            slot.busy = False
+        return slot.outputs
+
+    def latency_ms(self, ticket):
+        """Device time of the slot's last step, first launch to last (valid after result(ticket))."""
+        slot = self.slots[ticket]
+        return slot.start.elapsed_time(slot.done)
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+        for s in self.slots:
+            s.busy = False
+
+    # ------------------------------------------------------------------------------------------------------------ convenience
+    def run(self, batches, with_h2d=True):
+        """Push an iterable of host batches through the executor; yields (index, outputs) in submission order, each as soon as its
+        slot is needed again or the input is exhausted (outputs are cloned so they survive the slot's reuse)."""
+        pending = []
+        for i, b in enumerate(batches):
+            if len(pending) == self.n_streams:
+                j, t = pending.pop(0)
+                yield j, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.result(t).items()}
+            pending.append((i, self.submit(b, with_h2d=with_h2d)))
+        for j, t in pending:
+            yield j, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.result(t).items()}
+
+    def throughput(self, steps, warmup, with_h2d, barrier=None):
+        """Timed loop of the benchmark contract: `warmup` untimed steps, then exactly `steps` steps between two full synchronisations.
+        -> (seconds, outputs of the last step, per-step device latencies of the timed steps in ms)."""
+        self.warm_up(with_h2d)
+        for _ in range(warmup):
+            self.submit(None, with_h2d=with_h2d)
+        if barrier is not None:
+            barrier()
+        self.synchronize()
+        t0 = time.perf_counter()
+        tickets = [self.submit(None, with_h2d=with_h2d) for _ in range(steps)]
+        if barrier is not None:
+            barrier()
+        self.synchronize()
+        dt = time.perf_counter() - t0
+        last = self.slots[tickets[-1]].outputs
+        lat = [self.latency_ms(t) for t in sorted(set(tickets[-self.n_streams:]))]
+        return dt, last, lat
