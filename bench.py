@@ -133,6 +133,13 @@ def init_dist(args):
     backend = os.environ.get("DI2P_BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
     if os.environ.get("DI2P_BENCH_ONE_DEVICE"):
         local_rank = 0
+    elif not args.launch_selftest:
+        # one process per GPU: a rank without a device of its own would silently share (or fail much later inside RCCL)
+        ndev = torch.cuda.device_count()
+        if local_rank >= ndev:
+            raise SystemExit("bench.py: local rank %d of %d ranks, but this node exposes %d GPU(s) -- start at most one rank per GPU "
+                             "(or set DI2P_BENCH_ONE_DEVICE=1 with DI2P_BENCH_BACKEND=gloo to exercise the multi-rank path on one device)"
+                             % (local_rank, world, ndev))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -404,6 +411,11 @@ def main():
     collective = None
     if hyp and world > 1:
         collective = measure_collective(dist, backend, dev, B, R, world)
+    placement = [{"rank": rank, "device": local_rank, "device_count": torch.cuda.device_count(), "name": torch.cuda.get_device_name(local_rank)}]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, placement[0])
+        placement = gathered
     if rank == 0:
         line = {
             "metric": "frames/sec (img+pc infer + 60-restart GN pose) KITTI 20k-pt, 1/2/4/8 GPU",
@@ -417,7 +429,7 @@ def main():
                                     "+ %d-restart 2D GN/LM solver, max_iter 500" % (B, R)),
                        "mode": args.mode, "frames_per_gpu_per_step": B, "points": N, "image": [H, W], "restarts": R,
                        "parallelism": ("hyp%d" if hyp else "dp%d") % world, "streams": n_streams, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "hip_graph": bool(use_graph),
-                       "weights_broadcast_bytes": bcast_bytes},
+                       "weights_broadcast_bytes": bcast_bytes, "placement": placement},
             "value_with_h2d": (frames / dt_h2d) if dt_h2d else None,
             "ms_per_step_with_h2d": (dt_h2d / args.steps * 1e3) if dt_h2d else None,
             "latency_ms_per_batch": {"streams_%d" % n_streams: (sum(lat) / len(lat)) if lat else None,
@@ -453,7 +465,7 @@ def main_train(args):
     det.load_state_dict(synthetic.random_state_dict(opt, 0))
     det = det.to(dev)
     bcast_bytes = broadcast_weights(det, dist, backend) if world > 1 else 0
-    tr = ClassifierTrainer(det, opt, seed=rank)
+    tr = ClassifierTrainer(det, opt, seed=0)          # the trainer folds the rank into its dropout seed
     b = synthetic.make_batch(2000 + rank, B, N=N, H=H, W=W)
     t = [torch.from_numpy(np.ascontiguousarray(b[k])).to(dev) for k in ("pc", "intensity", "sn", "node_a", "node_b", "img")]
     K = torch.from_numpy(b["K"]).float().to(dev)

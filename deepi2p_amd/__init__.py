@@ -3,4 +3,4 @@
 Importing this package does not load the HIP library; the first operator call does, and raises
 ``DeepI2PHipError`` if it is missing.  There is no CPU fallback anywhere in this package.
 """
-__all__ = ["ops", "index_max", "ball_query", "FrustumRegistration", "networks", "registration", "synthetic"]
+__all__ = ["ops", "torch_ops", "index_max", "ball_query", "FrustumRegistration", "networks", "registration", "pipeline", "synthetic"]

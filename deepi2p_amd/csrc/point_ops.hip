@@ -26,26 +26,23 @@ __global__ __launch_bounds__(256) void knn_nodes_kernel(const float* __restrict_
     const int nc = min(n, Nq - 1);
     const float* q = query + (long long)b * 3 * Nq;
     const float qx = q[nc], qy = q[Nq + nc], qz = q[2 * Nq + nc];
-    float bd[KN];
-    int bi[KN];
+    // The k best candidates as SORTED 64-bit keys (bits of d^2 << 32 | node id): d^2 >= +0 is never negative, so the unsigned order of
+    // the keys is exactly the (d^2, id) order the insertion needs -- "closer, then lower id" is ONE compare, and inserting is a
+    // branch-free chain of selects (a NaN distance has the largest key and is never inserted, like `d < best` before).  The
+    // branchy insertion this replaces compiled to ~72 instructions per node, half of them exec-mask bookkeeping.
+    unsigned long long bk[KN];
 #pragma unroll
-    for (int j = 0; j < KN; ++j) { bd[j] = __builtin_inff(); bi[j] = 0x7fffffff; }
+    for (int j = 0; j < KN; ++j) bk[j] = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;       // (+inf, no node)
     auto consider = [&](float nx, float ny, float nz, int m) __attribute__((always_inline)) {
         const float dx = __fsub_rn(qx, nx), dy = __fsub_rn(qy, ny), dz = __fsub_rn(qz, nz);
-        float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-        int i = m;
-        if (d < bd[KN - 1] || (d == bd[KN - 1] && i < bi[KN - 1])) {
+        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)m;
+        bool lt[KN];
 #pragma unroll
-            for (int j = 0; j < KN; ++j) {
-                const bool lt = d < bd[j] || (d == bd[j] && i < bi[j]);
-                const float td = bd[j];
-                const int ti = bi[j];
-                bd[j] = lt ? d : td;
-                bi[j] = lt ? i : ti;
-                d = lt ? td : d;
-                i = lt ? ti : i;
-            }
-        }
+        for (int j = 0; j < KN; ++j) lt[j] = key < bk[j];
+#pragma unroll
+        for (int j = KN - 1; j >= 1; --j) bk[j] = lt[j - 1] ? bk[j - 1] : (lt[j] ? key : bk[j]);      // shift down / insert / keep
+        bk[0] = lt[0] ? key : bk[0];
     };
     int m = 0;
     for (; m + 4 <= M; m += 4) {          // uniform addresses: the compiler turns these into s_load_dwordx4
@@ -56,8 +53,10 @@ __global__ __launch_bounds__(256) void knn_nodes_kernel(const float* __restrict_
     }
     for (; m < M; ++m) consider(nb[m], nb[M + m], nb[2 * M + m], m);
     if (n >= Nq) return;
+    float bd[KN];
+    int bi[KN];
 #pragma unroll
-    for (int j = 0; j < KN; ++j) bd[j] = __fsqrt_rn(bd[j]);
+    for (int j = 0; j < KN; ++j) { bd[j] = __fsqrt_rn(__uint_as_float((unsigned)(bk[j] >> 32))); bi[j] = (int)(unsigned)(bk[j] & 0xffffffffu); }
     // equal rounded distances: lowest node id first (insertion sort on (d, id); the squared order is already almost that)
 #pragma unroll
     for (int a = 1; a < KN; ++a)

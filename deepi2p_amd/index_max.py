@@ -6,21 +6,29 @@
 Same names, argument order and error behaviour (RuntimeError for non-CUDA / non-contiguous input,
 index_max.cpp:119-121).  Both CUDA entry points run the same HIP kernel.  There is no CPU path here.
 """
-from . import ops
+import torch
+
+from . import ops, torch_ops  # noqa: F401  (torch_ops registers torch.ops.deepi2p_amd.*)
+
+
+def _check(data, index):
+    ops.require_cuda(data, index)          # the reference's CHECK_INPUT (index_max.cpp:119-121): RuntimeError, before the dispatcher
 
 
 def forward_cuda_shared_mem(data, index, K):
-    return ops.index_max(data, index, K)
+    _check(data, index)
+    return torch.ops.deepi2p_amd.index_max(data, index, int(K))
 
 
 def forward_cuda(data, index, K):
-    return ops.index_max(data, index, K)
+    _check(data, index)
+    return torch.ops.deepi2p_amd.index_max(data, index, int(K))
 
 
 def forward(data, index, K, mask=None):
-    """Fused variant: -> (max values with empty clusters zeroed f32[B,C,K], max_idx i32[B,C,K])."""
-    idx, val = ops.index_max(data, index, K, return_values=True, mask=mask)
-    return val, idx
+    """Fused variant (differentiable in `data`): -> (max values with empty clusters zeroed f32[B,C,K], max_idx i32[B,C,K])."""
+    _check(data, index)
+    return torch.ops.deepi2p_amd.index_max_values(data, index, mask, int(K))
 
 
 def forward_cpu(data, index, K):

@@ -50,6 +50,18 @@ class FlatAdam:
              float(self.betas[0]), float(self.betas[1]), float(self.eps), stream())
 
 
+def _allreduce_sum(t, group=None):
+    """In-place sum over the ranks of a (device) tensor; through host memory when the backend is gloo (CPU tests)."""
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def allreduce_gradients(flat_grads, group=None):
     """Average one flat gradient buffer over the ranks (a single all-reduce; no-op without a process group)."""
     import torch.distributed as dist
@@ -74,7 +86,10 @@ class ClassifierTrainer:
     synchronises with the host."""
 
     def __init__(self, detector, opt, lr=None, betas=(0.9, 0.999), group=None, seed=0):
-        self.detector, self.opt, self.group, self.seed, self.steps = detector, opt, group, int(seed), 0
+        import torch.distributed as dist
+        # every replica draws its OWN dropout masks (nn.DataParallel replicas do): the rank is folded into the Philox seed
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.detector, self.opt, self.group, self.seed, self.steps = detector, opt, group, int(seed) ^ (rank << 32), 0
         params = [p for _, p in detector.named_parameters()]
         if not params or not params[0].is_cuda:
             raise RuntimeError("the detector must live on a GPU")
@@ -127,8 +142,20 @@ class ClassifierTrainer:
         return scores, L
 
     def optimize(self, pc, intensity, sn, node_a, node_b, img, K, P_gt, dropouts="draw"):
+        import torch.distributed as dist
         self.flat_grad.zero_()
         scores, L = self.forward_pass(pc, intensity, sn, node_a, node_b, img, K, P_gt, True, dropouts)
+        if L["d_fine"] is not None and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            # The reference gathers the replicas' scores and takes ONE mean over the inside points of the whole batch
+            # (multimodal_classifier.py:189-191).  Here every rank normalised its fine-loss gradient by its OWN inside count and the
+            # gradients are averaged over the ranks afterwards: rescale by local_count * world / global_count so that the average is
+            # that single mean (device-side, no host synchronisation).  The coarse loss is a mean over B * N points on every rank,
+            # equal counts, so its average of means already is the global mean.
+            world = dist.get_world_size(self.group)
+            local = L["inside"].detach().to(torch.float64).reshape(1).clone()
+            total = _allreduce_sum(local.clone(), self.group)
+            L["d_fine"].mul_((local * world / total.clamp(min=1.0)).to(torch.float32))
+            L["inside_global"] = total[0]
         d = L["d_coarse"] if L["d_fine"] is None else torch.cat((L["d_coarse"], L["d_fine"]), dim=1)
         scores.backward(d)
         allreduce_gradients(self.flat_grad, self.group)
