@@ -369,10 +369,14 @@ def main():
             "unit": "GB/s", "ms_per_step": fam_ms["di2p_index_max_values"], "launches_per_step": launches["di2p_index_max_values"],
             "note": "in-pipeline durations (both calls: C=32 and C=64), not a cache-warm microbenchmark"},
         "knn_nodes_kernel": {
-            "bound": "hbm", "achieved": knn_bytes / (fam_ms["di2p_knn_nodes"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # VALU-bound: per query and node 26 wave-instructions (83 VALU + 19 SALU + 3 other per 4 nodes in the ISA of knn_nodes_kernel<3>:
+            # three subtractions, the squared distance, one 64-bit key compare per kept candidate and a branch-free chain of selects)
+            "bound": "valu", "achieved": 2 * B * N * 128 * 26.0 / (fam_ms["di2p_knn_nodes"] * 1e-3) / 1e12, "peak": 78.6, "unit": "T lane-instructions/s",
             "ms_per_step": fam_ms["di2p_knn_nodes"], "launches_per_step": launches["di2p_knn_nodes"],
-            "note": "SURVEY 8(d) prices the 3-NN assignment against HBM (read 12 N, write 12 N indices + 12 N weights per frame and call); "
-                    "the kernel is VALU-bound in fact: 128 distance evaluations + sorted insertion per point (~1.3 G lane-instructions per call)"},
+            "hbm_gbs_if_priced_as_survey_8d": knn_bytes / (fam_ms["di2p_knn_nodes"] * 1e-3) / 1e9,
+            "note": "3-NN assignment of every point against 128 nodes (two point-level calls + two node-level ones, whose work is negligible): "
+                    "achieved = 26 wave-instructions x 64 lanes per (query, node) pair / time, peak = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz; SURVEY 8(d) prices "
+                    "it against HBM (36 N bytes per frame and call), which it does not touch: `hbm_gbs_if_priced_as_survey_8d`"},
     }
     if sweeps is not None:
         roofs["solve_kernel"]["mean_sweeps"] = float(sweeps.float().mean())
@@ -383,7 +387,7 @@ def main():
     # HBM traffic per launch from the committed PMC passes of the same kernels on the same shapes (separate rocprofv3
     # --pmc FETCH_SIZE / WRITE_SIZE runs, corrected as MI355X_MICROARCH.md prescribes); None if absent
     pmc = {}
-    for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as fh:
                 pmc = json.load(fh)
@@ -394,12 +398,27 @@ def main():
         roofs["conv2d_kernel"]["traffic"] = pmc.get("conv2d_resnet34_B32_160x512", {}).get("hbm_bytes_per_call_corrected")
         roofs["index_max_kernel"]["traffic_C64"] = pmc.get("index_max_C64_B32_N20480_K128", {}).get("hbm_bytes_corrected")
         roofs["solve_kernel"]["traffic"] = pmc.get("solve_kernel_F32_R60_N20480", {}).get("hbm_bytes_corrected")
+    # executed fp64 flop of the solver: from the committed instruction-counter pass of the same kernel on the same workload shape
+    # (tools/prof_solver_counters.sh -> profiles/r03_solver_counters.json: 64 lanes x (2 FMA + ADD + MUL) wave-instructions per launch)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_solver_counters.json")) as fh:
+            sc = json.load(fh)
+        if B == 32 and R == 60 and N == 20480:
+            ex_flop = 64.0 * (2 * sc["SQ_INSTS_VALU_FMA_F64"] + sc["SQ_INSTS_VALU_ADD_F64"] + sc["SQ_INSTS_VALU_MUL_F64"])
+            roofs["solve_kernel"]["executed_fp64_flop_per_launch"] = ex_flop
+            roofs["solve_kernel"]["achieved_executed"] = ex_flop / (sol_ms * 1e-3) / 1e12
+            roofs["solve_kernel"]["frac_executed"] = roofs["solve_kernel"]["achieved_executed"] / FP64_VALU_PEAK_TFLOPS
+            roofs["solve_kernel"]["note"] += ("; achieved_executed = fp64 flop actually issued (counter pass on the same workload shape: the cluster test, the "
+                                              "fp32 pre-filter and the active-set compaction skip most of the 150 flop x points of the unit)")
+    except (OSError, ValueError, KeyError):
+        pass
     # the line's roofline object = the TIME-DOMINANT kernel family of the step
     dom_name = max((n for n in roofs if "frac" in roofs[n]), key=lambda n: roofs[n]["ms_per_step"])
     dom = roofs[dom_name]
     roofline = {"kernel": dom_name, "bound": "mfma" if dom["bound"] == "mfma" else ("hbm" if dom["bound"] == "hbm" else "valu-fp64"),
                 "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
-                "traffic": dom.get("traffic"), "ms_per_step": dom["ms_per_step"],
+                "traffic": dom.get("traffic"), "ms_per_step": dom["ms_per_step"], "achieved_executed": dom.get("achieved_executed"),
+                "frac_executed": dom.get("frac_executed"),
                 "algorithmic_per_launch": dom.get("algorithmic_flop_per_launch"),
                 "note": "time-dominant kernel family of the step; HIP events on the launch stream, serial pass of %d steps "
                         "directly after the timed region; every family's roofline is under `kernels`" % prof_steps}

@@ -1730,6 +1730,8 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
             case 42: DI2P_LAUNCH_SOLVE(4, 2, 4, pend1, tier, 0); break;
             case 43: DI2P_LAUNCH_SOLVE(4, 3, 4, pend1, tier, 0); break;
             case 23: DI2P_LAUNCH_SOLVE(4, 3, 2, pend1, tier, 0); break;
+            case 24: DI2P_LAUNCH_SOLVE(4, 4, 2, pend1, tier, 0); break;
+            case 14: DI2P_LAUNCH_SOLVE(4, 4, 1, pend1, tier, 0); break;
             case 83: DI2P_LAUNCH_SOLVE(4, 3, 8, pend1, tier, 0); break;
             case 84: DI2P_LAUNCH_SOLVE(4, 4, 8, pend1, tier, 0); break;
 #endif

@@ -11,7 +11,7 @@ g = torch.Generator().manual_seed(0)
 index = torch.randint(0, K, (B, N), generator=g, dtype=torch.int32).to(dev)
 for name, val in [kv.split("=") for kv in os.environ.get("OPTS", "").split(",") if kv]:
     _lib.set_option(name, int(val))
-for C in (32, 64):
+for C in [int(c) for c in os.environ.get("CS", "32,64").split(",")]:
     nbuf = max(2, int(1.2e9 // (B * C * N * 4)))
     datas = [torch.relu(torch.randn(B, C, N, generator=g)).to(dev) for _ in range(nbuf)]
     for i in range(3):

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Everything the round's profiles/ directory is built from, in one gpurun call (GPU box, repo root):  tools/final_round.sh r02
+# Everything the round's profiles/ directory is built from, in one gpurun call (GPU box, repo root):  tools/final_round.sh <tag>
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out
 mkdir -p $OUT
 timeout 600 python -m pytest tests -q -m gpu 2>&1 | tail -3 > $OUT/${TAG}_gputest_tail.txt
@@ -12,6 +12,9 @@ LAYERS=1 timeout 150 python tools/bench_conv.py > $OUT/${TAG}_conv_layers.txt 2>
 timeout 150 python tools/bench_winograd.py > $OUT/${TAG}_winograd_layers.txt 2>&1
 PROF=1 timeout 150 python tools/bench_solver.py > $OUT/${TAG}_solver_phases.txt 2>&1
 bash tools/profile_round.sh $TAG > $OUT/${TAG}_profile_round.log 2>&1
+bash tools/prof_solver_counters.sh $TAG > $OUT/${TAG}_solver_counters.log 2>&1
+timeout 200 python tools/call_times.py 15 > $OUT/${TAG}_call_times.txt 2>&1
+timeout 200 bash tools/sweep_streams2.sh > $OUT/${TAG}_sweep_streams.txt 2>&1
 export TMPDIR=/tmp; ROOT=$(pwd); cd /tmp; rm -rf /tmp/pt
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -- python $ROOT/bench.py --mode train --steps 4 --warmup 2 > /tmp/pt.log 2>&1
 f=$(find /tmp/pt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $ROOT/$OUT/${TAG}_train_kernel_stats.csv

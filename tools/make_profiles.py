@@ -1,9 +1,9 @@
 """Builds profiles/<tag>_* from the outputs of tools/final_round.sh in gpurun_out/ (run in the build container):
 copies the evidence files, derives <tag>_pmc_traffic.json from the counter passes and writes <tag>_README.md.
-    python tools/make_profiles.py r02"""
+    python tools/make_profiles.py r03"""
 import csv, json, os, shutil, sys
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out") + "/", os.path.join(ROOT, "profiles") + "/"
 KEEP_OLD = ("%s_sweep_solver_cfg.txt" % TAG, "%s_winograd_counters.txt" % TAG)
@@ -39,13 +39,27 @@ r1 = json.load(open(P + "r01_pmc_traffic.json"))
 sol_f = [r for r in rows(TAG + "_pmc_solver_FETCH_SIZE.csv") if "solve_kernel" in r["kernel"]][0]
 sol_w = [r for r in rows(TAG + "_pmc_solver_WRITE_SIZE.csv") if "solve_kernel" in r["kernel"]][0]
 fk, wk = float(sol_f["mean_per_launch"]), float(sol_w["mean_per_launch"])
+def index_max_entry(C, fallback):
+    try:
+        f = [r for r in rows("%s_pmc_index_max_C%d_FETCH_SIZE.csv" % (TAG, C)) if "index_max" in r["kernel"]][0]
+        w = [r for r in rows("%s_pmc_index_max_C%d_WRITE_SIZE.csv" % (TAG, C)) if "index_max" in r["kernel"]][0]
+    except (OSError, IndexError):
+        return fallback, True
+    fk, wk = float(f["mean_per_launch"]), float(w["mean_per_launch"])
+    alg = 32 * (4 * C * 20480 + 4 * 20480 + 2 * 4 * C * 128)
+    return {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "hbm_bytes_corrected": fk * 2048 + wk * 1024, "algorithmic_bytes": alg,
+            "launches": int(f["launches"]), "note": "cold inputs (tools/bench_index_max.py rotates > 1 GB of buffers); FETCH x2 (16-byte loads)"}, False
+
+
+im64, old64 = index_max_entry(64, r1["index_max_C64_B32_N20480_K128"])
+im32, old32 = index_max_entry(32, r1["index_max_C32_B32_N20480_K128"])
 out = {"units": r1["units"] + "; solver records and the 16-byte staged convolution kernels corrected x2; WRITE_SIZE raw",
        "commands": ["tools/profile_round.sh %s: rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python tools/bench_solver.py | tools/bench_conv.py (13 encoder passes)" % TAG],
-       "carried_over_from_r01": ["index_max_C64_B32_N20480_K128", "index_max_C32_B32_N20480_K128"],
-       "index_max_C64_B32_N20480_K128": r1["index_max_C64_B32_N20480_K128"], "index_max_C32_B32_N20480_K128": r1["index_max_C32_B32_N20480_K128"],
+       "carried_over_from_r01": [n for n, o in (("index_max_C64_B32_N20480_K128", old64), ("index_max_C32_B32_N20480_K128", old32)) if o],
+       "index_max_C64_B32_N20480_K128": im64, "index_max_C32_B32_N20480_K128": im32,
        "solve_kernel_F32_R60_N20480": {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "fetch_bytes_corrected": fk * 2048, "hbm_bytes_corrected": fk * 2048 + wk * 1024,
                                        "compulsory_bytes": 32 * 20480 * 16 + 32 * 320 * 32, "launches": int(sol_f["launches"]),
-                                       "note": "one launch = 32 frames x 60 hypotheses; a frame's records + boxes (338 KB) are read ~63 sweeps x 60 hypotheses times but stay cache resident; WRITE_SIZE ~= the kernel's private segment written back once"},
+                                       "note": "one launch = 32 frames x 60 hypotheses; a frame's records + boxes (338 KB) are read ~64 sweeps x 60 hypotheses times but stay cache resident; the kernel has no private segment since round 3 (round 2: 48.7 MiB of spill write-back per launch)"},
        "conv2d_resnet34_B32_160x512": {"FETCH_SIZE_KiB_per_encoder_pass_raw": fr, "FETCH_SIZE_KiB_per_encoder_pass_corrected": fc, "WRITE_SIZE_KiB_per_encoder_pass_raw": wr,
                                        "kernel_launches_per_pass": launches, "conv_calls_per_pass": 36, "hbm_bytes_per_call_corrected": (fc + wr) * 1024 / 36,
                                        "hbm_bytes_per_call_raw": (fr + wr) * 1024 / 36, "per_kernel": per_kernel,
@@ -77,16 +91,27 @@ def avg(sub):
 gt = open(P + TAG + "_gputest_tail.txt").read().strip().splitlines()[-1]
 wl = open(P + TAG + "_winograd_layers.txt").read().strip().splitlines()
 cvp = pm["conv2d_resnet34_B32_160x512"]; sp = pm["solve_kernel_F32_R60_N20480"]
-txt = f"""# Round-2 profiles (1x MI355X, ROCm 7.2)
+RN = TAG.lstrip("r").lstrip("0") or "0"
+sc = json.load(open(P + TAG + "_solver_counters.json")) if os.path.exists(P + TAG + "_solver_counters.json") else None
+sc_txt = ""
+if sc:
+    flop = 64.0 * (2 * sc["SQ_INSTS_VALU_FMA_F64"] + sc["SQ_INSTS_VALU_ADD_F64"] + sc["SQ_INSTS_VALU_MUL_F64"])
+    sc_txt = ("* `%s_solver_counters.json` -- `tools/prof_solver_counters.sh`: SQ / TCP / TCC counters of `solve_kernel` per launch (separate --pmc passes): "
+              "%.2e VALU, %.2e SALU, %.2e LDS, %.2e VMEM wave-instructions; fp64 FMA / MUL / ADD %.2e / %.2e / %.2e = %.2e fp64 flop executed per launch; "
+              "wave cycles: %.0f %% waiting (s_waitcnt / barrier), %.0f %% issue stalls, %.0f %% issuing; L2 hit rate %.3f; FETCH %.1f MiB raw, WRITE %.1f MiB.\n"
+              % (TAG, sc["SQ_INSTS_VALU"], sc["SQ_INSTS_SALU"], sc["SQ_INSTS_LDS"], sc["SQ_INSTS_VMEM_RD"], sc["SQ_INSTS_VALU_FMA_F64"], sc["SQ_INSTS_VALU_MUL_F64"],
+                 sc["SQ_INSTS_VALU_ADD_F64"], flop, 100 * sc["SQ_WAIT_ANY"] / sc["SQ_WAVE_CYCLES"], 100 * sc["SQ_WAIT_INST_ANY"] / sc["SQ_WAVE_CYCLES"],
+                 100 * sc["SQ_ACTIVE_INST_ANY"] / sc["SQ_WAVE_CYCLES"], sc["TCC_HIT_sum"] / (sc["TCC_HIT_sum"] + sc["TCC_MISS_sum"]), sc["FETCH_SIZE"] / 1024, sc["WRITE_SIZE"] / 1024))
+txt = f"""# Round-{RN} profiles (1x MI355X, ROCm 7.2)
 
 Everything here was produced by ONE gpurun call of `tools/final_round.sh {TAG}` (GPU tests, `bench.py`, `bench.py --mode train`, the
 micro-benchmarks, `tools/profile_round.sh {TAG}`) at the end of the round and turned into this directory by `tools/make_profiles.py`;
-`{TAG}_sweep_solver_cfg.txt` and `{TAG}_winograd_counters.txt` come from earlier calls of the round.
+files listed in KEEP_OLD (if present) come from earlier calls of the round.
 
 * `{TAG}_gputest_tail.txt` -- `python -m pytest tests -q -m gpu`: {gt}.
 * `{TAG}_bench_line.json` -- the JSON line of `python bench.py` ({line['steps']} steps, {line['warmup']} warm-up, {line['config']['streams']} streams on {line['config']['hw_queues']} hardware queues, one hipGraph per stream, CPU baseline
   leg included): **{line['value']:.0f} frames/s** resident ({line['ms_per_step']:.2f} ms per 32-frame step), {line['value_with_h2d']:.0f} frames/s with the
-  host->device copy of every batch inside the step (round 1: 2225).  Roofline object = time-dominant family = `solve_kernel`:
+  host->device copy of every batch inside the step; per-batch device latency {line['latency_ms_per_batch']}.  Roofline object = time-dominant family = `solve_kernel`:
   {k['solve_kernel']['ms_per_step']:.2f} ms per step, {k['solve_kernel']['achieved']:.1f} TFLOP/s by SURVEY 8(d)'s unit = {k['solve_kernel']['frac']:.2f} of the 78.6 TFLOP/s fp64 vector peak.
   Per family (`kernels`): convolution {cv['ms_per_step']:.2f} ms = {cv['achieved']:.1f} TFLOP/s algorithmic = **{cv['frac']:.2f}** of the fp32-MFMA peak (26 Winograd
   launches {cv['winograd']['ms_per_step']:.2f} ms, whose MFMA units issue {cv['winograd']['executed_mfma_tflops']:.0f} TFLOP/s; 9 implicit-GEMM launches {cv['winograd']['direct_kernel_ms_per_step']:.2f} ms; stem
@@ -97,13 +122,13 @@ micro-benchmarks, `tools/profile_round.sh {TAG}`) at the end of the round and tu
   contention.
 * `{TAG}_bench_kernel_stats_serial.csv` / `{TAG}_bench_line_serial.json` -- the same with `--streams 1` ({ser['value']:.0f} frames/s): durations without
   contention.  `solve_kernel` averages {avg('solve_kernel')/1e3:.2f} ms (rocprof) against {ser['kernels']['solve_kernel']['ms_per_step']:.2f} ms from the HIP events of the same run's JSON
-  line; `wino_conv_kernel<32, true, 4>` {avg('wino_conv_kernel<32, true, 4>'):.1f} us, `<32, true, 8>` {avg('wino_conv_kernel<32, true, 8>'):.1f} us, `wino_reg_kernel<4>` {avg('wino_reg_kernel<4>'):.1f} us per call.
+  line; `wino_conv_kernel<32, true, 4>` {avg('wino_conv_kernel<32, true, 4>'):.1f} us, `<32, true, 8>` {avg('wino_conv_kernel<32, true, 8>'):.1f} us, `wino_reg_kernel<4>` {avg('wino_reg_kernel<4>'):.1f} us per call; `knn_nodes_kernel<3>` {avg('knn_nodes_kernel<3>'):.1f} us, `index_max` {avg('index_max'):.1f} us.
 * `{TAG}_pmc_{{solver,conv}}_{{FETCH,WRITE}}_SIZE.csv`, `{TAG}_pmc_traffic.json` -- separate `--pmc` passes (kernel-trace only) on
   `tools/bench_solver.py` and `tools/bench_conv.py`.  solve_kernel: {sp['FETCH_SIZE_KiB']/1024:.1f} MiB fetched raw (x2 = {sp['fetch_bytes_corrected']/1e6:.1f} MB) per launch against 10.8 MB
-  of once-through records + boxes (the working set is cache resident), {sp['WRITE_SIZE_KiB']/1024:.1f} MiB written (scratch segment).  Convolution family of one
+  of once-through records + boxes (the working set is cache resident), {sp['WRITE_SIZE_KiB']/1024:.1f} MiB written (round 2: 48.7 MiB of spill write-back).  Convolution family of one
   encoder pass: FETCH {cvp['FETCH_SIZE_KiB_per_encoder_pass_raw']/1024:.0f} MiB raw / {cvp['FETCH_SIZE_KiB_per_encoder_pass_corrected']/1024:.0f} MiB corrected, WRITE {cvp['WRITE_SIZE_KiB_per_encoder_pass_raw']/1024:.0f} MiB = {cvp['hbm_bytes_per_call_corrected']/1e6:.0f} MB per convolution call against
   52 MB compulsory (the Winograd workgroups re-stream their slice of the transformed filters: under 1 TB/s over the family's time
-  -- not a limiter).  The index_max entries are carried over from round 1 (kernel unchanged).  (`{TAG}_bench_line.json` was written before
+  -- not a limiter).  index_max (fresh passes on cold inputs): C = 64 {pm['index_max_C64_B32_N20480_K128']['hbm_bytes_corrected']/1e6:.0f} MB against {pm['index_max_C64_B32_N20480_K128']['algorithmic_bytes']/1e6:.0f} MB algorithmic, C = 32 {pm['index_max_C32_B32_N20480_K128']['hbm_bytes_corrected']/1e6:.0f} / {pm['index_max_C32_B32_N20480_K128']['algorithmic_bytes']/1e6:.0f} MB.  (`{TAG}_bench_line.json` was written before
   this file was rebuilt: its `traffic` fields show the previous counter file's values.)
 * `{TAG}_conv_layers.txt`, `{TAG}_winograd_layers.txt` -- per-layer timings: the remaining implicit-GEMM layers (stride-2 3x3, 1x1
   downsample) and, for the four 3x3 stride-1 shapes at B = 32, direct vs the Winograd variants:
@@ -112,10 +137,12 @@ micro-benchmarks, `tools/profile_round.sh {TAG}`) at the end of the round and tu
 ```
 * `{TAG}_winograd_counters.txt` -- `tools/prof_winograd.sh`: SQ / TA / TCP / TCC counters of `wino_conv_kernel` on the stage-3 shape.
 * `{TAG}_solver_phases.txt` -- `PROF=1 python tools/bench_solver.py`: clock64() phase counters, cluster / line-search statistics, sweep-count
-  percentiles.  `{TAG}_sweep_solver_cfg.txt` -- the headline with 4 / 2 / 1 waves per hypothesis (4 x 3 per SIMD stays).
+  percentiles.
+{sc_txt}* `{TAG}_call_times.txt` -- `tools/call_times.py`: HIP events around every C-ABI call of one serial step, with the contraction shapes.
+* `{TAG}_sweep_streams.txt` -- the headline against streams / hardware queues.
 * `{TAG}_index_max_cold.txt` -- cache-cold index_max.
 * `{TAG}_train_line.json`, `{TAG}_train_kernel_stats.csv` -- `python bench.py --mode train` (reference training configuration: batch 8, 20480
-  points, 160x512, coarse+fine): **{tr['ms_per_step']:.1f} ms per step = {tr['value']:.0f} frames/s** (34.0 ms with every convolution on the generic kernels),
+  points, 160x512, coarse+fine): **{tr['ms_per_step']:.1f} ms per step = {tr['value']:.0f} frames/s**,
   and `rocprofv3 --kernel-trace --stats` of the same command.
 
 Top kernels of the bench command (default streams, durations include overlap):

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh r02
+#   tools/profile_round.sh <tag>
 # Writes gpurun_out/<tag>_*.csv (kernel-trace statistics of the bench command, default streams ("pipelined") and serial; separate --pmc passes
 # for the solver and index_max -- counters are never combined with other trace domains).  Copy what should be judged into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT/prof_$TAG
@@ -20,10 +20,10 @@ stats() {  # name, args...
 }
 stats pipelined --no-h2d-pass
 stats serial --streams 1 --no-h2d-pass
-pmc() {  # counter, tool
+pmc() {  # counter, tool, name [, env assignment]
   local c=$1 tool=$2 name=$3
   rm -rf $OUT/prof_$TAG/pmc_${name}_$c
-  timeout 180 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/prof_$TAG/pmc_${name}_$c -- python $ROOT/tools/$tool > $OUT/prof_$TAG/pmc_${name}_$c.log 2>&1
+  env ${4:-_X=1} timeout 180 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/prof_$TAG/pmc_${name}_$c -- python $ROOT/tools/$tool > $OUT/prof_$TAG/pmc_${name}_$c.log 2>&1
   f=$(find $OUT/prof_$TAG/pmc_${name}_$c -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python - "$f" $OUT/${TAG}_pmc_${name}_$c.csv <<'PY'
 import csv, sys, collections
@@ -41,4 +41,5 @@ PY
 }
 for c in FETCH_SIZE WRITE_SIZE; do pmc $c bench_solver.py solver; done
 for c in FETCH_SIZE WRITE_SIZE; do pmc $c bench_conv.py conv; done
+for c in FETCH_SIZE WRITE_SIZE; do pmc $c bench_index_max.py index_max_C64 CS=64; pmc $c bench_index_max.py index_max_C32 CS=32; done
 ls -la $OUT | grep ${TAG}_
