@@ -48,7 +48,7 @@ class RegistrationExecutor:
     SURVEY.md 8d: random-init weights predict nothing); default None = the network's own prediction, as the reference does."""
 
     def __init__(self, mm, pipe, K, example_batch, n_streams=8, use_graph=True, restarts=None, labels_override=None, step_fn=None,
-                 post_fn=None):
+                 post_fn=None, h2d_mode="graph"):
         self.mm, self.pipe = mm, pipe
         self.device = mm.device
         self.n_streams = max(1, int(n_streams))
@@ -61,11 +61,16 @@ class RegistrationExecutor:
         self.post_fn = post_fn            # launched EAGERLY on the slot's stream after the step (work that cannot be captured, e.g. a
                                           # torch.distributed collective): post_fn(slot, outputs) -> outputs dict
         self.graph_error = None
+        # where the host->device copies of a step run: "graph" = memcpy nodes of the step's graph (default); "eager" = hipMemcpyAsync on the
+        # slot's stream ahead of the replay; "copy_stream" = a second stream per slot + an event the step waits for
+        self.h2d_mode = h2d_mode
         mm.detector.prepack()                 # derive the kernel operands now, on the current stream, before other streams use them
         torch.cuda.synchronize(self.device)
         self.slots = []
         for i in range(self.n_streams):
             s = Slot(i, torch.cuda.Stream(device=self.device))
+            s.copy_stream = torch.cuda.Stream(device=self.device) if h2d_mode == "copy_stream" else None
+            s.copied = torch.cuda.Event()
             for k in INPUT_NAMES:
                 t = example_batch[k]
                 s.host[k] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
@@ -106,6 +111,7 @@ class RegistrationExecutor:
     def warm_up(self, with_h2d=True):
         """Capture (or run once) every slot's step so that the first timed submit pays nothing extra.  A failed capture switches the
         executor to eager launches (and remembers why in `graph_error`)."""
+        with_h2d = with_h2d and self.h2d_mode == "graph"
         for slot in self.slots:
             if self.use_graph and with_h2d not in slot.graphs:
                 try:
@@ -143,16 +149,29 @@ class RegistrationExecutor:
         if host_batch is not None:
             for k in INPUT_NAMES:
                 slot.host[k].copy_(host_batch[k])
+        in_step = with_h2d and self.h2d_mode == "graph"
+        if with_h2d and self.h2d_mode == "copy_stream":
+            with torch.cuda.stream(slot.copy_stream):
+                if slot.busy:
+                    slot.copy_stream.wait_event(slot.done)        # the previous step of this slot still reads the device inputs
+                for k in INPUT_NAMES:
+                    slot.dev[k].copy_(slot.host[k], non_blocking=True)
+                slot.copied.record()
         with torch.cuda.stream(slot.stream):
             slot.start.record()
+            if with_h2d and self.h2d_mode == "eager":
+                for k in INPUT_NAMES:
+                    slot.dev[k].copy_(slot.host[k], non_blocking=True)
+            elif with_h2d and self.h2d_mode == "copy_stream":
+                slot.stream.wait_event(slot.copied)
             if self.use_graph:
-                if with_h2d not in slot.graphs:
-                    self._capture(slot, with_h2d)
-                g, out = slot.graphs[with_h2d]
+                if in_step not in slot.graphs:
+                    self._capture(slot, in_step)
+                g, out = slot.graphs[in_step]
                 g.replay()
                 slot.outputs = out
             else:
-                slot.outputs = self._step(slot, with_h2d)
+                slot.outputs = self._step(slot, in_step)
             if self.post_fn is not None:
                 slot.outputs = self.post_fn(slot, slot.outputs)
             slot.done.record()

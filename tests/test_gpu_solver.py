@@ -74,7 +74,7 @@ def test_solver_matches_oracle_per_hypothesis(dev, is_2d, N, R):
     Po, co, it_o, term_o, par_o = flm.solve_restarts(pcf, labf, f["K"], ys, Ts, H, W, LB, UB, 500, is_2d, nthreads=8)
     Pg, cg, best, par_g, it_g = registration.solvePGivenK_batched(pcf, labf, f["K"], ys, Ts, H, W, LB, UB, 500, is_2d, return_all=True)
     ok = _agreement(par_o, par_g, is_2d)
-    assert ok.mean() >= 0.9, "only %.0f%% of hypotheses agree (iters oracle %s, hip %s)" % (100 * ok.mean(), it_o, it_g)
+    assert ok.mean() >= 0.95, "only %.0f%% of hypotheses agree (iters oracle %s, hip %s)" % (100 * ok.mean(), it_o, it_g)     # measured: all of them (tools/solver_oracle_agreement.py)
     np.testing.assert_allclose(cg[ok], co[ok], rtol=1e-6)
     assert abs(cg.min() - co.min()) <= 1e-6 * co.min()
     np.testing.assert_allclose(Pg[ok], Po[ok], atol=2e-3)
@@ -232,7 +232,7 @@ def test_solver_matches_oracle_other_cameras(dev, seed, is_2d, N, HW, flip):
     Po, co, it_o, term_o, par_o = flm.solve_restarts(pcf, labf, f["K"], ys, Ts, h, w, LB, UB, 500, is_2d, nthreads=8)
     Pg, cg, best, par_g, it_g = registration.solvePGivenK_batched(pcf, labf, f["K"], ys, Ts, h, w, LB, UB, 500, is_2d, return_all=True)
     ok = _agreement(par_o, par_g, is_2d)
-    assert ok.mean() >= 0.9, "only %.0f%% of hypotheses agree (iters oracle %s, hip %s)" % (100 * ok.mean(), it_o, it_g)
+    assert ok.mean() >= 0.95, "only %.0f%% of hypotheses agree (iters oracle %s, hip %s)" % (100 * ok.mean(), it_o, it_g)     # measured: all of them (tools/solver_oracle_agreement.py)
     np.testing.assert_allclose(cg[ok], co[ok], rtol=1e-6)
     assert abs(cg.min() - co.min()) <= 1e-6 * co.min()
     np.testing.assert_array_equal(it_g[ok], it_o[ok])            # same number of LM iterations where the iterates agree

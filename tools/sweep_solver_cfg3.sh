@@ -1,4 +1,4 @@
-for cfg in 44 24 14 43; do for s in 8 12; do
+for cfg in 42 44; do for s in 8 12 16; do
 DI2P_SOLVER_CFG=$cfg timeout 200 python bench.py --no-cpu-baseline --no-h2d-pass --steps 32 --warmup 6 --streams $s 2>/dev/null | python -c "
 import json,sys
 l=json.loads(sys.stdin.readline())
