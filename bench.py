@@ -5,7 +5,7 @@ One "step" = one batch of BASELINE.json configs[1]: 32 synthetic KITTI-shaped fr
 160x512 image), coarse frustum classification (image + point + fusion network, fp32) -> argmax labels ->
 initial guess -> 60-restart Gauss-Newton/LM pose solve (fp64) -> argmin.  Inputs are resident in HBM when
 the timed region starts (`value`); the same loop with the per-step H2D copy of the batch from pinned host
-memory inside the step is timed right after it and reported as `value_with_h2d` (SURVEY.md 8d's definition).
+memory inside the step (async copies on a second stream per slot) is timed right after it and reported as `value_with_h2d` (SURVEY.md 8d's definition).
 Weights are random-init closed-form (no checkpoints available).
 
 Multi-GPU: one process per GPU over RCCL.  `python bench.py --gpus N` launches the N ranks itself
@@ -269,7 +269,7 @@ def main():
             _, P, _ = ops.select_best(bp.view(B, 1, -1).contiguous(), bc.view(B, 1).contiguous(), True, has_inside=o["has_inside"])
             return dict(o, P=P, cost=bc, best=best.int(), costs=allc)
     ex = RegistrationExecutor(mm, pipe, K64, host, n_streams=n_streams, use_graph=not args.no_graph, restarts=restarts,
-                              labels_override=solver_labels, step_fn=step_fn, post_fn=post_fn, h2d_mode=os.environ.get("DI2P_H2D_MODE", "graph"))
+                              labels_override=solver_labels, step_fn=step_fn, post_fn=post_fn, h2d_mode=os.environ.get("DI2P_H2D_MODE", "copy_stream"))
 
     def barrier():
         if world > 1:

@@ -8,8 +8,9 @@ sweeps with a heavy tail, several classifier kernels have fewer workgroups than 
 
   * S HIP streams, one SLOT per stream: device input tensors, pinned host staging buffers, device outputs;
   * the ~150 launches of a step are captured ONCE per slot into a hipGraph (every entry point of the C-ABI library is
-    capture-safe: no allocation, no synchronisation) and replayed; the H2D copies are part of the graph, reading the slot's pinned
-    buffers, so `submit(host_batch)` is: memcpy into pinned memory + one graph launch;
+    capture-safe: no allocation, no synchronisation) and replayed; the H2D copies read the slot's pinned buffers on a second stream
+    per slot (SDMA engines; as memcpy nodes of the graph they would run as blit kernels on the CUs), so `submit(host_batch)` is:
+    memcpy into pinned memory + six async copies + one graph launch;
   * results stay on the device until `result()` is asked for them (one event per slot).
 
 `bench.py` is a thin caller of this class.  Environment: more than 3 streams need GPU_MAX_HW_QUEUES >= S (set before the HIP
@@ -48,7 +49,7 @@ class RegistrationExecutor:
     SURVEY.md 8d: random-init weights predict nothing); default None = the network's own prediction, as the reference does."""
 
     def __init__(self, mm, pipe, K, example_batch, n_streams=8, use_graph=True, restarts=None, labels_override=None, step_fn=None,
-                 post_fn=None, h2d_mode="graph"):
+                 post_fn=None, h2d_mode="copy_stream"):
         self.mm, self.pipe = mm, pipe
         self.device = mm.device
         self.n_streams = max(1, int(n_streams))
@@ -61,8 +62,10 @@ class RegistrationExecutor:
         self.post_fn = post_fn            # launched EAGERLY on the slot's stream after the step (work that cannot be captured, e.g. a
                                           # torch.distributed collective): post_fn(slot, outputs) -> outputs dict
         self.graph_error = None
-        # where the host->device copies of a step run: "graph" = memcpy nodes of the step's graph (default); "eager" = hipMemcpyAsync on the
-        # slot's stream ahead of the replay; "copy_stream" = a second stream per slot + an event the step waits for
+        # where the host->device copies of a step run: "copy_stream" (default) = hipMemcpyAsync on a second stream per slot + an event the step
+        # waits for (the copies go through the SDMA engines and overlap the slot's own previous step: 0.96-0.97 of the resident rate);
+        # "eager" = hipMemcpyAsync on the slot's stream ahead of the replay (0.95-0.96); "graph" = memcpy nodes of the step's graph, which
+        # the runtime executes as blit KERNELS on the CUs (0.91-0.95; tools/sweep_h2d_mode.sh, tools/probe_h2d.sh)
         self.h2d_mode = h2d_mode
         mm.detector.prepack()                 # derive the kernel operands now, on the current stream, before other streams use them
         torch.cuda.synchronize(self.device)

@@ -1,6 +1,6 @@
 """The product's stream / graph executor (deepi2p_amd/pipeline.py): a graph-replayed step is BIT-identical to eager launches and to the
 plain operator calls (MMClassifer.inference_pass-style argmax + RegistrationPipeline), with and without the H2D copies in the step,
-on every slot; new host data reaches the device through the captured copies."""
+on every slot; new host data reaches the device whichever way the copies are issued (second stream per slot, the slot's stream, graph nodes)."""
 import numpy as np
 import pytest
 import torch
@@ -36,14 +36,14 @@ def _reference(mm, pipe, K, restarts, hb, labels, dev):
     return out
 
 
-@pytest.mark.parametrize("override", [False, True])
-def test_graph_replay_equals_eager_and_operator_calls(dev, override):
+@pytest.mark.parametrize("override,h2d_mode", [(False, "copy_stream"), (True, "copy_stream"), (True, "eager"), (True, "graph")])
+def test_graph_replay_equals_eager_and_operator_calls(dev, override, h2d_mode):
     from deepi2p_amd.pipeline import RegistrationExecutor
     mm, pipe, K, restarts, batches, host = _setup(dev)
     labels = torch.from_numpy(batches[0]["labels"]).to(dev) if override else None     # the benchmark's synthetic labels / the network's own
     outs = {}
     for graph in (True, False):
-        ex = RegistrationExecutor(mm, pipe, K, host[0], n_streams=2, use_graph=graph, restarts=restarts, labels_override=labels)
+        ex = RegistrationExecutor(mm, pipe, K, host[0], n_streams=2, use_graph=graph, restarts=restarts, labels_override=labels, h2d_mode=h2d_mode)
         ex.warm_up(with_h2d=True)
         assert ex.use_graph == graph, ex.graph_error
         got = []
