@@ -209,16 +209,26 @@ __global__ __launch_bounds__(256) void rc_gemm_kernel(LA la, LB lb, int R, int r
     rc_gemm_tile<AV, BV>(lds, la, lb, r_begin, r_end, blockIdx.y * RC_BM, blockIdx.x * RC_BM, partial + (long long)blockIdx.z * rows * cols, rows, cols);
 }
 
-// out[g][e] = alpha * sum_{p < per_group} partial[g * per_group + p][e], summed in p order
+// out[g][e] = alpha * sum_{p < per_group} partial[g * per_group + p][e], in a fixed order
 __global__ __launch_bounds__(256) void rc_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int per_group, long long elems,
                                                         long long total, float alpha) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const long long g = i / elems, e = i - g * elems;
     const float* p = partial + g * per_group * elems + e;
-    float s = 0.0f;
-    for (int k = 0; k < per_group; ++k) s += p[(long long)k * elems];
-    out[i] = alpha * s;
+    // eight partial sums over p = k mod 8 (eight loads in flight instead of one dependent chain of up to ~160), combined as a fixed tree:
+    // deterministic, independent of launch geometry
+    float s[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    int k = 0;
+    for (; k + 8 <= per_group; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(long long)(k + u) * elems];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += v[u];
+    }
+    for (int u = 0; k < per_group; ++k, ++u) s[u] += p[(long long)k * elems];
+    out[i] = alpha * (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7])));
 }
 
 struct RcPlan { int rch, chunks; long long bytes; };
