@@ -1741,7 +1741,8 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
 #define DI2P_LAUNCH_SOLVE_P(NPV, MW, WP, PEND, BUDGET, RESUME)                                                                   \
     do {                                                                                                                         \
         ka.pending = PEND; ka.budget = BUDGET; ka.resume = RESUME;                                                               \
-        if (g_prof) hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP, true>), grid, dim3(WP * 64), 0, st, ka);                   \
+        /* the instrumented build runs at <= 3 waves per SIMD: at 128 registers its timers push it into scratch and distort the phases */ \
+        if (g_prof) hipLaunchKernelGGL((solve_kernel<NPV, PT, (MW > 3 ? 3 : MW), WP, true>), grid, dim3(WP * 64), 0, st, ka);    \
         else hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP, false>), grid, dim3(WP * 64), 0, st, ka);                         \
     } while (0)
 #define DI2P_LAUNCH_SOLVE(NPV, MW, WP, PEND, BUDGET, RESUME)                                                                     \

@@ -66,5 +66,5 @@ for name, lab_np in (("noisy-gt", np.stack([f["labels"] for f in frames])),):
         print("  two-tier launch, park after %d sweeps: %.2f ms (costs bit-identical to the single launch: %s; max rel diff %.2e)" % (
             tier, dtt * 1e3, same, float(((c2 - cost).abs() / cost.abs().clamp(min=1e-30)).max())))
     print("%s CFG=%s: %.2f ms  iters mean %.1f max %d  sweeps mean %.1f max %d  kept pts %.0f  -> %.1f us/sweep/hyp-wave" % (
-        name, os.environ.get("DI2P_SOLVER_CFG", "43"), dt * 1e3, iters.float().mean().item(), iters.max().item(),
+        name, os.environ.get("DI2P_SOLVER_CFG", "44"), dt * 1e3, iters.float().mean().item(), iters.max().item(),
         sweeps.float().mean().item(), sweeps.max().item(), kept, dt * 1e6 / max(sweeps.float().mean().item(), 1)))
