@@ -34,7 +34,6 @@ def _stale(out, deps):
 
 def build(force=False, verbose=True, variant=None, extra_flags=(), csrc=None):
     """variant: build into lib/variants/<name>/ with extra hipcc flags (A/B experiments, loaded through DI2P_LIB); csrc: other source tree"""
-    global LIBDIR, LIB, CSRC
     if variant:
         return _build_variant(variant, list(extra_flags), csrc)
     os.makedirs(LIBDIR, exist_ok=True)
