@@ -211,6 +211,32 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(const float* __restrict_
     const int egc = e_valid ? egt : total_tiles - 1;
     const int eb = egc / (TH * TW), erem = egc - eb * TH * TW, ety = erem / TW, etx = erem - ety * TW;
     const int oy = 2 * ety, ox = 2 * etx;
+    // every load of the epilogue (scale, shift, the residual's two rows for the thread's 4*MT channels) is issued ahead of the exchange
+    // passes: inside them they were two serialised memory latencies per pass.  The width is even (entry-point check), so a tile's two
+    // output columns always exist and are 8-byte aligned.
+    const bool row1 = oy + 1 < H;
+    const long long ch_stride = (long long)H * W;
+    const long long o_base = (((long long)eb * Cout + co_blk + e_ch) * H + oy) * W + ox;
+    float scv[4][MT], shv[4][MT];
+    float2 q0[4][MT], q1[4][MT];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int pp = 0; pp < MT; ++pp) {
+            const int co = co_blk + pp * 32 + 8 * q + e_ch;
+            scv[q][pp] = scale[co]; shv[q][pp] = shift[co];
+            q0[q][pp] = q1[q][pp] = make_float2(0.0f, 0.0f);
+        }
+    if (residual && e_valid) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int pp = 0; pp < MT; ++pp) {
+                const long long o = o_base + (pp * 32 + 8 * q) * ch_stride;
+                q0[q][pp] = *reinterpret_cast<const float2*>(residual + o);
+                q1[q][pp] = *reinterpret_cast<const float2*>(residual + o + (row1 ? W : 0));
+            }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -229,7 +255,6 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(const float* __restrict_
 #pragma unroll
         for (int pp = 0; pp < MT; ++pp) {
             const int chs = pp * 8 + e_ch;                                      // slot -> MFMA tile pp, row 8q + e_ch within it
-            const int co = co_blk + pp * 32 + 8 * q + e_ch;
             float m[16];
 #pragma unroll
             for (int xi = 0; xi < 16; ++xi) m[xi] = Ms[(xi * CH + chs) * WG_TILES + e_tile];
@@ -238,25 +263,14 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(const float* __restrict_
             for (int c = 0; c < 4; ++c) { s0[c] = m[c] + m[4 + c] + m[8 + c]; s1[c] = m[4 + c] - m[8 + c] - m[12 + c]; }
             float o00 = s0[0] + s0[1] + s0[2], o01 = s0[1] - s0[2] - s0[3];
             float o10 = s1[0] + s1[1] + s1[2], o11 = s1[1] - s1[2] - s1[3];
-            if (e_valid && co < Cout) {
-                const float sc = scale[co], sh = shift[co];
-                const long long o = (((long long)eb * Cout + co) * H + oy) * W + ox;
-                const bool row1 = oy + 1 < H, col1 = ox + 1 < W;
-                o00 = o00 * sc + sh; o01 = o01 * sc + sh; o10 = o10 * sc + sh; o11 = o11 * sc + sh;
-                if (residual) {
-                    o00 += residual[o];
-                    if (col1) o01 += residual[o + 1];
-                    if (row1) { o10 += residual[o + W]; if (col1) o11 += residual[o + W + 1]; }
-                }
+            if (e_valid) {
+                const float sc = scv[q][pp], sh = shv[q][pp];
+                const long long o = o_base + (pp * 32 + 8 * q) * ch_stride;
+                o00 = o00 * sc + sh + q0[q][pp].x; o01 = o01 * sc + sh + q0[q][pp].y;
+                o10 = o10 * sc + sh + q1[q][pp].x; o11 = o11 * sc + sh + q1[q][pp].y;
                 if (relu) { o00 = fmaxf(o00, 0.0f); o01 = fmaxf(o01, 0.0f); o10 = fmaxf(o10, 0.0f); o11 = fmaxf(o11, 0.0f); }
-                if (col1 && (W & 1) == 0) {
-                    *reinterpret_cast<float2*>(y + o) = make_float2(o00, o01);
-                    if (row1) *reinterpret_cast<float2*>(y + o + W) = make_float2(o10, o11);
-                } else {
-                    y[o] = o00;
-                    if (col1) y[o + 1] = o01;
-                    if (row1) { y[o + W] = o10; if (col1) y[o + W + 1] = o11; }
-                }
+                *reinterpret_cast<float2*>(y + o) = make_float2(o00, o01);
+                if (row1) *reinterpret_cast<float2*>(y + o + W) = make_float2(o10, o11);
             }
         }
         __syncthreads();
@@ -370,15 +384,36 @@ __global__ __launch_bounds__(NW * 64, 2) void wino_reg_kernel(const float* __res
         if (t + 1 < T) stage(buf ^ 1);
         __syncthreads();
     }
-    // ---- epilogue, all in registers: lane = tile l15, channels co_blk + 16h + 4*kq + r
-    if (!tvalid) return;
+    // ---- epilogue, all in registers: lane = tile l15, channels co_blk + 16h + 4*kq + r.  Every load of the epilogue (scale, shift, the
+    // residual's two rows for the lane's 8 channels) is issued BEFORE the first inverse transform: as loads inside the per-channel loop
+    // they were 16 serialised memory latencies per wave (~1/3 of a wave's lifetime at 64 input channels).
     const int oy = 2 * ty, ox = 2 * tx;
     const bool row1 = oy + 1 < H;
+    const long long o_base = (((long long)b * Cout + co_blk + 4 * kq) * H + oy) * W + ox, ch_stride = (long long)H * W;
+    float scv[8], shv[8];
+    float2 q0[8], q1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int co = co_blk + (i >> 2) * 16 + 4 * kq + (i & 3);
+        scv[i] = scale[co]; shv[i] = shift[co];
+    }
+    if (residual) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long long o = o_base + ((i >> 2) * 16 + (i & 3)) * ch_stride;
+            q0[i] = *reinterpret_cast<const float2*>(residual + o);
+            q1[i] = *reinterpret_cast<const float2*>(residual + o + (row1 ? W : 0));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q0[i] = q1[i] = make_float2(0.0f, 0.0f);
+    }
+    if (!tvalid) return;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int co = co_blk + h * 16 + 4 * kq + r;
+            const int i = h * 4 + r;
             float m[16];
 #pragma unroll
             for (int xi = 0; xi < 16; ++xi) m[xi] = acc[xi][h][r];
@@ -387,14 +422,9 @@ __global__ __launch_bounds__(NW * 64, 2) void wino_reg_kernel(const float* __res
             for (int c = 0; c < 4; ++c) { s0[c] = m[c] + m[4 + c] + m[8 + c]; s1[c] = m[4 + c] - m[8 + c] - m[12 + c]; }
             float o00 = s0[0] + s0[1] + s0[2], o01 = s0[1] - s0[2] - s0[3];
             float o10 = s1[0] + s1[1] + s1[2], o11 = s1[1] - s1[2] - s1[3];
-            const float sc = scale[co], sh = shift[co];
-            const long long o = (((long long)b * Cout + co) * H + oy) * W + ox;
-            o00 = o00 * sc + sh; o01 = o01 * sc + sh; o10 = o10 * sc + sh; o11 = o11 * sc + sh;
-            if (residual) {
-                const float2 q0 = *reinterpret_cast<const float2*>(residual + o);
-                o00 += q0.x; o01 += q0.y;
-                if (row1) { const float2 q1 = *reinterpret_cast<const float2*>(residual + o + W); o10 += q1.x; o11 += q1.y; }
-            }
+            const float sc = scv[i], sh = shv[i];
+            const long long o = o_base + (h * 16 + r) * ch_stride;
+            o00 = o00 * sc + sh + q0[i].x; o01 = o01 * sc + sh + q0[i].y; o10 = o10 * sc + sh + q1[i].x; o11 = o11 * sc + sh + q1[i].y;
             if (relu) { o00 = fmaxf(o00, 0.0f); o01 = fmaxf(o01, 0.0f); o10 = fmaxf(o10, 0.0f); o11 = fmaxf(o11, 0.0f); }
             *reinterpret_cast<float2*>(y + o) = make_float2(o00, o01);
             if (row1) *reinterpret_cast<float2*>(y + o + W) = make_float2(o10, o11);
@@ -423,7 +453,7 @@ extern "C" int di2p_conv3x3_winograd(const float* x, const float* U, const float
     const int n_tb = di2p_cdiv(total, WG_TILES);
     // co-block 64 when that still leaves >= 3 workgroups per CU, else 32 (more, smaller workgroups for the small late stages)
     const long long opt = di2p_opt(DI2P_OPT_WINO_COB);
-    const bool cob64 = opt ? opt == 64 : (Cout % 64 == 0 && (long long)n_tb * (Cout / 64) >= 768);
+    const bool cob64 = opt ? (opt == 64 && Cout % 64 == 0) : (Cout % 64 == 0 && (long long)n_tb * (Cout / 64) >= 768);
     hipStream_t st = (hipStream_t)stream;
     const bool db = di2p_opt(DI2P_OPT_WINO_DB) != 0;
     const int map_opt = (int)di2p_opt(DI2P_OPT_WINO_MAP);      // 0: automatic, 1: tile blocks over the XCDs, 2: co-blocks over the XCDs
