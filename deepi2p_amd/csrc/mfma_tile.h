@@ -15,6 +15,20 @@
 #pragma once
 #include "common.h"
 
+// Priority of a wave while it issues an MFMA cluster.  Two waves of a SIMD that contend for the matrix pipe at equal priority drift into
+// lockstep (both in the MFMA phase, then both in the load / transform phase with the pipe idle); the wave that enters its cluster first
+// keeps the pipe until it is through, the other one runs its VALU / memory phase underneath.  DI2P_MFMA_PRIO=0 builds without it.
+#ifndef DI2P_MFMA_PRIO
+#define DI2P_MFMA_PRIO 1
+#endif
+#if DI2P_MFMA_PRIO
+#define DI2P_MFMA_BEGIN() __builtin_amdgcn_s_setprio(1)
+#define DI2P_MFMA_END() __builtin_amdgcn_s_setprio(0)
+#else
+#define DI2P_MFMA_BEGIN() ((void)0)
+#define DI2P_MFMA_END() ((void)0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int WM_, int WN_, int TM_, int TN_, int BK_ = 16>
@@ -90,6 +104,7 @@ __device__ __forceinline__ void mfma_gemm_block(float* lds, LoaderA& la, LoaderB
 #pragma unroll
             for (int j = 0; j < Cfg::TN; ++j) b[kk / 2][j] = Bb[(kk + half) * BN + j * 32];
         }
+        DI2P_MFMA_BEGIN();
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk)
 #pragma unroll
@@ -97,6 +112,7 @@ __device__ __forceinline__ void mfma_gemm_block(float* lds, LoaderA& la, LoaderB
 #pragma unroll
                 for (int j = 0; j < Cfg::TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+        DI2P_MFMA_END();
         if (t + 1 < T) lstore(buf ^ 1);
         __syncthreads();
     }
@@ -202,6 +218,7 @@ __device__ __forceinline__ void mfma_gemm_block_vec(float* lds, LoaderA& la, Loa
 #pragma unroll
             for (int j = 0; j < Cfg::TN; ++j) b[s][j] = Bb[(kk + half) * BN + j * 32];
         };
+        DI2P_MFMA_BEGIN();
         fread(0, 0);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
@@ -213,6 +230,7 @@ __device__ __forceinline__ void mfma_gemm_block_vec(float* lds, LoaderA& la, Loa
                 for (int j = 0; j < Cfg::TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
         }
+        DI2P_MFMA_END();
     };
     // Steady state: branch-free body.  The scheduling fences pin the global loads of step t+1 AHEAD of the MFMA phase of
     // step t and their first use (fix + ds_write) BEHIND it, so the L2/HBM latency hides under the MFMAs; without them
@@ -307,6 +325,7 @@ __device__ __forceinline__ void mfma_gemm_block_vec2(float* lds, LoaderA& la, Lo
 #pragma unroll
             for (int j = 0; j < Cfg::TN; ++j) b[s][j] = Bb[(kk + half) * BN + j * 32];
         };
+        DI2P_MFMA_BEGIN();
         fread(0, 0);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
@@ -318,6 +337,7 @@ __device__ __forceinline__ void mfma_gemm_block_vec2(float* lds, LoaderA& la, Lo
                 for (int j = 0; j < Cfg::TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
         }
+        DI2P_MFMA_END();
     };
     // step t computes from LDS buffer t & 1; stage s0 carries the even steps' data, s1 the odd ones (static register sets).
     // (Measured and dropped: letting the LDS store of step t+1 interleave with the MFMAs of step t through a
@@ -414,6 +434,7 @@ __device__ __forceinline__ void mfma_gemm_block_blds(float* lds, LoaderA& la, co
 #pragma unroll
             for (int j = 0; j < Cfg::TN; ++j) b[s][j] = (t * BK + kk + half < K) ? Bb[(kk + half) * ldb + j * 32] : 0.0f;
         };
+        DI2P_MFMA_BEGIN();
         fread(0, 0);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
@@ -425,6 +446,7 @@ __device__ __forceinline__ void mfma_gemm_block_blds(float* lds, LoaderA& la, co
                 for (int j = 0; j < Cfg::TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
         }
+        DI2P_MFMA_END();
     };
     gload(0);
     lstore(0);

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][h][r] = 0.0f;
         const float* Bb = Ps + half * ST_PC + wave * 32 + l31;      // + (ci*(2R+5) + 2j + ky)*264 + m: immediates
+        DI2P_MFMA_BEGIN();
 #pragma unroll
         for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
                         acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], bv[j][m], acc[j][1], 0, 0, 0);
                     }
             }
+        DI2P_MFMA_END();
         const int ct = item % n_ct, rt = (item / n_ct) % n_rt, b = item / (n_ct * n_rt);
         const int ox = ct * ST_PX + wave * 32 + l31;
         if (ox < OW) {

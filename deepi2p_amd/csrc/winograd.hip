@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(const float* __restrict_
         if (t + 1 < T) gload(t + 1);
         const float* Us = lds + buf * L::STAGE;
         const float* Vs = Us + L::U_FLOATS;
+        DI2P_MFMA_BEGIN();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {            // (hoisting all 32 operand reads of the K-step ahead of the 16 MFMAs measured no gain)
             const int xi = wave * 4 + j;
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(const float* __restrict_
 #pragma unroll
                 for (int h = 0; h < MT; ++h) acc[j][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][h], bv[kk], acc[j][h], 0, 0, 0);
         }
+        DI2P_MFMA_END();
         if (DB) {
             if (t + 1 < T) lstore(buf ^ 1);
             __syncthreads();
@@ -375,12 +377,14 @@ __global__ __launch_bounds__(NW * 64, 2) void wino_reg_kernel(const float* __res
         const int buf = t & 1;
         if (t + 1 < T) gload(t + 1);
         const float* Ab = &Us[buf][kq * 16 + l15];
+        DI2P_MFMA_BEGIN();
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
             const float a0 = Ab[xi * 128], a1 = Ab[xi * 128 + 64];
             acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv[xi], acc[xi][0], 0, 0, 0);
             acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv[xi], acc[xi][1], 0, 0, 0);
         }
+        DI2P_MFMA_END();
         if (t + 1 < T) stage(buf ^ 1);
         __syncthreads();
     }
