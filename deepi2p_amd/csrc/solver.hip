@@ -68,7 +68,7 @@ __device__ __forceinline__ void make_rot(const double* x, Rot<NP>& r) {
         // AngleAxisRotatePoint with axis (0,theta,0): Ry(theta); first-order branch for theta^2 <= eps
         const double th = x[0];
         double c, s;
-        if (th * th > DBL_EPSILON) { c = cos(th); s = sin(th); } else { c = 1.0; s = th; }
+        if (th * th > DBL_EPSILON) { sincos(th, &s, &c); } else { c = 1.0; s = th; }      // one argument reduction for both
         r.R[0] = c; r.R[1] = 0; r.R[2] = s; r.R[3] = 0; r.R[4] = 1; r.R[5] = 0; r.R[6] = -s; r.R[7] = 0; r.R[8] = c;
     } else {
         const double wx = x[0], wy = x[1], wz = x[2];
@@ -76,7 +76,9 @@ __device__ __forceinline__ void make_rot(const double* x, Rot<NP>& r) {
         for (int i = 0; i < 9; ++i) { r.R[i] = 0; r.dR[0][i] = r.dR[1][i] = r.dR[2][i] = 0; }
         if (t2 > DBL_EPSILON) {
             const double th = sqrt(t2), ux = wx / th, uy = wy / th, uz = wz / th;
-            const double c = cos(th), s = sin(th), oc = 1.0 - c;
+            double c, s;
+            sincos(th, &s, &c);
+            const double oc = 1.0 - c;
             const double u[3] = {ux, uy, uz};
             r.R[0] = r.R[4] = r.R[8] = c;
             skew_add(r.R, s, ux, uy, uz);

@@ -437,6 +437,16 @@ def pc_encoder(P, opt, pc, intensity, sn, node_a, node_b, p="pc_encoder"):
                 global_feature=global_feature, idx_a=idx_a, w_a=w_a)
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 def _conv_bn(P, pc, pb, x, stride, pad, relu, residual=None):
     y = _Conv2d.apply(x, P[pc + ".weight"], stride, pad)
     return batch_norm(P, pb, y, relu=relu, residual=residual)
@@ -459,12 +469,26 @@ def resnet34(P, x, p="img_encoder.backbone"):
     return outs[2], outs[3], _AvgPool.apply(x)
 
 
-def keypoint_detector(P, opt, pc, intensity, sn, node_a, node_b, img, dropouts=None):
+def keypoint_detector(P, opt, pc, intensity, sn, node_a, node_b, img, dropouts=None, branch_streams=False):
     """KeypointDetector.forward (networks_united.py:105-210) in train mode -> scores f32[B, 2 (+L), N].
-    dropouts: the two u8 keep-masks [B, C, N] of per_point_pn layers 0 and 1 (None: no dropout, i.e. p = 0)."""
+    dropouts: the two u8 keep-masks [B, C, N] of per_point_pn layers 0 and 1 (None: no dropout, i.e. p = 0).
+    branch_streams: run the image branch on a second HIP stream (same results: no kernel changes its summation order)."""
     B, N, Ma, Mb = pc.shape[0], pc.shape[2], node_a.shape[2], node_b.shape[2]
-    e = pc_encoder(P, opt, pc, intensity, sn, node_a, node_b)
-    s16, s32, iglob = resnet34(P, img)
+    if branch_streams and img.is_cuda:
+        # The image branch and the point branch are independent up to the attention layers, and at the training batch (8 frames) neither
+        # fills the chip: the ResNet runs on a second stream next to the point encoder.  autograd runs every backward node on the stream
+        # of its forward, so the two backward halves overlap the same way, and the engine joins the streams at the end of backward().
+        main, side = torch.cuda.current_stream(img.device), _side_stream(img.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            s16, s32, iglob = resnet34(P, img)
+        e = pc_encoder(P, opt, pc, intensity, sn, node_a, node_b)
+        main.wait_stream(side)
+        for t in (s16, s32, iglob):
+            t.record_stream(main)          # allocated on the side stream, read on the main one
+    else:
+        e = pc_encoder(P, opt, pc, intensity, sn, node_a, node_b)
+        s16, s32, iglob = resnet34(P, img)
     C_img = iglob.shape[1]
     s16f = s16.reshape(B, s16.shape[1], -1)
     s32f = s32.reshape(B, s32.shape[1], -1)

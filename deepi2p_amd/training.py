@@ -129,7 +129,8 @@ class ClassifierTrainer:
             if dropouts == "draw":
                 c0, c1 = train_net.head_widths(P)
                 dropouts = [train_net.dropout_mask((B, c, N), 0.5, self.seed, 2 * self.steps + i, pc.device) for i, c in enumerate((c0, c1))]
-            scores = train_net.keypoint_detector(P, self.opt, pc, intensity, sn, node_a, node_b, img, dropouts)
+            scores = train_net.keypoint_detector(P, self.opt, pc, intensity, sn, node_a, node_b, img, dropouts,
+                                                 branch_streams=bool(getattr(self.opt, "branch_streams", True)))
         else:
             with torch.no_grad():
                 out = self.detector(pc, intensity, sn, node_a, node_b, img)
