@@ -503,6 +503,7 @@ def main_train(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses.append(tr.optimize(*t, K, Pgt)["loss"])
+    t_enqueue = time.perf_counter() - t0          # host time to enqueue the steps (close to dt: the step is launch-bound)
     sync_all()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -531,7 +532,8 @@ def main_train(args):
         top = sorted(fam.items(), key=lambda kv: -kv[1][0])[:10]
         line = {"metric": "training frames/sec (train-mode fwd + focal/CE loss + bwd + gradient all-reduce + Adam) KITTI 20k-pt 160x512, batch %d per GPU" % B,
                 "value": B * world * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "ms_per_step": 1e3 * dt / args.steps, "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f32 (fp32-input MFMA contractions, fp64 BatchNorm/bias reductions)", "data": "synthetic frames, seeded He-normal initial weights",
                 "config": {"workload": "reference training configuration kitti/options.py:20-60 (batch 8, 20480 pts, 160x512, coarse+fine, Adam 1e-3)",
                            "mode": "train", "frames_per_gpu_per_step": B, "points": N, "image": [H, W], "parallelism": "dp%d" % world,

@@ -9,6 +9,8 @@ allreduce_gradients    the data-parallel gradient exchange (replaces nn.DataPara
 ClassifierTrainer      MMClassifer.optimize / test_model (models/multimodal_classifier.py:119-225): labels by projection, train-mode
                        forward and backward on the HIP kernels (deepi2p_amd/train_net.py), gradient all-reduce, Adam
 """
+import os
+
 import torch
 
 from . import _lib, ops, prep, train_net
@@ -130,7 +132,7 @@ class ClassifierTrainer:
                 c0, c1 = train_net.head_widths(P)
                 dropouts = [train_net.dropout_mask((B, c, N), 0.5, self.seed, 2 * self.steps + i, pc.device) for i, c in enumerate((c0, c1))]
             scores = train_net.keypoint_detector(P, self.opt, pc, intensity, sn, node_a, node_b, img, dropouts,
-                                                 branch_streams=bool(getattr(self.opt, "branch_streams", True)))
+                                                 branch_streams=bool(getattr(self.opt, "branch_streams", os.environ.get("DI2P_TRAIN_BRANCH_STREAMS", "1") != "0")))
         else:
             with torch.no_grad():
                 out = self.detector(pc, intensity, sn, node_a, node_b, img)
