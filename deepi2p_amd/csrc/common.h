@@ -50,9 +50,9 @@ enum Di2pOption {
     DI2P_OPT_WINO_MAP,              // workgroup -> XCD mapping of the Winograd convolution: 0 automatic, 1 by tile block, 2 by co-block
     DI2P_OPT_WINO_KC,               // 8 / 4: input channels per K-step of the Winograd convolution (0: 4 up to 256 input channels, else 8)
     DI2P_OPT_CONV_NOSTEM,           // 1: the host layer runs the 7x7 stem on the generic implicit-GEMM kernel (read by networks.py)
-    DI2P_OPT_PW_CFG,                // force the tile of the vector pointwise GEMM: 1 = 64x64, 2 = 64x128, 3 = 128x128 (0: by grid size)
+    DI2P_OPT_PW_CFG,                // tile of the vector pointwise GEMM: 0/1 = 64x64 (default), 2 = 64x128, 3 = 128x128, >= 16: larger tiles from that many workgroups on
     DI2P_OPT_WINO_REG,              // Winograd kernel: 0 automatic, 1 LDS-panel kernel, 2 register-resident (4 waves), 3 register-resident (2 waves)
-    DI2P_OPT_WINO_REG_MIN,          // automatic choice: register-resident Winograd kernel from this many 64-tile workgroups on (default 1024)
+    DI2P_OPT_WINO_REG_MIN,          // automatic choice: register-resident Winograd kernel from this many 64-tile workgroups on (default 256: all but the 512-channel stage)
     DI2P_OPT_COUNT
 };
 long long di2p_opt(int id);

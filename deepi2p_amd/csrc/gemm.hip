@@ -279,7 +279,12 @@ struct HeadTail {
     const float* sh2;
     int relu1, relu2, P;
 };
-using HeadCfg = TileCfg<2, 2, 2, 1, 32>;       // 128 rows x 64 points, 4 waves of 64 x 32
+// K-step 16: 24 KB of staging + the 32 KB activation tile = 56 KB per workgroup (K-step 32: 80 KB).  Alone the two are level; in the
+// 8-stream pipeline the smaller footprint is worth +1.3 % frames/s (more workgroups of the other families fit beside it).
+#ifndef DI2P_HEAD_BK
+#define DI2P_HEAD_BK 16
+#endif
+using HeadCfg = TileCfg<2, 2, 2, 1, DI2P_HEAD_BK>;       // 128 rows x 64 points, 4 waves of 64 x 32
 constexpr int HEAD_M = 128, HEAD_BN = 64;
 
 __global__ __launch_bounds__(HeadCfg::THREADS) void point_head_kernel(SrcDev srcs, const float* __restrict__ W0t, int K0, EpiDev e0,
@@ -492,12 +497,17 @@ extern "C" int di2p_pointwise_gemm(const di2p_src_t* srcs, int n_src, const floa
     for (int i = 0; i < n_src; ++i)
         dense = dense && srcs[i].mode == DI2P_SRC_DENSE && srcs[i].row_stride % 4 == 0 && srcs[i].batch_stride % 4 == 0 && aligned16(srcs[i].ptr);
     if (vec) {
-        // small grids (node-level layers: N = 128 columns per frame) take smaller tiles to spread over the CUs
+        // 64 x 64 tiles for every layer.  Alone, the big point layers are a few per cent faster on 128 x 128 tiles, but in the 8-stream
+        // pipeline the small tile (32 KB of LDS and 100 registers per workgroup instead of 64 KB and 200) packs better beside the pose
+        // solver's workgroups and the family's own serial time drops too (2.05 -> 1.95 ms): +1.5-2 % frames/s (tools/sweep_packing.sh).
+        // DI2P_PW_CFG: 2 = 64x128, 3 = 128x128 tiles everywhere, 4 = 64x64 with K-step 16 (level with K-step 32); >= 16: 128x128 / 64x128 from that many workgroups on (the old rule: 1024)
         const long long wg128 = (long long)B * di2p_cdiv(N, 128) * di2p_cdiv(M, 128);
         const long long wg64x128 = (long long)B * di2p_cdiv(N, 128) * di2p_cdiv(M, 64);
-        const long long force = di2p_opt(DI2P_OPT_PW_CFG);       // experiments: 1 = 64x64, 2 = 64x128, 3 = 128x128 tiles
-        if (force == 3 || (!force && wg128 >= 1024)) launch_pw_vec<TileCfg<2, 2, 2, 2, 32>>(dense, s, Wt, Y, B, M, K, N, e, st);
-        else if (force == 2 || (!force && (wg64x128 >= 1024 || N % 64 != 0)) || (force == 1 && N % 64 != 0)) launch_pw_vec<TileCfg<2, 2, 1, 2, 32>>(dense, s, Wt, Y, B, M, K, N, e, st);
+        const long long opt = di2p_opt(DI2P_OPT_PW_CFG);
+        const long long force = opt < 16 ? opt : 0, thr = opt >= 16 ? opt : (1ll << 62);
+        if (force == 4 && N % 64 == 0) launch_pw_vec<TileCfg<2, 2, 1, 1, 16>>(dense, s, Wt, Y, B, M, K, N, e, st);
+        else if (force == 3 || (!force && wg128 >= thr)) launch_pw_vec<TileCfg<2, 2, 2, 2, 32>>(dense, s, Wt, Y, B, M, K, N, e, st);
+        else if (force == 2 || (!force && wg64x128 >= thr) || N % 64 != 0) launch_pw_vec<TileCfg<2, 2, 1, 2, 32>>(dense, s, Wt, Y, B, M, K, N, e, st);
         else launch_pw_vec<TileCfg<2, 2, 1, 1, 32>>(dense, s, Wt, Y, B, M, K, N, e, st);
         DI2P_RETURN_LAUNCH();
     }

@@ -473,9 +473,10 @@ extern "C" int di2p_conv3x3_winograd(const float* x, const float* U, const float
                            TH, TW, (int)total, n_tb, n_cb, relu, by_co);                                                                     \
     } while (0)
     const long long reg_opt = di2p_opt(DI2P_OPT_WINO_REG);      // 0: automatic, 1: LDS-panel kernel, 2: register-resident, 4 waves, 3: 2 waves
-    // automatic: the register-resident kernel where its 64-tile workgroups still fill the chip four times over (ResNet stage 1:
-    // 82 vs 100 us); it holds 128 accumulator registers per lane (2 waves per SIMD), so on smaller grids the LDS-panel kernel's
-    // higher occupancy wins (stage 3: 89 vs 99 us)
+    // automatic: the register-resident kernel wherever its 64-tile workgroups number at least 256 (ResNet stages 1-3).  Alone, the LDS-panel
+    // kernel is level or ahead from stage 2 on (stage 3: 85 vs 93 us), but in the 8-stream pipeline the register-resident kernel's
+    // 16 KB of LDS per workgroup (against 32-64 KB) lets it share a CU with the pose solver's workgroups: +2.8 % frames/s with the
+    // threshold at 300 instead of 1024 (tools/sweep_wino_reg_min.sh); at the 512-channel stage (192 workgroups) the LDS-panel kernel stays
     const bool reg_auto = reg_opt == 0 && (long long)di2p_cdiv(total, 64) * (Cout / 32) >= di2p_opt(DI2P_OPT_WINO_REG_MIN);
     if ((reg_opt >= 2 || reg_auto) && Cin % 4 == 0 && ((uintptr_t)residual & 7) == 0) {
         const int nw = reg_opt == 3 ? 2 : 4;
