@@ -31,6 +31,7 @@ const OptDef kOpts[DI2P_OPT_COUNT] = {
     {"wino_db", "DI2P_WINO_DB", 1},                 {"wino_map", "DI2P_WINO_MAP", 0},
     {"wino_kc", "DI2P_WINO_KC", 0},                 {"conv_nostem", "DI2P_CONV_NOSTEM", 0},
     {"pw_cfg", "DI2P_PW_CFG", 0},                   {"wino_reg", "DI2P_WINO_REG", 0},                 {"wino_reg_min", "DI2P_WINO_REG_MIN", 256},
+    {"solver_lds_pad", "DI2P_SOLVER_LDS_PAD", 0},
 };
 long long g_opt[DI2P_OPT_COUNT];
 std::once_flag g_opt_once;

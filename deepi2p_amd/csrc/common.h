@@ -53,6 +53,7 @@ enum Di2pOption {
     DI2P_OPT_PW_CFG,                // tile of the vector pointwise GEMM: 0/1 = 64x64 (default), 2 = 64x128, 3 = 128x128, >= 16: larger tiles from that many workgroups on
     DI2P_OPT_WINO_REG,              // Winograd kernel: 0 automatic, 1 LDS-panel kernel, 2 register-resident (4 waves), 3 register-resident (2 waves)
     DI2P_OPT_WINO_REG_MIN,          // automatic choice: register-resident Winograd kernel from this many 64-tile workgroups on (default 256: all but the 512-channel stage)
+    DI2P_OPT_SOLVER_LDS_PAD,        // bytes of unused dynamic LDS per solver workgroup (caps its workgroups per CU; experiments)
     DI2P_OPT_COUNT
 };
 long long di2p_opt(int id);

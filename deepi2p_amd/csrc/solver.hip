@@ -1745,13 +1745,16 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
         ka.pending = PEND; ka.budget = BUDGET; ka.resume = RESUME;                                                               \
         /* the instrumented build runs at <= 3 waves per SIMD: at 128 registers its timers push it into scratch and distort the phases */ \
         if (g_prof) hipLaunchKernelGGL((solve_kernel<NPV, PT, (MW > 3 ? 3 : MW), WP, true>), grid, dim3(WP * 64), 0, st, ka);    \
-        else hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP, false>), grid, dim3(WP * 64), 0, st, ka);                         \
+        else hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP, false>), grid, dim3(WP * 64), lds_pad, st, ka);                   \
     } while (0)
 #define DI2P_LAUNCH_SOLVE(NPV, MW, WP, PEND, BUDGET, RESUME)                                                                     \
     do {                                                                                                                         \
         ka.pending = PEND; ka.budget = BUDGET; ka.resume = RESUME;                                                               \
-        hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP, false>), grid, dim3(WP * 64), 0, st, ka);                              \
+        hipLaunchKernelGGL((solve_kernel<NPV, PT, MW, WP, false>), grid, dim3(WP * 64), lds_pad, st, ka);                        \
     } while (0)
+    // unused dynamic LDS: caps the solver's workgroups per CU (160 KB / (static + pad)) so that registers and LDS stay free for
+    // the MFMA kernels of the other streams -- the solver needs VALU issue slots, they need the matrix pipe
+    const size_t lds_pad = (size_t)di2p_opt(DI2P_OPT_SOLVER_LDS_PAD);
     int* pend1 = tier > 0 ? pending : nullptr;
     if (is_2d) {
         switch (cfg) {

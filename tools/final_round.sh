@@ -15,6 +15,7 @@ bash tools/profile_round.sh $TAG > $OUT/${TAG}_profile_round.log 2>&1
 bash tools/prof_solver_counters.sh $TAG > $OUT/${TAG}_solver_counters.log 2>&1
 timeout 200 python tools/call_times.py 15 > $OUT/${TAG}_call_times.txt 2>&1
 timeout 200 bash tools/sweep_streams2.sh > $OUT/${TAG}_sweep_streams.txt 2>&1
+bash tools/prof_step_instructions.sh $TAG > $OUT/${TAG}_step_instructions.log 2>&1
 export TMPDIR=/tmp; ROOT=$(pwd); cd /tmp; rm -rf /tmp/pt
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -- python $ROOT/bench.py --mode train --steps 4 --warmup 2 > /tmp/pt.log 2>&1
 f=$(find /tmp/pt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $ROOT/$OUT/${TAG}_train_kernel_stats.csv

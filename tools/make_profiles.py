@@ -140,6 +140,8 @@ files listed in KEEP_OLD (if present) come from earlier calls of the round.
   percentiles.
 {sc_txt}* `{TAG}_call_times.txt` -- `tools/call_times.py`: HIP events around every C-ABI call of one serial step, with the contraction shapes.
 * `{TAG}_sweep_streams.txt` -- the headline against streams / hardware queues.
+* `{TAG}_step_instructions.txt` -- `tools/prof_step_instructions.sh`: VALU / MFMA / SALU / LDS wave-instruction counters of every kernel of a step
+  (what the 8-stream step time is bounded by: DESIGN.md section 4).
 * `{TAG}_index_max_cold.txt` -- cache-cold index_max.
 * `{TAG}_train_line.json`, `{TAG}_train_kernel_stats.csv` -- `python bench.py --mode train` (reference training configuration: batch 8, 20480
   points, 160x512, coarse+fine): **{tr['ms_per_step']:.1f} ms per step = {tr['value']:.0f} frames/s**,
