@@ -81,6 +81,7 @@ class RegistrationExecutor:
                 s.dev[k] = t.to(self.device, non_blocking=False).contiguous()
             self.slots.append(s)
         self._next = 0
+        self._h2d_warm = False
         torch.cuda.synchronize(self.device)
 
     # ------------------------------------------------------------------------------------------------------------ one step
@@ -114,6 +115,7 @@ class RegistrationExecutor:
     def warm_up(self, with_h2d=True):
         """Capture (or run once) every slot's step so that the first timed submit pays nothing extra.  A failed capture switches the
         executor to eager launches (and remembers why in `graph_error`)."""
+        want_h2d = bool(with_h2d)
         with_h2d = with_h2d and self.h2d_mode == "graph"
         for slot in self.slots:
             if self.use_graph and with_h2d not in slot.graphs:
@@ -127,6 +129,14 @@ class RegistrationExecutor:
             if not self.use_graph:
                 with torch.cuda.stream(slot.stream):
                     slot.outputs = self._step(slot, with_h2d)
+        if want_h2d and not self._h2d_warm:
+            # the first copy on a stream pays one-time costs (DMA queue set-up, first touch of the pinned buffers by the engine): once per
+            # slot here, like the graph capture above, not inside somebody's first timed steps
+            for slot in self.slots:
+                with torch.cuda.stream(slot.copy_stream if slot.copy_stream is not None else slot.stream):
+                    for k in INPUT_NAMES:
+                        slot.dev[k].copy_(slot.host[k], non_blocking=True)
+            self._h2d_warm = True
         torch.cuda.synchronize(self.device)
 
     def step_eager(self, slot_index=0, with_h2d=False):
