@@ -82,6 +82,7 @@ class RegistrationExecutor:
             self.slots.append(s)
         self._next = 0
         self._h2d_warm = False
+        self._replayed = set()
         torch.cuda.synchronize(self.device)
 
     # ------------------------------------------------------------------------------------------------------------ one step
@@ -129,6 +130,13 @@ class RegistrationExecutor:
             if not self.use_graph:
                 with torch.cuda.stream(slot.stream):
                     slot.outputs = self._step(slot, with_h2d)
+        if self.use_graph:
+            # likewise the first replay of a captured graph (the runtime uploads it then): once per slot and graph here
+            for slot in self.slots:
+                if with_h2d in slot.graphs and (slot.index, with_h2d) not in self._replayed:
+                    with torch.cuda.stream(slot.stream):
+                        slot.graphs[with_h2d][0].replay()
+                    self._replayed.add((slot.index, with_h2d))
         if want_h2d and not self._h2d_warm:
             # the first copy on a stream pays one-time costs (DMA queue set-up, first touch of the pinned buffers by the engine): once per
             # slot here, like the graph capture above, not inside somebody's first timed steps
