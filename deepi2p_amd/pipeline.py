@@ -83,6 +83,7 @@ class RegistrationExecutor:
         self._next = 0
         self._h2d_warm = False
         self._replayed = set()
+        self._warmed = set()
         torch.cuda.synchronize(self.device)
 
     # ------------------------------------------------------------------------------------------------------------ one step
@@ -145,6 +146,7 @@ class RegistrationExecutor:
                     for k in INPUT_NAMES:
                         slot.dev[k].copy_(slot.host[k], non_blocking=True)
             self._h2d_warm = True
+        self._warmed.add(want_h2d)
         torch.cuda.synchronize(self.device)
 
     def step_eager(self, slot_index=0, with_h2d=False):
@@ -161,12 +163,14 @@ class RegistrationExecutor:
         """Start one step on the next slot (round robin) and return its ticket.  host_batch: dict of CPU tensors (copied into the slot's
         pinned buffers, then H2D inside the step); None: the slot's resident device inputs are used as they are (with_h2d=False) or
         re-sent from its pinned buffers (with_h2d=True)."""
+        if with_h2d is None:
+            with_h2d = host_batch is not None
+        if bool(with_h2d) not in self._warmed:
+            self.warm_up(with_h2d)                # first use: captures, first replays, first copies (synchronises the device once)
         slot = self.slots[self._next]
         self._next = (self._next + 1) % self.n_streams
         if slot.busy and host_batch is not None:
             slot.done.synchronize()               # new host data: the slot's previous H2D copies must have read the pinned buffers
-        if with_h2d is None:
-            with_h2d = host_batch is not None
         if host_batch is not None:
             for k in INPUT_NAMES:
                 slot.host[k].copy_(host_batch[k])
