@@ -16,7 +16,7 @@ void di2p_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* di2p_last_error(void) { return g_err; }
-extern "C" int di2p_version(void) { return 3; }
+extern "C" int di2p_version(void) { return 4; }
 
 namespace {
 struct OptDef { const char* name; const char* env; long long def; };
@@ -31,7 +31,7 @@ const OptDef kOpts[DI2P_OPT_COUNT] = {
     {"wino_db", "DI2P_WINO_DB", 1},                 {"wino_map", "DI2P_WINO_MAP", 0},
     {"wino_kc", "DI2P_WINO_KC", 0},                 {"conv_nostem", "DI2P_CONV_NOSTEM", 0},
     {"pw_cfg", "DI2P_PW_CFG", 0},                   {"wino_reg", "DI2P_WINO_REG", 0},                 {"wino_reg_min", "DI2P_WINO_REG_MIN", 256},
-    {"solver_lds_pad", "DI2P_SOLVER_LDS_PAD", 0},
+    {"solver_lds_pad", "DI2P_SOLVER_LDS_PAD", 0},   {"solver_nocache", "DI2P_SOLVER_NOCACHE", 0},
 };
 long long g_opt[DI2P_OPT_COUNT];
 std::once_flag g_opt_once;

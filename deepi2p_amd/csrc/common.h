@@ -54,6 +54,7 @@ enum Di2pOption {
     DI2P_OPT_WINO_REG,              // Winograd kernel: 0 automatic, 1 LDS-panel kernel, 2 register-resident (4 waves), 3 register-resident (2 waves)
     DI2P_OPT_WINO_REG_MIN,          // automatic choice: register-resident Winograd kernel from this many 64-tile workgroups on (default 256: all but the 512-channel stage)
     DI2P_OPT_SOLVER_LDS_PAD,        // bytes of unused dynamic LDS per solver workgroup (caps its workgroups per CU; experiments)
+    DI2P_OPT_SOLVER_NOCACHE,        // 1: no classification cache in the cluster walk (bit-identical by construction)
     DI2P_OPT_COUNT
 };
 long long di2p_opt(int id);

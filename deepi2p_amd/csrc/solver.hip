@@ -121,7 +121,9 @@ template <> struct __attribute__((aligned(16))) Rec<double> { double x, y, z; lo
 // classify the points of a cluster individually only when the box touches a plane (see sweep_clusters).
 constexpr int CL = 64;
 // axis-aligned bounds of a cluster (centre, half extents) in fp32, rounded OUTWARD: the fp32 box contains every point of the cluster
-struct __attribute__((aligned(16))) Box { float cx, cy, cz, hx, hy, hz, pad0, pad1; };
+// rxz / r3: the largest ground-plane radius sqrt(x^2 + z^2) and the largest norm of a point of the cluster, rounded UP -- how far a point of
+// the cluster can move per radian of iterate rotation (2-D solver: about the y axis; 3-D: any axis), see the classification cache below.
+struct __attribute__((aligned(16))) Box { float cx, cy, cz, hx, hy, hz, rxz, r3; };
 
 __device__ __forceinline__ unsigned spread10(unsigned v) {
     v &= 0x3ffu;
@@ -278,6 +280,9 @@ __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ po
         for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
             for (int a = 0; a < 3; ++a) { lo[a] = fmin(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmax(hi[a], __shfl_xor(hi[a], o)); }
+        double rxz = valid ? x * x + z * z : 0.0, r3 = valid ? x * x + y * y + z * z : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { rxz = fmax(rxz, __shfl_xor(rxz, o)); r3 = fmax(r3, __shfl_xor(r3, o)); }
         // a NaN coordinate must poison the box (fmin/fmax drop it): such clusters are always classified per point
         const bool nan_any = __any(valid && !(x == x && y == y && z == z)) != 0;
         if (lane == 0) {
@@ -294,7 +299,8 @@ __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ po
                 bh[a] = (float)(hd * (1.0 + 1e-6)) + 1e-30f;
             }
             if (nan_any) bx.hx = __builtin_nanf("");
-            bx.pad0 = bx.pad1 = 0.0f;
+            bx.rxz = (float)(sqrt(rxz) * (1.0 + 1e-6)) + 1e-30f;
+            bx.r3 = (float)(sqrt(r3) * (1.0 + 1e-6)) + 1e-30f;
             boxes[c] = bx;
         }
     }
@@ -328,6 +334,7 @@ struct SweepShared {
     double acc[WPH][1 + NP + Tri<NP>::N][64];
     int acc_e[WPH][64];
     alignas(16) float btest[WPH][BOXTEST_WORDS];   // the wave's box-test table of the current sweep (wave-uniform, re-read per cluster round)
+    alignas(16) double ring[8][NP];                // iterates of the last RING sweeps (slot = sweep number % RING), see the classification cache
 };
 
 // v_rcp_f64 + two Newton steps: <= 1 ulp for finite non-zero inputs; 0 / inf / NaN give inf / 0 / NaN-like values that the
@@ -499,17 +506,19 @@ __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& ro
     }
 }
 
-// The five planes of the camera frustum in camera coordinates, f_i(p) = n_i . p (un-normalised) with |n_i|:
-//   pix_x > 0  <=> f_L = fx*p0 + cx*p2 > 0,  pix_x < W1 <=> f_R = -fx*p0 + (W1-cx)*p2 > 0   (for p2 > 0; for p2 < 0 the
-//   pix_y > 0  <=> f_T = fy*p1 + cy*p2 > 0,  pix_y < H1 <=> f_B = -fy*p1 + (H1-cy)*p2 > 0    signs flip together),
-//   p2 > 0     <=> f_Z = p2 > 0.
-struct Planes { double nL, nR, nT, nB; };
+// The five planes of the camera frustum in camera coordinates, f_i(p) = n_i . p, each NORMALISED to |n_i|_1 = 1:
+//   pix_x > 0  <=> f_L = (fx*p0 + cx*p2) / (|fx|+|cx|) > 0,  pix_x < W1 <=> f_R = (-fx*p0 + (W1-cx)*p2) / (|fx|+|W1-cx|) > 0   (for p2 > 0; for
+//   pix_y > 0  <=> f_T = (fy*p1 + cy*p2) / (|fy|+|cy|) > 0,  pix_y < H1 <=> f_B = (-fy*p1 + (H1-cy)*p2) / (|fy|+|H1-cy|) > 0    p2 < 0 the signs flip
+//   p2 > 0     <=> f_Z = p2 > 0.                                                                                              together),
+// With unit 1-norms every |f_i(p)| <= |p|_inf, a displacement d of the point changes every f_i by at most |d|_inf, and ONE relative margin
+// serves all five planes (min_i (f_i - m S) = min_i f_i - m S: the per-point tests below need one subtraction instead of five fused
+// multiply-adds).
 
 // Cluster test, in fp32 with conservative margins.  The axis-aligned box (centre c, half extents h) of a cluster, moved by
 // the iterate (R, t), lies strictly on one side of plane i iff |f_i(Rc + t)| > sum_j |(n_i^T R)_j| h_j  (support function of
 // the rotated box).  The fp32 evaluation decides only when it clears that bound by
-//     1e-5 * support + 4e-6 * |n_i|_1 * (|c|_1 + |h|_1 + |t|_1)
-// (>= 8x the worst-case rounding of the fp32 evaluation, see the pre-filter below); anything closer is "undecided" and goes
+//     1e-5 * support + 4e-6 * (|c|_1 + |h|_1 + |t|_1)
+// (>= 7x the worst-case rounding of the fp32 evaluation, see the pre-filter below); anything closer is "undecided" and goes
 // to the per-point path, which is always right.  If ALL five planes are decided, every point of the cluster has the sign
 // pattern of the centre, none of dx, dy, p2 is zero or non-finite, and the per-point classification is known:
 //   label 1: inactive iff all five are positive, else every point is active;
@@ -522,18 +531,18 @@ struct alignas(16) BoxAbs {        // per sweep: |n_i^T R|_j * (1 + 1e-5) of the
 };
 // fp32 PRE-FILTER of the per-point classification (phase A).  The exact test costs ~55 fp64 instructions per 64 points
 // (rotation, reciprocal, projection, pixel-form comparisons); most points it is run on are nowhere near a frustum plane.
-// Here the five plane functions f_i(p) = n_i . (R x + t) are evaluated in fp32 and compared with a margin
-//   m_i = 4e-6 * |n_i|_1 * (|x|_1 + |t|_1),
-// >= 8x the worst-case fp32 evaluation error (inputs rounded to fp32, <= 5 roundings per coordinate, <= 3 per plane:
-// <= 8 * 2^-24 * |n_i|_1 * (|x|_1 + |t|_1)).  A point whose five |f_i| all exceed their margins has, in exact arithmetic,
+// Here the five normalised plane functions f_i(p) = n_i . (R x + t) are evaluated in fp32 and compared with the margin
+//   m S,  m = 4e-6,  S = |x|_1 + |t|_1,
+// >= 7x the worst-case fp32 evaluation error (inputs and normalised coefficients rounded to fp32, <= 5 roundings per coordinate,
+// <= 3 per plane: <= 9 * 2^-24 * (|x|_1 + |t|_1)).  A point whose five |f_i| all exceed the margin has, in exact arithmetic,
 // pixel coordinates at least 3e-6 * fx away from 0 / W-1 / H-1 and |p2| > 3e-6 * |p|, five orders of magnitude above the
 // rounding of the fp64 pixel-form test: its classification is the exact test's and none of dx, dy, p2 is zero or non-finite.
 // If ANY lane of a cluster is not certified, the whole cluster takes the exact fp64 path, so the active set -- and every
 // sum -- is bit-identical with and without the pre-filter (DI2P_SOLVER_NOPREFILTER=1; tests compare).
+constexpr float kPreRel = 4e-6f;
 struct Pre32 {
     float R[9], t[3], T1;
-    float fx, cx, wcx, fy, cy, hcy;
-    float mL, mR, mT, mB, mZ;
+    float aL, bL, aR, bR, aT, bT, aB, bB;      // f_L = aL p0 + bL p2, f_R = -aR p0 + bR p2, f_T = aT p1 + bT p2, f_B = -aB p1 + bB p2
 };
 template <int NP>
 __device__ __forceinline__ void make_pre32(const Rot<NP>& rot, double tx, double ty, double tz, const Cam& k, Pre32& q) {
@@ -541,21 +550,24 @@ __device__ __forceinline__ void make_pre32(const Rot<NP>& rot, double tx, double
     for (int i = 0; i < 9; ++i) q.R[i] = (float)rot.R[i];
     q.t[0] = (float)tx; q.t[1] = (float)ty; q.t[2] = (float)tz;
     q.T1 = (fabsf(q.t[0]) + fabsf(q.t[1]) + fabsf(q.t[2])) * 1.000001f;
-    q.fx = (float)k.fx; q.cx = (float)k.cx; q.wcx = (float)(k.W1 - k.cx);
-    q.fy = (float)k.fy; q.cy = (float)k.cy; q.hcy = (float)(k.H1 - k.cy);
-    const float rel = 4e-6f;
-    q.mL = rel * (fabsf(q.fx) + fabsf(q.cx)); q.mR = rel * (fabsf(q.fx) + fabsf(q.wcx));
-    q.mT = rel * (fabsf(q.fy) + fabsf(q.cy)); q.mB = rel * (fabsf(q.fy) + fabsf(q.hcy));
-    q.mZ = rel;
+    const float fx = (float)k.fx, cx = (float)k.cx, wcx = (float)(k.W1 - k.cx), fy = (float)k.fy, cy = (float)k.cy, hcy = (float)(k.H1 - k.cy);
+    const float iL = 1.0f / (fabsf(fx) + fabsf(cx)), iR = 1.0f / (fabsf(fx) + fabsf(wcx));
+    const float iT = 1.0f / (fabsf(fy) + fabsf(cy)), iB = 1.0f / (fabsf(fy) + fabsf(hcy));
+    q.aL = fx * iL; q.bL = cx * iL; q.aR = fx * iR; q.bR = wcx * iR;
+    q.aT = fy * iT; q.bT = cy * iT; q.aB = fy * iB; q.bB = hcy * iB;
     // wave-uniform by construction: keep the whole table in SGPRs (it is live across the cluster loop)
     float* f = reinterpret_cast<float*>(&q);
 #pragma unroll
     for (int i = 0; i < (int)(sizeof(Pre32) / sizeof(float)); ++i) f[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, f[i])));
 }
-// -> act (valid only when !uncertain).  NaN / inf anywhere fails every comparison -> uncertain.
+// -> act, and the point's SLACK: how far (normalised plane units = metres of displacement of the point, |.|_inf) the point is, beyond the
+// margin, from changing its classification -- label 1: |min_i f_i| - m S (an inside point: the nearest plane; an outside point: its most
+// negative plane, which keeps it active whatever the others do); label 0: min_i |f_i| - m S (EVERY plane: an exact zero on any of them is an
+// evaluation failure in the reference).  slack > 0 <=> the point is certified (act is then the exact test's answer); NaN / inf anywhere
+// fails that comparison.
 template <int NP, int LAB>
-__device__ __forceinline__ void prefilter32(const Pre32& q, float X, float Y, float Z, bool& act, bool& uncertain) {
-    const float S = (fabsf(X) + fabsf(Y)) + (fabsf(Z) + q.T1);
+__device__ __forceinline__ void prefilter32(const Pre32& q, float X, float Y, float Z, bool& act, float& slack) {
+    const float mS = kPreRel * ((fabsf(X) + fabsf(Y)) + (fabsf(Z) + q.T1));
     float p0, p1, p2;
     if (NP == 4) {
         p0 = fmaf(q.R[0], X, fmaf(q.R[2], Z, q.t[0])); p1 = Y + q.t[1]; p2 = fmaf(q.R[6], X, fmaf(q.R[8], Z, q.t[2]));
@@ -564,50 +576,35 @@ __device__ __forceinline__ void prefilter32(const Pre32& q, float X, float Y, fl
         p1 = fmaf(q.R[3], X, fmaf(q.R[4], Y, fmaf(q.R[5], Z, q.t[1])));
         p2 = fmaf(q.R[6], X, fmaf(q.R[7], Y, fmaf(q.R[8], Z, q.t[2])));
     }
-    const float fL = fmaf(q.fx, p0, q.cx * p2), fR = fmaf(-q.fx, p0, q.wcx * p2);
-    const float fT = fmaf(q.fy, p1, q.cy * p2), fB = fmaf(-q.fy, p1, q.hcy * p2);
-    // all five certified positive  <=>  min_i (f_i - m_i S) > 0
-    const float lo = fminf(fminf(fminf(fmaf(-q.mL, S, fL), fmaf(-q.mR, S, fR)), fminf(fmaf(-q.mT, S, fT), fmaf(-q.mB, S, fB))), fmaf(-q.mZ, S, p2));
-    const bool inside = lo > 0.0f;
+    const float fL = fmaf(q.aL, p0, q.bL * p2), fR = fmaf(-q.aR, p0, q.bR * p2);
+    const float fT = fmaf(q.aT, p1, q.bT * p2), fB = fmaf(-q.aB, p1, q.bB * p2);
+    const float mn = fminf(fminf(fminf(fL, fR), fT), fminf(fB, p2));       // two v_min3_f32
     if (LAB == 1) {
-        // some plane certified negative  <=>  min_i (f_i + m_i S) < 0  -> active whatever the other planes say
-        const float hi = fminf(fminf(fminf(fmaf(q.mL, S, fL), fmaf(q.mR, S, fR)), fminf(fmaf(q.mT, S, fT), fmaf(q.mB, S, fB))), fmaf(q.mZ, S, p2));
-        const bool outside = hi < 0.0f;
-        act = outside;
-        uncertain = !(inside || outside);
+        act = mn < 0.0f;                       // some plane negative -> active (certified iff slack > 0)
+        slack = fabsf(mn) - mS;
     } else {
-        // label 0 needs EVERY plane certified (an exact zero on any of them is an evaluation failure in the reference)
-        const float cm = fminf(fminf(fminf(fmaf(-q.mL, S, fabsf(fL)), fmaf(-q.mR, S, fabsf(fR))), fminf(fmaf(-q.mT, S, fabsf(fT)), fmaf(-q.mB, S, fabsf(fB)))),
-                               fmaf(-q.mZ, S, fabsf(p2)));
-        act = inside;
-        uncertain = !(cm > 0.0f);
+        const float ma = fminf(fminf(fminf(fabsf(fL), fabsf(fR)), fabsf(fT)), fminf(fabsf(fB), fabsf(p2)));
+        act = mn > 0.0f;                       // all five positive -> active
+        slack = ma - mS;
     }
 }
 
-// Zero-guard of a label-0 point that is known to be inactive: true unless every |f_i| clears its margin.
-template <int NP>
-__device__ __forceinline__ bool zero_guard32(const Pre32& q, float X, float Y, float Z) {
-    bool act, unc;
-    prefilter32<NP, 0>(q, X, Y, Z, act, unc);
-    return unc;
-}
-
-// The box-test table of an iterate, from the pre-filter's table (same fp32 R, t, intrinsics and margin factors).
+// The box-test table of an iterate, from the pre-filter's table (same fp32 R, t and normalised plane coefficients).
 __device__ __forceinline__ void make_box_abs(const Pre32& p, BoxAbs& q) {
     const float g = 1.0f + 1e-5f;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {      // (n^T R)_j = a R0j + b R1j + c R2j
-        q.aL[j] = fabsf(p.fx * p.R[j] + p.cx * p.R[6 + j]) * g;
-        q.aR[j] = fabsf(-p.fx * p.R[j] + p.wcx * p.R[6 + j]) * g;
-        q.aT[j] = fabsf(p.fy * p.R[3 + j] + p.cy * p.R[6 + j]) * g;
-        q.aB[j] = fabsf(-p.fy * p.R[3 + j] + p.hcy * p.R[6 + j]) * g;
+        q.aL[j] = fabsf(p.aL * p.R[j] + p.bL * p.R[6 + j]) * g;
+        q.aR[j] = fabsf(-p.aR * p.R[j] + p.bR * p.R[6 + j]) * g;
+        q.aT[j] = fabsf(p.aT * p.R[3 + j] + p.bT * p.R[6 + j]) * g;
+        q.aB[j] = fabsf(-p.aB * p.R[3 + j] + p.bB * p.R[6 + j]) * g;
         q.aZ[j] = fabsf(p.R[6 + j]) * g;
     }
     q.T1 = fabsf(p.t[0]) + fabsf(p.t[1]) + fabsf(p.t[2]);
 }
 template <int NP, int LAB>
 __device__ __forceinline__ int cluster_status(const Box& bx, const Pre32& q, const BoxAbs& ab) {
-    const float S = ((fabsf(bx.cx) + fabsf(bx.cy)) + (fabsf(bx.cz) + ab.T1)) + ((bx.hx + bx.hy) + bx.hz);
+    const float mS = kPreRel * (((fabsf(bx.cx) + fabsf(bx.cy)) + (fabsf(bx.cz) + ab.T1)) + ((bx.hx + bx.hy) + bx.hz));
     float p0, p1, p2;
     if (NP == 4) {
         p0 = fmaf(q.R[0], bx.cx, fmaf(q.R[2], bx.cz, q.t[0])); p1 = bx.cy + q.t[1]; p2 = fmaf(q.R[6], bx.cx, fmaf(q.R[8], bx.cz, q.t[2]));
@@ -616,10 +613,10 @@ __device__ __forceinline__ int cluster_status(const Box& bx, const Pre32& q, con
         p1 = fmaf(q.R[3], bx.cx, fmaf(q.R[4], bx.cy, fmaf(q.R[5], bx.cz, q.t[1])));
         p2 = fmaf(q.R[6], bx.cx, fmaf(q.R[7], bx.cy, fmaf(q.R[8], bx.cz, q.t[2])));
     }
-    const float fL = fmaf(q.fx, p0, q.cx * p2), fR = fmaf(-q.fx, p0, q.wcx * p2);
-    const float fT = fmaf(q.fy, p1, q.cy * p2), fB = fmaf(-q.fy, p1, q.hcy * p2);
-    auto bound = [&](const float* a, float m) { return fmaf(a[0], bx.hx, fmaf(a[1], bx.hy, fmaf(a[2], bx.hz, m * S))); };
-    const float tL = bound(ab.aL, q.mL), tR = bound(ab.aR, q.mR), tT = bound(ab.aT, q.mT), tB = bound(ab.aB, q.mB), tZ = bound(ab.aZ, q.mZ);
+    const float fL = fmaf(q.aL, p0, q.bL * p2), fR = fmaf(-q.aR, p0, q.bR * p2);
+    const float fT = fmaf(q.aT, p1, q.bT * p2), fB = fmaf(-q.aB, p1, q.bB * p2);
+    auto bound = [&](const float* a) { return fmaf(a[0], bx.hx, fmaf(a[1], bx.hy, fmaf(a[2], bx.hz, mS))); };
+    const float tL = bound(ab.aL), tR = bound(ab.aR), tT = bound(ab.aT), tB = bound(ab.aB), tZ = bound(ab.aZ);
     // all five decided positive <=> min_i (f_i - t_i) > 0 ; all five decided <=> min_i (|f_i| - t_i) > 0
     const float lo = fminf(fminf(fminf(fL - tL, fR - tR), fminf(fT - tT, fB - tB)), p2 - tZ);
     const float cm = fminf(fminf(fminf(fabsf(fL) - tL, fabsf(fR) - tR), fminf(fabsf(fT) - tT, fabsf(fB) - tB)), fabsf(p2) - tZ);
@@ -634,22 +631,66 @@ __device__ __forceinline__ int cluster_status(const Box& bx, const Pre32& q, con
     return 1;
 }
 
+// Wave-wide minima of FOUR non-negative floats (or +inf) at once, by DPP (no LDS round trip): four joins inside rows of 16 lanes, then
+// row_bcast15 / row_bcast31 carry the row results into lane 63, which is read back as a scalar.  Non-negative floats order like their bit
+// patterns, so the joins are v_min_u32 with the DPP modifier ON the instruction -- written as one asm block because hipcc expands
+// fminf(v, dpp(v)) into mov + mov_dpp + canonicalise + min (24 instructions per value instead of 6).  The four values are interleaved: three
+// independent instructions separate a value's consecutive joins, which covers the two wait states a DPP read needs after a VALU write.
+__device__ __forceinline__ void wave_min4_nonneg(float& a, float& b, float& c, float& d) {
+#define DI2P_MIN4(CTRL)                                \
+    "v_min_u32_dpp %0, %0, %0 " CTRL "\n\t"           \
+    "v_min_u32_dpp %1, %1, %1 " CTRL "\n\t"           \
+    "v_min_u32_dpp %2, %2, %2 " CTRL "\n\t"           \
+    "v_min_u32_dpp %3, %3, %3 " CTRL "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 DI2P_MIN4("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 DI2P_MIN4("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 DI2P_MIN4("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 DI2P_MIN4("row_mirror row_mask:0xf bank_mask:0xf")
+                 DI2P_MIN4("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 DI2P_MIN4("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef DI2P_MIN4
+    a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
+    b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 63));
+    c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), 63));
+    d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), 63));
+}
+
+// CLASSIFICATION CACHE (temporal coherence of the cluster walk).  Between two sweeps of a hypothesis the iterate moves little (line-search
+// trials along one step, LM steps that shrink towards the minimum), while a cluster that needs per-point work needs it sweep after sweep
+// because a frustum plane passes through its box.  When a cluster IS classified per point, the wave also takes the minimum of the points'
+// slacks (prefilter32) and records {active mask, slack, sweep number} per hypothesis and cluster (16 bytes, global memory, L2 resident); the
+// iterates of the last RING sweeps stay in LDS.  A later sweep moves every point of the cluster by at most
+//     mu = |d theta| * r + |d t|_inf        (r = the cluster's largest ground-plane radius; 3-D solver: |d w|_1 * largest norm)
+// against the recorded iterate, and a displacement d changes every normalised plane function by at most |d|_inf.  While
+// slack > 1.0001 mu + 1e-6 every point keeps its certified sign pattern with room to spare (>= 1e-6 m beyond the margin, nine orders above the
+// rounding of the fp64 test): the recorded mask IS the classification, and no point sits on a plane.  A hit costs the walk one append
+// (status 4) or nothing at all (guard-only clusters); the active sequence -- hence every sum -- is bit-identical with the cache off
+// (DI2P_SOLVER_NOCACHE=1) and with the cluster test off (tests and tools/fuzz_solver_cull.py compare).  Measured on the oracle's iterate
+// traces (tools/model_temporal.py): 70 % of the per-point classifications and 61 % of the guard walks hit.
+struct __attribute__((aligned(16))) CacheEnt { unsigned mlo, mhi; float slack; unsigned stamp; };      // stamp = sweep number + 1, 0 = empty
+constexpr int RING = 8;            // iterates kept in LDS (power of two)
+constexpr int CACHE_PAD = 32;      // per hypothesis: NCMAX + CACHE_PAD entries (each label block is rounded up to a multiple of WPH clusters)
+
 // One label-uniform block of records [recs, recs+cnt) = nc clusters of CL records.  Cluster c belongs to wave
 // c % WPH (neighbouring clusters -- which tend to share their status -- spread over the waves).  Per round a lane
-// tests one cluster; the wave then walks the flagged ones:
-//   status 1 -> phase A (exact fp64 classification with the reference's pixel-form conditions) on its 64 records,
-//   status 2 -> all 64 records are active.
-// Active ids go to the per-wave LDS queue and are evaluated densely (phase B) 64 at a time.  The queue sequence is the
-// same as if every cluster had been classified per point, so the sums are bit-identical to the unculled sweep
-// (nocull != 0 forces status 1 everywhere: tests compare the two).
+// tests one cluster (box test, then the classification cache); the wave then
+//   phase I : classifies the clusters that need it -- status 1: fp32 pre-filter (exact fp64 test with the reference's pixel-form
+//             conditions for a cluster with an uncertified record) -> active mask + slack into the lane that owns the cluster;
+//             status 3: zero guard only -> slack -- and records them in the cache;
+//   phase II: appends the active ids of the status 1 / 2 (all active) / 4 (cached mask) clusters to the per-wave LDS queue IN CLUSTER
+//             ORDER; the queue is evaluated densely (phase B) 64 records at a time.
+// The queue sequence is the same as if every cluster had been classified per point, so the sums are bit-identical to the unculled
+// sweep (nocull bit 0 forces status 1 everywhere, bit 1 the exact test, bit 2 switches the cache off: tests compare).
 template <int NP, typename PT, int WPH, int LAB, int MODE, bool PROFILE>
 __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs, int cnt, const Box* __restrict__ boxes, int nc,
                                                const Cam& k, const double* x, const Rot<NP>& rot, int nocull,
-                                               int* queue, double (*acc)[64], int* acc_e, const Pre32& pre, const float* btest_lds, bool& bad, int* n_active, long long* tp) {
+                                               int* queue, double (*acc)[64], int* acc_e, const Pre32& pre, const float* btest_lds,
+                                               CacheEnt* __restrict__ cache, const double* ring, int s_now, bool& bad, int* n_active, long long* tp) {
     constexpr int TOFF = NP == 4 ? 1 : 3;
     const double tx = x[TOFF], ty = x[TOFF + 1], tz = x[TOFF + 2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // the wave index as a SCALAR
     const double hw = k.W1 * 0.5, hh = k.H1 * 0.5;
     int qn = 0;  // wave-uniform
     // A cluster's 64 records: one load per lane at (wave-uniform cluster base) + (lane offset).  Label blocks are cluster-aligned and padded
@@ -713,13 +754,22 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
         return valid && dx > 0.0 && dy > 0.0 && p2 > 0.0;
     };
     const bool use_pre = (nocull & 2) == 0;
+    const bool use_cache = (nocull & 5) == 0;            // the cache rides on the cluster test
     nocull &= 1;
     const int mine = (nc - wave + WPH - 1) / WPH;        // clusters wave, wave+WPH, ... < nc
+    CacheEnt* cache_w = cache + wave * ((nc + WPH - 1) / WPH);      // the wave's entries are consecutive: lane j <-> its j-th cluster
+    constexpr int PF = DI2P_SOLVER_PF;
+    auto take_bit = [](unsigned long long& m) { int b = -1; if (m) { b = (int)__builtin_ctzll(m); m &= m - 1; } return b; };
+    const unsigned bit_lo = lane < 32 ? 1u << lane : 0u, bit_hi = lane >= 32 ? 1u << (lane - 32) : 0u;
     for (int j0 = 0; j0 < mine; j0 += 64) {
         const long long ts0 = PROFILE ? clock64() : 0;
         const int j = j0 + lane;
         int status = 0;
+        unsigned mlo = 0u, mhi = 0u;      // active mask of the lane's cluster (status 4: cached, 2: its valid records, 1: filled in by phase I)
+        float slack = 0.0f;               // min slack of the lane's cluster (phase I)
+        bool cached_guard = false;
         if (j < mine) {
+            const int c = j * WPH + wave;
             if (nocull) {
                 status = 1;
             } else {
@@ -731,102 +781,149 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                 float4* dst4 = reinterpret_cast<float4*>(&ab);
 #pragma unroll
                 for (int i = 0; i < (int)(sizeof(BoxAbs) / 16); ++i) dst4[i] = bt4[i];
-                status = cluster_status<NP, LAB>(boxes[j * WPH + wave], pre, ab);
-            }
-        }
-        const unsigned long long mA = __ballot(status == 1), mB = __ballot(status == 2), mC = __ballot(status == 3);
-        if (PROFILE) { n_active[1] += __popcll(mA); n_active[2] += __popcll(mB); n_active[3] += __popcll(mC); tp[0] += clock64() - ts0; }
-        // The flagged clusters are walked FOUR AT A TIME in straight-line code (a cluster's 64 records are one 16-byte load per lane):
-        // the four pre-filters are independent instruction streams, ONE wave-wide vote covers the "some lane is not certified" test
-        // of all four, and the records of the next four are in flight meanwhile.  Walked one by one (round 2) a cluster cost ~600
-        // cycles of dependent latency -- load, pre-filter, two votes, two scalar branches -- for ~40 instructions of work.
-        constexpr int PF = DI2P_SOLVER_PF;
-        auto take_bit = [](unsigned long long& m) { int b = -1; if (m) { b = (int)__builtin_ctzll(m); m &= m - 1; } return b; };
-        if (LAB == 0 && mC) {
-            // (1) zero-guard-only clusters (status 3): no point is active, nothing is queued; only an exact zero / non-finite value on
-            // an undecided plane must be found (sets `bad`).  Order does not matter, so the "not certified" flags of ALL of them are
-            // OR-ed per lane and voted on ONCE; the (practically never taken) slow path then repeats the list with the exact test.
-            unsigned uncb = 0;           // per lane: bit k = some record of this lane in batch k is not certified (<= 16 batches per round)
-            {
-                unsigned long long mg = mC;
-                int nb[PF];
-                Rec<PT> ring[PF];
-#pragma unroll
-                for (int u = 0; u < PF; ++u) { nb[u] = take_bit(mg); ring[u] = load_rec((j0 + nb[u]) * WPH + wave); }
-                for (unsigned batch = 1; nb[0] >= 0; batch <<= 1) {
-                    bool unc = false;
-#pragma unroll
-                    for (int u = 0; u < PF; ++u) {
-                        const Rec<PT> cur = ring[u];
-                        const bool valid = nb[u] >= 0 && ((j0 + nb[u]) * WPH + wave) * CL + lane < cnt;      // exhausted slots / padding lanes
-                        nb[u] = take_bit(mg);
-                        ring[u] = load_rec((j0 + nb[u]) * WPH + wave);
-                        const bool g = !use_pre | zero_guard32<NP>(pre, (float)cur.x, (float)cur.y, (float)cur.z);     // no short circuit: branch-free
-                        unc = unc | (valid & g);
+                const Box bx = boxes[c];
+                CacheEnt e;                                     // fetched together with the box, whatever the box test will say
+                e.mlo = e.mhi = 0u; e.slack = 0.0f; e.stamp = 0u;
+                if (use_cache) e = cache_w[j];
+                status = cluster_status<NP, LAB>(bx, pre, ab);
+                if (use_cache && (status == 1 || status == 3)) {
+                    const unsigned age = (unsigned)s_now + 1u - e.stamp;               // e.stamp <= s_now + 1
+                    const double* xr = ring + ((e.stamp - 1u) & (unsigned)(RING - 1)) * NP;
+                    float mu;
+                    if (NP == 4) {
+                        const double dth = fabs(x[0] - xr[0]);
+                        const double dt = fmax(fmax(fabs(x[1] - xr[1]), fabs(x[2] - xr[2])), fabs(x[3] - xr[3]));
+                        mu = fmaf((float)dth, bx.rxz, (float)dt);
+                    } else {
+                        const double dth = (fabs(x[0] - xr[0]) + fabs(x[1] - xr[1])) + fabs(x[2] - xr[2]);     // >= |d w|_2
+                        const double dt = fmax(fmax(fabs(x[3] - xr[3]), fabs(x[4] - xr[4])), fabs(x[5] - xr[5]));
+                        mu = fmaf((float)dth, bx.r3, (float)dt);
                     }
-                    uncb |= unc ? batch : 0u;
-                }
-            }
-            if (__any(uncb != 0)) {      // rare: some record the fp32 guard cannot certify -> exact test of the clusters of ITS batch only
-                unsigned long long mg = mC;
-                for (unsigned batch = 1; mg; batch <<= 1) {
-                    const bool hit = __any((uncb & batch) != 0);        // wave-uniform
-#pragma unroll 1
-                    for (int u = 0; u < PF; ++u) {
-                        const int b = take_bit(mg);
-                        if (b >= 0 && hit) {
-                            const int c = (j0 + b) * WPH + wave;
-                            (void)exact_active(load_rec(c), c * CL + lane < cnt);      // sets `bad` on a zero
+                    const float need = fmaf(1.0001f, mu, 1e-6f);
+                    if (e.stamp != 0u && age < (unsigned)RING && e.slack > need) {       // NaN fails
+                        cached_guard = status == 3;
+                        status = status == 3 ? 0 : 4;
+                        mlo = e.mlo; mhi = e.mhi;
+                        if (age >= (unsigned)(RING / 2)) {
+                            // still valid but about to leave the ring: re-record against THIS iterate with what is left of the slack
+                            CacheEnt ne;
+                            ne.mlo = e.mlo; ne.mhi = e.mhi; ne.slack = (e.slack - need) * 0.99999f; ne.stamp = (unsigned)s_now + 1u;
+                            cache_w[j] = ne;
                         }
                     }
                 }
             }
+            if (status == 2) {       // all active: the cluster's valid records
+                const int nv = min(cnt - c * CL, CL);
+                mlo = nv >= 32 ? ~0u : ((1u << nv) - 1u);
+                mhi = nv >= 64 ? ~0u : (nv > 32 ? ((1u << (nv - 32)) - 1u) : 0u);
+            }
         }
-        {
-            // (2) clusters classified per point (status 1) and all-active clusters (status 2), in cluster order: their active ids are
-            // appended to the queue in the order a per-point classification of every cluster would produce
-            unsigned long long mo = mA | mB;
+        const unsigned long long mA = __ballot(status == 1), mB = __ballot(status == 2), mC = __ballot(status == 3), mD = __ballot(status == 4);
+        if (PROFILE) {
+            n_active[1] += __popcll(mA); n_active[2] += __popcll(mB); n_active[3] += __popcll(mC);
+            n_active[4] += __popcll(mD); n_active[5] += __popcll(__ballot(cached_guard));
+            tp[0] += clock64() - ts0;
+        }
+        // ---- phase I.  The flagged clusters are walked PF AT A TIME in straight-line code (a cluster's 64 records are one 16-byte load per
+        // lane): the pre-filters are independent instruction streams and the records of the next PF are in flight meanwhile.
+        if (LAB == 0 && mC) {
+            // (a) zero-guard-only clusters (status 3): no point is active; only an exact zero / non-finite value on an undecided plane must
+            // be found (sets `bad`).  The cluster's min slack says both whether every record is certified (> 0) and for how long.
+            unsigned long long mg = mC;
             int nb[PF];
-            Rec<PT> ring[PF];
+            Rec<PT> ring_r[PF];
 #pragma unroll
-            for (int u = 0; u < PF; ++u) { nb[u] = take_bit(mo); ring[u] = load_rec((j0 + nb[u]) * WPH + wave); }
+            for (int u = 0; u < PF; ++u) { nb[u] = take_bit(mg); ring_r[u] = load_rec((j0 + nb[u]) * WPH + wave); }
             while (nb[0] >= 0) {
-                while (nb[0] >= 0 && qn <= QCAP - PF * 64) {
-                    Rec<PT> cur[PF];
-                    int cid[PF];
-                    bool valid[PF], isA[PF], act[PF], unc[PF];
+                float sm[PF];
+                int nbp[PF];
+                Rec<PT> cur[PF];
 #pragma unroll
-                    for (int u = 0; u < PF; ++u) {
-                        cur[u] = ring[u];
-                        cid[u] = (j0 + nb[u]) * WPH + wave;
-                        valid[u] = nb[u] >= 0 && cid[u] * CL + lane < cnt;
-                        isA[u] = nb[u] >= 0 && ((mA >> (nb[u] & 63)) & 1ull);                  // wave-uniform
-                        nb[u] = take_bit(mo);
-                        ring[u] = load_rec((j0 + nb[u]) * WPH + wave);
-                    }
-                    bool any_unc = false;
+                for (int u = 0; u < PF; ++u) {
+                    cur[u] = ring_r[u];
+                    nbp[u] = nb[u];
+                    const bool valid = nb[u] >= 0 && ((j0 + nb[u]) * WPH + wave) * CL + lane < cnt;      // exhausted slots / padding lanes
+                    nb[u] = take_bit(mg);
+                    ring_r[u] = load_rec((j0 + nb[u]) * WPH + wave);
+                    bool a;
+                    float sl;
+                    prefilter32<NP, 0>(pre, (float)cur[u].x, (float)cur[u].y, (float)cur[u].z, a, sl);
+                    sl = (use_pre && sl > 0.0f) ? sl : 0.0f;                    // not certified (or NaN) -> 0
+                    sm[u] = valid ? sl : __builtin_inff();
+                }
+                static_assert(PF == 4, "wave_min4_nonneg joins four values");
+                wave_min4_nonneg(sm[0], sm[1], sm[2], sm[3]);
 #pragma unroll
-                    for (int u = 0; u < PF; ++u) {          // no short circuits: four independent, branch-free instruction streams
-                        bool pa = true, pu = true;
-                        prefilter32<NP, LAB>(pre, (float)cur[u].x, (float)cur[u].y, (float)cur[u].z, pa, pu);
-                        pa = pa | !use_pre; pu = pu | !use_pre;
-                        act[u] = valid[u] & (!isA[u] | pa);               // status 2: every (valid) record is active
-                        unc[u] = valid[u] & isA[u] & pu;
-                        any_unc = any_unc | unc[u];
-                    }
-                    if (__any(any_unc)) {        // rare: some lane of some cluster is not certified -> exact test for THAT cluster
-#pragma unroll
-                        for (int u = 0; u < PF; ++u)
-                            if (__any(unc[u])) act[u] = exact_active(cur[u], valid[u]);
-                    }
-#pragma unroll
-                    for (int u = 0; u < PF; ++u) {      // exhausted slots: act is false on every lane, the append is a no-op
-                        const unsigned long long bal = __ballot(act[u]);
-                        if (act[u]) queue[qn + __popcll(bal & lt)] = cid[u] * CL + lane;
-                        qn += __popcll(bal);
+                for (int u = 0; u < PF; ++u) {
+                    if (nbp[u] >= 0) {              // wave-uniform
+                        if (!(sm[u] > 0.0f)) {      // rare: some record the fp32 guard cannot certify -> exact test of this cluster
+                            const int c = (j0 + nbp[u]) * WPH + wave;
+                            (void)exact_active(cur[u], c * CL + lane < cnt);       // sets `bad` on a zero
+                        }
+                        slack = lane == nbp[u] ? sm[u] : slack;            // into the lane that owns the cluster
                     }
                 }
-                if (nb[0] >= 0) drain(false);      // queue nearly full: evaluate the full rounds, keep the remainder queued
+            }
+        }
+        if (mA) {
+            // (b) clusters classified per point (status 1)
+            unsigned long long mo = mA;
+            int nb[PF];
+            Rec<PT> ring_r[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) { nb[u] = take_bit(mo); ring_r[u] = load_rec((j0 + nb[u]) * WPH + wave); }
+            while (nb[0] >= 0) {
+                Rec<PT> cur[PF];
+                int nbp[PF];
+                bool valid[PF], act[PF];
+                float sm[PF];
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    cur[u] = ring_r[u];
+                    nbp[u] = nb[u];
+                    valid[u] = nb[u] >= 0 && ((j0 + nb[u]) * WPH + wave) * CL + lane < cnt;
+                    nb[u] = take_bit(mo);
+                    ring_r[u] = load_rec((j0 + nb[u]) * WPH + wave);
+                }
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {          // no short circuits: PF independent, branch-free instruction streams
+                    bool a;
+                    float sl;
+                    prefilter32<NP, LAB>(pre, (float)cur[u].x, (float)cur[u].y, (float)cur[u].z, a, sl);
+                    sl = (use_pre && sl > 0.0f) ? sl : 0.0f;
+                    act[u] = valid[u] & a;
+                    sm[u] = valid[u] ? sl : __builtin_inff();
+                }
+                wave_min4_nonneg(sm[0], sm[1], sm[2], sm[3]);
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    if (nbp[u] >= 0) {              // wave-uniform
+                        if (!(sm[u] > 0.0f)) act[u] = exact_active(cur[u], valid[u]);        // rare: some record is not certified -> exact test for THAT cluster
+                        const unsigned long long bal = __ballot(act[u]);
+                        mlo = lane == nbp[u] ? (unsigned)bal : mlo;
+                        mhi = lane == nbp[u] ? (unsigned)(bal >> 32) : mhi;
+                        slack = lane == nbp[u] ? sm[u] : slack;            // into the lane that owns the cluster
+                    }
+                }
+            }
+        }
+        if (use_cache && (status == 1 || status == 3)) {       // what phase I found, one entry per lane
+            CacheEnt ne;
+            ne.mlo = mlo; ne.mhi = mhi; ne.slack = slack; ne.stamp = (unsigned)s_now + 1u;
+            cache_w[j] = ne;
+        }
+        // ---- phase II: the active ids of the round, in cluster order
+        {
+            unsigned long long mo = mA | mB | mD;
+            while (mo) {
+                const int b = (int)__builtin_ctzll(mo);
+                mo &= mo - 1;
+                if (qn > QCAP - 64) drain(false);      // queue nearly full: evaluate the full rounds, keep the remainder queued
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)mlo, b), hi = (unsigned)__builtin_amdgcn_readlane((int)mhi, b);
+                const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+                if (((lo & bit_lo) | (hi & bit_hi)) != 0u) queue[pos] = ((j0 + b) * WPH + wave) * CL + lane;
+                qn += __builtin_popcount(lo) + __builtin_popcount(hi);
             }
         }
     }
@@ -848,7 +945,8 @@ template <int CTRL> __device__ __forceinline__ double dpp_double(double v) {
 // specialised loops.
 template <int NP, typename PT, int WPH, int MODE, bool PROFILE>
 __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Box* __restrict__ boxes, int cnt1, int cnt0, int nc1,
-                                     int nc0, const Cam& k, const double* x, int nocull, SweepShared<NP, WPH>& sh, int* n_active, long long* tp) {
+                                     int nc0, const Cam& k, const double* x, int nocull, SweepShared<NP, WPH>& sh, CacheEnt* __restrict__ cache, int s_now,
+                                     int* n_active, long long* tp) {
     constexpr int NV = Tri<NP>::N + NP + 2;
     const long long tq0 = PROFILE ? clock64() : 0;
     constexpr int TOFF = NP == 4 ? 1 : 3;
@@ -881,8 +979,12 @@ __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Bo
     __builtin_amdgcn_wave_barrier();
     bool bad = false;
     if (PROFILE) tp[2] += clock64() - tq0;          // set-up: rotation, fp32 tables, zeroed sums
-    sweep_clusters<NP, PT, WPH, 1, MODE, PROFILE>(recs, cnt1, boxes, nc1, k, x, rot, nocull, queue, acc, acc_e, pre, sh.btest[wave], bad, n_active, tp);
-    sweep_clusters<NP, PT, WPH, 0, MODE, PROFILE>(recs + nc1 * CL, cnt0, boxes + nc1, nc0, k, x, rot, nocull, queue, acc, acc_e, pre, sh.btest[wave], bad, n_active, tp);
+    static_assert(RING == 8, "SweepShared::ring holds RING iterates");
+    const double* ring = &sh.ring[0][0];
+    // the label-0 block's cache entries follow the label-1 block's (each block rounded up to a multiple of WPH clusters)
+    sweep_clusters<NP, PT, WPH, 1, MODE, PROFILE>(recs, cnt1, boxes, nc1, k, x, rot, nocull, queue, acc, acc_e, pre, sh.btest[wave], cache, ring, s_now, bad, n_active, tp);
+    sweep_clusters<NP, PT, WPH, 0, MODE, PROFILE>(recs + nc1 * CL, cnt0, boxes + nc1, nc0, k, x, rot, nocull, queue, acc, acc_e, pre, sh.btest[wave],
+                                                  cache + WPH * ((nc1 + WPH - 1) / WPH), ring, s_now, bad, n_active, tp);
     __builtin_amdgcn_wave_barrier();
     const long long tq1 = PROFILE ? clock64() : 0;
     // Wave totals of the 1 + NP + tri running values, read back from LDS TRANSPOSED: 16 lanes per value (4 values per round), each
@@ -1384,6 +1486,7 @@ struct SolveArgs {
     long long* prof;
     unsigned long long* state_buf;
     int* pending;
+    CacheEnt* cache;           // classification cache: [F * R][NCMAX + CACHE_PAD]
     double H, W;
     Bounds bnd;
     int NCMAX, nocull, max_iter, F, R, N, budget, resume;
@@ -1412,6 +1515,9 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
     const Cam k{Kf[0], Kf[4], Kf[2], Kf[5], a->H - 1.0, a->W - 1.0};
     const int nocull = a->nocull;
     const long long hr = (long long)f * R + r;
+    CacheEnt* cache = a->cache + hr * (a->NCMAX + CACHE_PAD);
+    // empty classification cache (also on resume: the wide tier maps clusters to waves differently)
+    for (int i = threadIdx.x; i < a->NCMAX + CACHE_PAD; i += WPH * 64) { CacheEnt z; z.mlo = z.mhi = 0u; z.slack = 0.0f; z.stamp = 0u; cache[i] = z; }
     constexpr int ST_WORDS = (int)(sizeof(LMState<NP>) / 8);
     static_assert(sizeof(LMState<NP>) % 8 == 0, "LMState is copied as 8-byte words");
     // Two-tier launch (see launch_solve): the first launch stops a hypothesis after `budget` sweeps and parks its LM state;
@@ -1428,22 +1534,30 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
         const double y0 = a->init_y[hr] + (yaw0 ? yaw0[f] : 0.0);
         if (NP == 4) { st.x[0] = y0; } else { st.x[0] = 0.0; st.x[1] = y0; st.x[2] = 0.0; }
         for (int i = 0; i < 3; ++i) st.x[TOFF + i] = a->init_T[hr * 3 + i];
-        for (int i = 0; i < NP; ++i) { st.x[i] = fmin(fmax(st.x[i], st.lb[i]), st.ub[i]); st.xe[i] = st.x[i]; }
+        for (int i = 0; i < NP; ++i) { st.x[i] = fmin(fmax(st.x[i], st.lb[i]), st.ub[i]); st.xe[i] = st.x[i]; sh.ring[0][i] = st.x[i]; }
         st.radius = 1e4; st.decrease = 2.0; st.reuse_diag = 0; st.invalid_run = 0; st.iter = 0; st.nsweep = 0;
         st.phase = PH_INIT; st.done = 0; st.max_iter = a->max_iter; st.cost = 0.0; st.gmax = 0.0;
         st.n_ls_extra = 0; st.n_ls_late_accept = 0; st.n_resweep = 0; st.want_j = 2; st.poly_req = 0;
     }
     __syncthreads();
     long long c_sweep = 0, c_wait = 0, c_lm = 0, c_comb = 0;
-    int n_act[4] = {0, 0, 0, 0};   // wave 0: phase-B evaluations, clusters classified per point / all active / guard-only
+    int n_act[6] = {0, 0, 0, 0, 0, 0};   // wave 0: phase-B evaluations, clusters classified per point / all active / guard-only, cache hits {classification, guard}
+    // sweep numbers of the classification cache count from this launch's first sweep (resume: the cache and the ring start empty)
+    const int s_base = a->resume ? st.nsweep : 0;
+    if (a->resume) {
+        if (threadIdx.x == 0)
+            for (int i = 0; i < NP; ++i) sh.ring[0][i] = st.xe[i];
+        __syncthreads();
+    }
     long long tp[4] = {0, 0, 0, 0}; // wave 0, inside the sweep: cluster-test rounds, drains (phase B), set-up, reduction
     long long c_decide = 0, c_poly = 0, c_apply = 0;
     for (;;) {
         double xe[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) xe[i] = st.xe[i];
+        const int s_now = st.nsweep - s_base;
         const long long t0 = PROFILE ? clock64() : 0;
-        sweep<NP, PT, WPH, 2, PROFILE>(recs, boxes, cnt1, cnt0, nc1, nc0, k, xe, nocull, sh, n_act, tp);
+        sweep<NP, PT, WPH, 2, PROFILE>(recs, boxes, cnt1, cnt0, nc1, nc0, k, xe, nocull, sh, cache, s_now, n_act, tp);
         const long long t1 = PROFILE ? clock64() : 0;
         __syncthreads();
         const long long t2 = PROFILE ? clock64() : 0;
@@ -1485,6 +1599,10 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
         if (threadIdx.x == 0) {
             if (action == ACT_TRIAL_NEXT) action = lm_trial_next_decide<NP>(st);
             lm_apply<NP>(st, action, sh.comb[0], sh.comb + 1, sh.comb + 1 + NP);
+            // the iterate of the NEXT sweep enters the ring of the classification cache (slot = its sweep number % RING)
+            const int slot = (st.nsweep - s_base) & (RING - 1);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) sh.ring[slot][i] = st.xe[i];
         }
         const long long t3 = PROFILE ? clock64() : 0;
         c_comb += t2b - t2; c_decide += t2c - t2b; c_poly += t2d - t2c; c_apply += t3 - t2d;
@@ -1503,12 +1621,12 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
             for (int i = threadIdx.x; i < ST_WORDS; i += WPH * 64) state_buf[hr * ST_WORDS + i] = src[i];
         }
     }
-    if (PROFILE && threadIdx.x == 0) {   // diagnostics, 16 int64 per hypothesis (wave 0's shader-clock cycles and counts; see di2p_solver_set_profile_buffer)
-        long long* prof = a->prof + hr * 16;
-        long long v[16] = {c_sweep, c_wait, c_lm, n_act[0], n_act[1], n_act[2], c_comb,
+    if (PROFILE && threadIdx.x == 0) {   // diagnostics, 20 int64 per hypothesis (wave 0's shader-clock cycles and counts; see di2p_solver_set_profile_buffer)
+        long long* prof = a->prof + hr * 20;
+        long long v[20] = {c_sweep, c_wait, c_lm, n_act[0], n_act[1], n_act[2], c_comb,
                            (long long)st.n_ls_extra | ((long long)st.n_ls_late_accept << 20) | ((long long)st.n_resweep << 40),
-                           c_decide, c_poly, c_apply, n_act[3], tp[0], tp[1], tp[2], tp[3]};
-        for (int i = 0; i < 16; ++i) prof[i] = (a->resume && i != 7 ? prof[i] : 0) + v[i];
+                           c_decide, c_poly, c_apply, n_act[3], tp[0], tp[1], tp[2], tp[3], n_act[4], n_act[5], 0, 0};
+        for (int i = 0; i < 20; ++i) prof[i] = (a->resume && i != 7 ? prof[i] : 0) + v[i];
     }
     if (threadIdx.x == 0 && st.done) {
         double* params_out = a->params_out;
@@ -1692,7 +1810,7 @@ __global__ __launch_bounds__(256) void residuals_kernel(const double* __restrict
 static long long* g_prof = nullptr;   // diagnostics hook, see di2p_solver_set_profile_buffer
 
 constexpr size_t kStateBytes = sizeof(LMState<6>) > sizeof(LMState<4>) ? sizeof(LMState<6>) : sizeof(LMState<4>);
-struct SolveWs { int P, NCMAX; size_t off_recs, off_boxes, off_keys, off_pending, off_state, bytes; };
+struct SolveWs { int P, NCMAX; size_t off_recs, off_boxes, off_keys, off_pending, off_state, off_cache, bytes; };
 static SolveWs solve_ws_layout(int F, int R, int N) {
     SolveWs w;
     w.P = 64;
@@ -1704,7 +1822,8 @@ static SolveWs solve_ws_layout(int F, int R, int N) {
     w.off_keys = up(w.off_boxes + (size_t)F * w.NCMAX * sizeof(Box));
     w.off_pending = up(w.off_keys + (size_t)F * w.P * 8);
     w.off_state = up(w.off_pending + (size_t)F * R * sizeof(int));
-    w.bytes = up(w.off_state + (size_t)F * R * kStateBytes) + 256;
+    w.off_cache = up(w.off_state + (size_t)F * R * kStateBytes);
+    w.bytes = up(w.off_cache + (size_t)F * R * (w.NCMAX + CACHE_PAD) * sizeof(CacheEnt)) + 256;
     return w;
 }
 
@@ -1714,7 +1833,8 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
                  int R, int N, double* params, double* cost, int* iters, int* sweeps, void* workspace, hipStream_t st) {
     Bounds b;
     for (int i = 0; i < 3; ++i) { b.lb[i] = lb[i]; b.ub[i] = ub[i]; }
-    // workspace: counts i32[F][4] | records Rec[F][N] | cluster boxes [F][NCMAX] | sort keys u64[F][P] | pending i32[F][R] | parked LM states [F][R]
+    // workspace: counts i32[F][4] | records Rec[F][N] | cluster boxes [F][NCMAX] | sort keys u64[F][P] | pending i32[F][R] | parked LM states [F][R] |
+    // classification cache [F][R][NCMAX + CACHE_PAD]
     const SolveWs ws = solve_ws_layout(F, R, N);
     char* base = (char*)workspace;
     int* counts = (int*)base;
@@ -1725,7 +1845,8 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
     // DI2P_SOLVER_CFG=<waves per hypothesis><min waves/SIMD>, e.g. 43 (default); DI2P_SOLVER_NOCULL=1 classifies every
     // cluster per point (the sums are bit-identical by construction: tests compare the two)
     const int cfg = (int)di2p_opt(DI2P_OPT_SOLVER_CFG);
-    const int nocull = (di2p_opt(DI2P_OPT_SOLVER_NOCULL) ? 1 : 0) | (di2p_opt(DI2P_OPT_SOLVER_NOPREFILTER) ? 2 : 0);   // bit 0: no cluster test, bit 1: no fp32 pre-filter
+    const int nocull = (di2p_opt(DI2P_OPT_SOLVER_NOCULL) ? 1 : 0) | (di2p_opt(DI2P_OPT_SOLVER_NOPREFILTER) ? 2 : 0) |
+                       (di2p_opt(DI2P_OPT_SOLVER_NOCACHE) ? 4 : 0);   // bit 0: no cluster test, bit 1: no fp32 pre-filter, bit 2: no classification cache
     const dim3 grid(R * F);
     // Two tiers against the tail: the sweep counts of the hypotheses are heavy-tailed (median 48, 10 % above 140, max > 200 on the
     // config-2 workload) and a hypothesis is a sequential chain of sweeps, so a lone launch ends with a few long chains on an
@@ -1738,6 +1859,7 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
     SolveArgs<PT> ka;
     ka.packed = packed; ka.boxes_all = boxes; ka.counts = counts; ka.Kmat = K; ka.init_y = init_y; ka.init_T = init_T; ka.yaw0 = yaw0;
     ka.params_out = params; ka.cost_out = cost; ka.iters_out = iters; ka.sweeps_out = sweeps; ka.prof = g_prof; ka.state_buf = state;
+    ka.cache = (CacheEnt*)(base + ws.off_cache);
     ka.H = H; ka.W = W; ka.bnd = b; ka.NCMAX = ws.NCMAX; ka.nocull = nocull; ka.max_iter = max_iter; ka.F = F; ka.R = R; ka.N = N;
     // the diagnostics (phase clocks, cluster / evaluation counters) are a separate instantiation: the production kernel carries none of it
 #define DI2P_LAUNCH_SOLVE_P(NPV, MW, WP, PEND, BUDGET, RESUME)                                                                   \
@@ -1839,9 +1961,10 @@ extern "C" long long di2p_solve_workspace_bytes(int F, int R, int N) {
     return (long long)solve_ws_layout(F, R, N).bytes;
 }
 
-// Diagnostics: when set to a device buffer of F*R*16 int64, every solve launch (a separate instantiation of the kernel) records per
+// Diagnostics: when set to a device buffer of F*R*20 int64 (library version >= 4; 16 before), every solve launch (a separate instantiation of the kernel) records per
 // hypothesis: [0..2] shader-clock cycles wave 0 spent in {sweep, waiting at the reduction barrier, LM update}, [3] its phase-B
 // evaluations, [4..5] its clusters {classified per point, taken as all-active}, [6] cycles combining the wave partials, [7] packed
 // line-search counters, [8..10] LM stages {decide, wave-wide interpolant minimiser, finish + begin iteration}, [11] guard-only
-// clusters, [12..15] inside the sweep: {cluster-test rounds, drains = phase B, set-up, log + wave reduction}.
+// clusters, [12..15] inside the sweep: {cluster-test rounds, drains = phase B, set-up, log + wave reduction}, [16..17] classification-cache
+// hits {clusters whose recorded mask was re-used, guard-only clusters skipped} ([4] and [11] count the misses), [18..19] reserved.
 extern "C" void di2p_solver_set_profile_buffer(void* buf) { g_prof = (long long*)buf; }

@@ -50,6 +50,10 @@
 
 namespace {
 
+// Diagnostics (tools/model_temporal.py): when set, eval() appends every point it is called at with gradients -- the sequence of
+// trial points a solve visits, which the HIP kernel sweeps in the same order.
+thread_local std::vector<double>* g_eval_trace = nullptr;
+
 template <int NP>
 struct Dual {
     double a;
@@ -147,6 +151,7 @@ struct Problem {
     bool eval(const double* x, double* cost, double* g, double* A, std::vector<double>* res_out) const {
         Dual<NP> cam[NP];
         for (int i = 0; i < NP; ++i) cam[i] = Dual<NP>(x[i], i);
+        if (g_eval_trace && g) for (int i = 0; i < NP; ++i) g_eval_trace->push_back(x[i]);
         double c = 0.0;
         if (g) { std::memset(g, 0, sizeof(double) * NP); std::memset(A, 0, sizeof(double) * NP * NP); }
         bool ok = true;
@@ -485,6 +490,22 @@ int oracle_solve_p_given_k(const double* points, const int* labels, int N, const
                            int* term, double* params_out) {
     if (is_2d) return solve_impl<4>(points, labels, N, K, init_y_angle, init_T, H, W, lb, ub, max_iter, P_out, final_cost, residuals, n_res, iters, term, params_out);
     return solve_impl<6>(points, labels, N, K, init_y_angle, init_T, H, W, lb, ub, max_iter, P_out, final_cost, residuals, n_res, iters, term, params_out);
+}
+
+// Diagnostics: the same solve, also returning the points every cost + gradient evaluation was made at (trace: cap x (4|6) doubles).
+// Returns the number of evaluations (may exceed cap; only the first cap are stored).
+int oracle_solve_trace(const double* points, const int* labels, int N, const double* K, double init_y_angle, const double* init_T,
+                       double H, double W, const double* lb, const double* ub, int max_iter, int is_2d, double* final_cost,
+                       double* trace, int cap) {
+    std::vector<double> tr;
+    g_eval_trace = &tr;
+    double P[16];
+    oracle_solve_p_given_k(points, labels, N, K, init_y_angle, init_T, H, W, lb, ub, max_iter, is_2d, P, final_cost, nullptr, nullptr,
+                           nullptr, nullptr, nullptr);
+    g_eval_trace = nullptr;
+    const int np = is_2d ? 4 : 6, n = (int)(tr.size() / np);
+    std::memcpy(trace, tr.data(), sizeof(double) * np * std::min(n, cap));
+    return n;
 }
 
 // R independent restarts of one frame spread over nthreads std::threads (mirrors the reference's

@@ -388,6 +388,285 @@ def make_prep():
     print("prep_golden.npz written")
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Front ends of the path that are METHODS / functions / script bodies of the reference: extracted with ``ast`` and run here against
+# stub collaborators (canned network scores, a recording cv2, a recording FrustumRegistration), exactly like make_lsq_driver does for
+# the LSQ helpers.  Only inputs and outputs are stored.
+# ----------------------------------------------------------------------------------------------------------------------
+class _NpProxy:
+    """numpy with the aliases the reference's era still had (np.int / np.float) and a recording np.save"""
+
+    def __init__(self, saved=None):
+        self._saved = saved
+        self.int = int
+        self.float = float
+
+    def save(self, path, arr):
+        self._saved.append((os.path.basename(path), np.array(arr)))
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+
+def _method_as_function(path, cls, name, ns):
+    tree = ast.parse(open(path).read())
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == cls:
+            for sub in node.body:
+                if isinstance(sub, ast.FunctionDef) and sub.name == name:
+                    exec(compile(ast.Module(body=[sub], type_ignores=[]), path, "exec"), ns)
+                    return ns[name]
+    raise KeyError(name)
+
+
+def _label_inputs(seed, B, N, H, W, P_rows):
+    """pc / P / K of a seeded synthetic batch, with a few points planted close to (not on) the image borders and the z = 0.1 plane"""
+    from deepi2p_amd import synthetic
+    b = synthetic.make_batch(seed, B, N=N, H=H, W=W, with_image=False)
+    pc = b["pc"].astype(np.float32).copy()
+    P = b["P_gt"].astype(np.float32)[:, :P_rows, :].copy()
+    K = b["K"].astype(np.float32)
+    rng = np.random.default_rng(seed + 1)
+    for bi in range(B):
+        Pi = b["P_gt"][bi]
+        Rm, t = Pi[:3, :3], Pi[:3, 3]
+        for j in range(24):
+            z = rng.uniform(1.0, 40.0)
+            u = [0.0, W - 1.0, rng.uniform(0, W - 1)][j % 3] + rng.choice([-1, 1]) * rng.uniform(2e-2, 0.4)
+            v = [rng.uniform(0, H - 1), 0.0, H - 1.0][(j // 3) % 3] + rng.choice([-1, 1]) * rng.uniform(2e-2, 0.4)
+            if j >= 18:
+                z = 0.1 + rng.choice([-1, 1]) * rng.uniform(1e-3, 5e-2)
+            cam = np.array([(u - K[bi, 0, 2]) * z / K[bi, 0, 0], (v - K[bi, 1, 2]) * z / K[bi, 1, 1], z])
+            pc[bi, :, j] = (Rm.T @ (cam - t)).astype(np.float32)
+    return pc, P, K
+
+
+def make_forward_pass():
+    """MMClassifer.foraward_pass (models/multimodal_classifier.py:119-212) run on a stub ``self``: label projection, fine labels,
+    loss assembly (reference FocalLoss + CrossEntropyLoss), accuracies."""
+    from types import SimpleNamespace
+    import torch.nn as nn
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_focal_loss", os.path.join(REF, "models", "focal_loss.py"))
+    focal = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(focal)
+    ns = {"torch": torch}
+    fwd = _method_as_function(os.path.join(REF, "models", "multimodal_classifier.py"), "MMClassifer", "foraward_pass", ns)
+    out = {}
+    for ci, (seed, B, N, H, W) in enumerate([(71, 2, 2048, 64, 128), (72, 1, 4096, 160, 512)]):
+        scale = 32
+        L = int(round(H / scale)) * int(round(W / scale))
+        pc, P, K = _label_inputs(seed, B, N, H, W, 3)
+        g = torch.Generator().manual_seed(seed)
+        coarse_scores = torch.randn((B, 2, N), generator=g)
+        fine_scores = torch.randn((B, L, N), generator=g)
+        self_ = SimpleNamespace(
+            pc=torch.from_numpy(pc), intensity=None, sn=None, node_a=None, node_b=None, img=torch.zeros((B, 3, H, W)),
+            P=torch.from_numpy(P), K=torch.from_numpy(K),
+            opt=SimpleNamespace(node_a_num=128, node_b_num=128, img_fine_resolution_scale=scale, coarse_loss_alpha=50, is_debug=False),
+            forward=lambda *a: (coarse_scores, fine_scores),
+            coarse_ce_criteria=focal.FocalLoss(alpha=0.5, gamma=2, reduction="mean"), fine_ce_criteria=nn.CrossEntropyLoss())
+        loss_dict, vis, acc = fwd(self_)
+        k = "fp%d_" % ci
+        out[k + "pc"], out[k + "P"], out[k + "K"] = pc, P, K
+        out[k + "HW"] = np.array([H, W, scale], dtype=np.int64)
+        out[k + "coarse_scores"], out[k + "fine_scores"] = coarse_scores.numpy(), fine_scores.numpy()
+        out[k + "coarse_labels"] = vis["coarse_labels"].numpy()
+        out[k + "fine_labels"] = vis["fine_labels"].numpy()
+        out[k + "KP_pc_pxpy"] = vis["KP_pc_pxpy"].numpy()
+        out[k + "P_pc"] = vis["pc"].numpy()
+        out[k + "coarse_predictions"] = vis["coarse_predictions"].numpy()
+        out[k + "fine_predictions"] = vis["fine_predictions"].numpy()
+        out[k + "losses"] = np.array([float(loss_dict[n]) for n in ("loss", "coarse", "fine")])
+        out[k + "accuracy"] = np.array([float(acc["coarse_accuracy"]), float(acc["fine_accuracy"])])
+    np.savez_compressed(os.path.join(HERE, "forward_pass_golden.npz"), **out)
+    print("forward_pass_golden.npz written")
+
+
+def make_eval_script():
+    """The per-batch body of evaluation/visualize_and_save_data.py (the ``for i, data in enumerate(testloader)`` loop, :81-187): GT labels,
+    per-frame accuracies and the saved pc_label / K / P records, with a stub model (canned predictions), stub visualisation and a
+    recording np.save."""
+    from types import SimpleNamespace
+    path = os.path.join(REF, "evaluation", "visualize_and_save_data.py")
+    tree = ast.parse(open(path).read())
+    loop = None
+    for node in ast.walk(tree):
+        if isinstance(node, ast.For) and isinstance(node.iter, ast.Call) and getattr(node.iter.func, "id", "") == "enumerate" \
+                and getattr(node.iter.args[0], "id", "") == "testloader":
+            loop = node
+    assert loop is not None
+    code = compile(ast.Module(body=[loop], type_ignores=[]), path, "exec")
+    out = {}
+    for ci, (seed, B, N, H, W, fine, P_rows) in enumerate([(81, 2, 2048, 64, 128, True, 3), (82, 2, 1024, 160, 512, False, 4)]):
+        scale = 32
+        L = int(round(H / scale)) * int(round(W / scale))
+        pc, P, K = _label_inputs(seed, B, N, H, W, P_rows)
+        rng = np.random.default_rng(seed)
+        cpred = torch.from_numpy(rng.integers(0, 2, (B, N)).astype(np.int64))
+        fpred = torch.from_numpy(rng.integers(0, L, (B, N)).astype(np.int64))
+        img = torch.from_numpy(rng.uniform(0, 255, (B, 3, H, W)).astype(np.float32))
+        saved, sums = [], []
+
+        class Model:
+            def set_input(self, *a):
+                pass
+
+            def inference_pass(self):
+                return (cpred, fpred) if fine else cpred
+
+        data = (torch.from_numpy(pc), torch.zeros((B, 1, N)), torch.zeros((B, 3, N)), torch.zeros((B, 3, 128)), torch.zeros((B, 3, 128)),
+                torch.from_numpy(P), img, torch.from_numpy(K), torch.zeros((B, 3)))
+        vis = SimpleNamespace(get_classification_visualization=lambda *a, **k: np.zeros((4, 4, 3), np.uint8),
+                              get_classification_visualization_coarse=lambda *a, **k: np.zeros((4, 4, 3), np.uint8))
+        lines = []
+        ns = {"np": _NpProxy(saved), "torch": torch, "os": os, "testloader": [data], "model": Model(), "vis_tools": vis, "cv2": None,
+              "opt": SimpleNamespace(img_fine_resolution_scale=scale, is_fine_resolution=fine), "counter": 0, "coarse_accuracy_sum": 0,
+              "fine_accuracy_sum": 0, "is_save_visualization": False, "is_save_data": True, "is_plot": False, "iter_max": 1e9,
+              "data_output_path": "data", "visualization_output_path": "vis", "print": lambda *a: lines.append(a[0])}
+        with np.errstate(all="ignore"):
+            exec(code, ns)
+        k = "ev%d_" % ci
+        out[k + "pc"], out[k + "P"], out[k + "K"] = pc, P, K
+        out[k + "HW"] = np.array([H, W, scale, int(fine)], dtype=np.int64)
+        out[k + "coarse_pred"], out[k + "fine_pred"] = cpred.numpy(), fpred.numpy()
+        recs = [a for n, a in saved if n.endswith("pc_label.npy")]
+        assert len(recs) == B and recs[0].shape == (7, N)
+        out[k + "pc_label"] = np.stack(recs)
+        out[k + "saved_K"] = np.stack([a for n, a in saved if n.endswith("_K.npy")])
+        out[k + "saved_P"] = np.stack([a for n, a in saved if n.endswith("_P.npy")])
+        out[k + "acc_sums"] = np.array([ns["coarse_accuracy_sum"], ns["fine_accuracy_sum"], ns["counter"]], dtype=np.float64)
+        out[k + "acc_lines"] = np.array(lines)
+    np.savez_compressed(os.path.join(HERE, "eval_script_golden.npz"), **out)
+    print("eval_script_golden.npz written")
+
+
+def make_pnp_frontend():
+    """solve_PnP + camera_matrix_scaling (evaluation/registration_pnp.py:58-61,95-148) with a cv2 that records what reaches
+    solvePnPRansac and returns canned answers: correspondence packing, the >= 4 rule, the |t| < 14.14 acceptance, the outlier ratio."""
+    from scipy.spatial.transform import Rotation
+    path = os.path.join(REF, "evaluation", "registration_pnp.py")
+    out = {}
+    cases = [dict(n_in=300, ok=True, t=[1.0, -0.5, 3.0], n_inl=120), dict(n_in=300, ok=True, t=[10.0, 1.0, 10.0], n_inl=80),
+             dict(n_in=300, ok=False, t=[0.1, 0.1, 0.1], n_inl=10), dict(n_in=3, ok=True, t=[0, 0, 1.0], n_inl=3),
+             dict(n_in=4, ok=True, t=[0.2, 0, 1.0], n_inl=4), dict(n_in=50, ok=True, t=[0, 0, 1.0], n_inl=20, throw=True)]
+    for ci, c in enumerate(cases):
+        rng = np.random.default_rng(200 + ci)
+        N, Hf, Wf, scale = 1000, 5, 16, 1.0 / 32          # the caller passes the FINE grid size and the 1/32 factor (registration_pnp.py:207)
+        pc = rng.uniform(-30, 30, (3, N)).astype(np.float32)
+        coarse = np.zeros(N, np.int64)
+        coarse[rng.choice(N, c["n_in"], replace=False)] = 1
+        fine = rng.integers(0, Hf * Wf, N).astype(np.int64)
+        K = np.array([[358.4, 0, 256.0], [0, 358.4, 80.0], [0, 0, 1.0]])
+        rec = {}
+
+        class CV2:
+            SOLVEPNP_EPNP = 1
+
+            @staticmethod
+            def solvePnPRansac(points, pixels, Kf, useExtrinsicGuess, iterationsCount, reprojectionError, flags, distCoeffs):
+                rec.update(points=np.array(points), pixels=np.array(pixels), K=np.array(Kf), iters=iterationsCount, err=reprojectionError,
+                           flags=flags, guess=useExtrinsicGuess)
+                if c.get("throw"):
+                    raise RuntimeError("cv2 error")
+                return c["ok"], np.array([[0.1], [-0.2], [0.05]]), np.array(c["t"], dtype=np.float64).reshape(3, 1), np.arange(c["n_inl"]).reshape(-1, 1)
+
+            @staticmethod
+            def Rodrigues(rvec):
+                return Rotation.from_rotvec(np.asarray(rvec).reshape(3)).as_matrix(), None
+
+        ns = {"np": _NpProxy(), "cv2": CV2}
+        tree = ast.parse(open(path).read())
+        for node in tree.body:
+            if isinstance(node, ast.FunctionDef) and node.name in ("camera_matrix_scaling", "solve_PnP"):
+                exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+        Pm, ratio = ns["solve_PnP"](pc, coarse, fine, K.copy(), Hf * 32, Wf * 32, scale, 500, CV2.SOLVEPNP_EPNP)
+        k = "pnp%d_" % ci
+        out[k + "pc"], out[k + "coarse"], out[k + "fine"], out[k + "K"] = pc, coarse, fine, K
+        out[k + "HWs"] = np.array([Hf * 32, Wf * 32, scale])
+        out[k + "called"] = np.int64(1 if rec else 0)
+        if rec:
+            out[k + "arg_points"], out[k + "arg_pixels"], out[k + "arg_K"] = rec["points"], rec["pixels"], rec["K"]
+            out[k + "arg_scalars"] = np.array([rec["iters"], rec["err"], rec["flags"], float(rec["guess"])])
+        out[k + "ret"] = np.array([float(c["ok"]), c["n_inl"], float(bool(c.get("throw")))] + list(c["t"]))
+        out[k + "P"], out[k + "ratio"] = Pm, np.float64(ratio)
+    np.savez_compressed(os.path.join(HERE, "pnp_frontend_golden.npz"), **out)
+    print("pnp_frontend_golden.npz written")
+
+
+def make_lsq_restart_driver():
+    """solve_P_random_perturb + solver_wrapper (evaluation/registration_lsq.py:127-186) with a recording FrustumRegistration, an in-process
+    ``multiprocessing`` and a seeded ``random``: the restart list (ry = y0 + gauss, t = (0, 0, U)), the hard-coded max_iter = 500, the
+    strict-< minimum, and the wave arithmetic (iteration_num % thread_num == 0 drops the last wave)."""
+    import random as pyrandom
+    path = os.path.join(REF, "evaluation", "registration_lsq.py")
+    out = {}
+    for ci, (iteration_num, thread_num) in enumerate([(60, 8), (64, 8), (5, 8), (16, 4)]):
+        calls = []
+        costs_rng = np.random.default_rng(300 + ci)
+        canned = costs_rng.uniform(5.0, 50.0, 200)
+        canned[7] = canned[3] = canned.min() - 1.0          # an exact tie: the FIRST one must win (strict <)
+
+        class FR:
+            @staticmethod
+            def solvePGivenK(pc, lab, K, R_init, t_init, H, W, lb, ub, max_iter, is_debug, is_2d):
+                i = len(calls)
+                calls.append((float(R_init), np.array(t_init, dtype=np.float64), H, W, list(lb), list(ub), max_iter, is_debug, is_2d))
+                P = np.eye(4)
+                P[0, 3] = i
+                return P, float(canned[i]), np.full(3, float(i))
+
+        class Proc:
+            def __init__(self, target, args):
+                self.t, self.a = target, args
+
+            def start(self):
+                self.t(*self.a)
+
+            def join(self):
+                pass
+
+        class MP:
+            Process = Proc
+
+            @staticmethod
+            def Manager():
+                class M:
+                    @staticmethod
+                    def dict():
+                        return {}
+                return M()
+
+        ns = {"np": np, "math": math, "random": pyrandom.Random(1234 + ci), "multiprocessing": MP, "FrustumRegistration": FR}
+        tree = ast.parse(open(path).read())
+        for node in tree.body:
+            if isinstance(node, ast.FunctionDef) and node.name in ("solver_wrapper", "solve_P_random_perturb"):
+                exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+        pc, lab, K = np.zeros((3, 8)), np.ones(8, np.int32), np.eye(3)
+        P, cost, res = ns["solve_P_random_perturb"](pc, lab, K, 160, 512, 10.0, 0.37, 10 * math.pi / 180, [-5, -0.1, -10], [5, 0.1, 10],
+                                                    iteration_num, True, thread_num)
+        k = "rp%d_" % ci
+        out[k + "args"] = np.array([iteration_num, thread_num, 1234 + ci], dtype=np.int64)
+        out[k + "n_calls"] = np.int64(len(calls))
+        out[k + "ry"] = np.array([c[0] for c in calls])
+        out[k + "t"] = np.array([c[1] for c in calls]).reshape(len(calls), 3)
+        out[k + "max_iter"] = np.array([c[6] for c in calls], dtype=np.int64)
+        out[k + "flags"] = np.array([[int(c[7]), int(c[8])] for c in calls], dtype=np.int64).reshape(len(calls), 2)
+        out[k + "bounds"] = np.array(calls[0][4] + calls[0][5]) if calls else np.zeros(6)
+        out[k + "canned_cost"] = canned[:max(len(calls), 1)]
+        out[k + "best_call"] = np.int64(-1 if P is None else int(P[0, 3]))
+        out[k + "cost"] = np.float64(cost)
+    np.savez_compressed(os.path.join(HERE, "lsq_restart_golden.npz"), **out)
+    print("lsq_restart_golden.npz written")
+
+
+def make_front_ends():
+    make_forward_pass()
+    make_eval_script()
+    make_pnp_frontend()
+    make_lsq_restart_driver()
+
+
 if __name__ == "__main__":
     only = sys.argv[1] if len(sys.argv) > 1 else None
     assert rn.available(), "needs /root/reference and oracle/_ref (make -C oracle ref)"
@@ -401,6 +680,9 @@ if __name__ == "__main__":
     if only == "training":
         make_training()
         sys.exit(0)
+    if only == "frontends":
+        make_front_ends()
+        sys.exit(0)
     make_index_max()
     make_network(True, "network_golden.npz")
     make_network(False, "network_coarse_golden.npz")
@@ -409,3 +691,4 @@ if __name__ == "__main__":
     make_fullsize()
     make_losses()
     make_training()
+    make_front_ends()

@@ -133,6 +133,12 @@ def test_cluster_culling_is_exact(dev, is_2d, use_f32):
             d = run()
     for u, v, w in zip(a, c, d):
         assert u.tobytes() == v.tobytes() == w.tobytes()
+    # the classification cache re-uses a cluster's recorded active mask only while the iterate's motion is provably below the
+    # recorded slack: same bits with it switched off (a was computed with it on)
+    with _lib.option("solver_nocache", 1):
+        e = run()
+    for u, v in zip(a, e):
+        assert u.tobytes() == v.tobytes()
     assert np.isfinite(a[1]).sum() >= R - 4      # the planted on-plane points may fail hypotheses 0/1 only
 
 

@@ -27,13 +27,20 @@ for name, lab_np in (("noisy-gt", np.stack([f["labels"] for f in frames])),):
         return best, out
     from deepi2p_amd import _lib
     with _lib.option("solver_nocull", 1):
-        dt_nocull, _ = timed()
+        dt_nocull, (p_nc, c_nc, i_nc) = timed(2)
+    dt_nocache = float("nan")
+    if _lib.load().di2p_get_option(b"solver_nocache") >= 0:
+        with _lib.option("solver_nocache", 1):
+            dt_nocache, (p_n, c_n, i_n) = timed()
     dt, (params, cost, iters) = timed()
-    print("per-point classification of every cluster (DI2P_SOLVER_NOCULL=1): %.2f ms ; with the cluster test: %.2f ms" % (dt_nocull * 1e3, dt * 1e3))
+    print("per-point classification of every cluster (DI2P_SOLVER_NOCULL=1): %.2f ms ; cluster test without the classification cache: %.2f ms ; with it: %.2f ms" % (
+        dt_nocull * 1e3, dt_nocache * 1e3, dt * 1e3))
+    print("  bit-identical to the unculled solve: params %s cost %s iterations %s" % (torch.equal(p_nc, params), torch.equal(c_nc, cost), torch.equal(i_nc, iters)))
     kept = (lab_front >= 0).sum(1).float().mean().item()
     if os.environ.get("PROF"):
         from deepi2p_amd import _lib
-        PW = 16 if _lib.load().di2p_version() >= 3 else 8       # int64 words per hypothesis (version 3: finer phases)
+        ver = _lib.load().di2p_version()
+        PW = 20 if ver >= 4 else (16 if ver >= 3 else 8)       # int64 words per hypothesis (version 3: finer phases, 4: classification-cache hits)
         prof = torch.zeros((F, R, PW), dtype=torch.int64, device=dev)
         _lib.load().di2p_solver_set_profile_buffer(prof.data_ptr())
         ops.solve_batched(pc, lab_front, K, restarts[0], restarts[1], H, W, pipe.lb, pipe.ub, 500, True, yaw0=yaw0, sweeps=sweeps)
@@ -44,8 +51,11 @@ for name, lab_np in (("noisy-gt", np.stack([f["labels"] for f in frames])),):
         print("  per-sweep cycles (mean over hyps): sweep %.0f  barrier-wait %.0f  LM %.0f ; active evals/sweep (wave0) %.1f of %d records/wave"
               % ((p[:, 0] / sw).mean(), (p[:, 1] / sw).mean(), (p[:, 2] / sw).mean(), (p[:, 3] / sw).mean(), kept / 4))
         print("  clusters per sweep (wave 0): per-point %.1f  all-active %.1f  guard-only %s ; partial-combine cycles per sweep %.0f (part of LM)" % (
-            (p[:, 4] / sw).mean(), (p[:, 5] / sw).mean(), ("%.1f" % (p[:, 11] / sw).mean()) if PW == 16 else "n/a", (p[:, 6] / sw).mean()))
-        if PW == 16:
+            (p[:, 4] / sw).mean(), (p[:, 5] / sw).mean(), ("%.1f" % (p[:, 11] / sw).mean()) if PW >= 16 else "n/a", (p[:, 6] / sw).mean()))
+        if PW >= 20:
+            print("  classification cache (wave 0, clusters per sweep): re-used masks %.1f (misses = per-point above)  guard walks skipped %.1f (misses = guard-only above)" % (
+                (p[:, 16] / sw).mean(), (p[:, 17] / sw).mean()))
+        if PW >= 16:
             print("  LM stages per sweep: combine %.0f  decide %.0f  wave minimiser %.0f  finish+begin %.0f" % tuple((p[:, i] / sw).mean() for i in (6, 8, 9, 10)))
             print("  inside the sweep (wave 0, cycles per sweep): set-up %.0f  cluster-test rounds %.0f  phase B (drains) %.0f  log+reduction %.0f  -> cluster walk / phase A %.0f" % (
                 (p[:, 14] / sw).mean(), (p[:, 12] / sw).mean(), (p[:, 13] / sw).mean(), (p[:, 15] / sw).mean(), ((p[:, 0] - p[:, 12] - p[:, 13] - p[:, 14] - p[:, 15]) / sw).mean()))

@@ -1,5 +1,5 @@
 """Randomised check that the cluster shortcut of the pose solver never changes a result: for many random frames, point
-counts, intrinsics and hypotheses the outputs with and without DI2P_SOLVER_NOCULL must be bit-identical (GPU box)."""
+counts, intrinsics and hypotheses the outputs with and without DI2P_SOLVER_NOCULL (and with the classification cache off, DI2P_SOLVER_NOCACHE) must be bit-identical (GPU box)."""
 import os, sys, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -33,8 +33,10 @@ for it in range(cases):
     a = run()
     with _lib.option("solver_nocull", 1), _lib.option("solver_noprefilter", 1):
         b = run()
-    if a != b:
+    with _lib.option("solver_nocache", 1):
+        c = run()
+    if a != b or a != c:
         bad += 1
-        print("MISMATCH", dict(N=N, H=H, W=W, is_2d=is_2d, f32=f32))
+        print("MISMATCH", dict(N=N, H=H, W=W, is_2d=is_2d, f32=f32, vs_nocull=a != b, vs_nocache=a != c))
 print("solver cull fuzz: %d cases, %d mismatches" % (cases, bad))
 sys.exit(1 if bad else 0)
