@@ -71,6 +71,7 @@ _SIGS = {
     "di2p_pnp_ransac": [c_void_p] * 5 + [c_int, c_void_p, c_int, c_double, c_int, c_int, c_int, c_int] + [c_void_p] * 7,
     "di2p_draw_restarts": [ctypes.c_ulonglong, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p],
     "di2p_random_choice": [ctypes.c_ulonglong, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "di2p_pnp_pack": [c_void_p] * 4 + [c_int, c_int, c_int] + [c_void_p] * 3,
     "di2p_pnp_ransac_epnp": [c_void_p] * 5 + [c_int, c_void_p, c_int, c_double, c_int, c_int] + [c_void_p] * 7,
     "di2p_classifier_loss": [c_void_p] * 4 + [c_int, c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 5,
     "di2p_adam_step": [c_void_p] * 4 + [c_ll, c_int, c_float, c_float, c_float, c_float, c_void_p],

@@ -566,6 +566,18 @@ extern "C" long long di2p_pnp_workspace_bytes(int F, int N, int iters) {
     return 256 + (long long)F * 4 + 256 + (long long)F * N * 32 + (long long)F * iters * (HYP * 8 + 4) + (long long)F * N + 1024;
 }
 
+// The correspondence list alone -- exactly what solve_PnP hands to cv2.solvePnPRansac (evaluation/registration_pnp.py:97-110,125-127):
+// points[n_corr[f]][3] = pc[:, coarse == 1].T and pixels[n_corr[f]][2] = (fine - floor(fine / W) * W, floor(fine / W)) in point order.
+// corr: f32 [F][N][8] records {x, y, z, u, v, 0, 0, 0}, the first n_corr[f] of each frame valid.
+extern "C" int di2p_pnp_pack(const float* pc, const int32_t* coarse, const int32_t* fine, const float* pixels, int W_fine, int F, int N,
+                             float* corr, int32_t* n_corr, void* stream) {
+    DI2P_CHECK_ARG(F >= 0 && N >= 1 && W_fine >= 1, "bad size");
+    if (F == 0) return 0;
+    DI2P_CHECK_ARG(pc && coarse && (fine || pixels) && corr && n_corr, "null pointer");
+    hipLaunchKernelGGL(pnp_pack_kernel, dim3(F), dim3(256), 0, (hipStream_t)stream, pc, coarse, fine, pixels, N, W_fine, (Corr*)corr, n_corr);
+    DI2P_RETURN_LAUNCH();
+}
+
 extern "C" int di2p_pnp_ransac(const float* pc, const int32_t* coarse, const int32_t* fine, const float* pixels,
                                const double* K_scaled, int W_fine,
                                const int32_t* samples, int iters, double reproj_err, int refine_rounds, int refine_iters, int F, int N,

@@ -423,6 +423,12 @@ struct LogProd {
     __device__ __forceinline__ double log_value() const { return log(m) + (double)e * 0.69314718055994530942; }
 };
 
+// compile-time list of parameter indices (the non-zero columns of a Jacobian row)
+template <int... I> struct ParamSet {
+    static constexpr int N = sizeof...(I);
+    __device__ static constexpr int at(int u) { constexpr int v[] = {I...}; return v[u]; }
+};
+
 // MODE 2: cost, gradient J^T r and normal equations J^T J; MODE 1: cost and gradient only (line-search trials beyond the
 // first: Ceres' CUBIC interpolation needs the directional derivative at every trial, 92 % of them are rejected, the accepted
 // ones are confirmed by a MODE-2 sweep); MODE 0: cost only.  The residual rows, s, the cost product and the gradient terms
@@ -467,11 +473,52 @@ __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& ro
     const double rho1 = fast_rcp(s1);
     const double ax = k.fx * iz, bx = -k.fx * p0 * iz * iz;   // dpix_x = ax*dp0 + bx*dp2
     const double ay = k.fy * iz, by = -k.fy * p1 * iz * iz;   // dpix_y = ay*dp1 + by*dp2
-    double dp0[NP], dp1[NP], dp2[NP];
     if (NP == 4) {
-        dp0[0] = qz; dp1[0] = 0.0; dp2[0] = -qx;              // d/dtheta of Ry(theta) X
-        if (!(x[0] * x[0] > DBL_EPSILON)) { dp0[0] = Z; dp2[0] = -X; }   // first-order branch
-    } else {
+        // 2-D solver: the parameter derivatives of p = Ry(theta) X + t are  dp0 = (d00, 1, 0, 0), dp1 = (0, 0, 1, 0), dp2 = (d20, 0, 0, 1), so every
+        // Jacobian row has STRUCTURAL zeros: row "pix_x" lives on parameters {0, 1, 3}, row "pix_y" on {0, 2, 3}, row "p2" on {0, 3}.  Written
+        // out, a label-1 block costs 15 instead of 30 normal-equation updates (the generic form multiplies by 0.0 and 1.0: IEEE rules forbid the
+        // compiler to drop x * 0.0).  Same values as the generic form whenever the terms are finite (x * 1.0 = x, fma(a, 0.0, y) = y, s + (+-0) = s).
+        double d00 = qz, d20 = -qx;                              // d/dtheta of Ry(theta) X
+        if (!(x[0] * x[0] > DBL_EPSILON)) { d00 = Z; d20 = -X; }   // first-order branch
+        auto add_row = [&](auto idx, const double* J, double r) {
+            constexpr int NI = decltype(idx)::N;
+            const double wr = rho1 * r;
+#pragma unroll
+            for (int u = 0; u < NI; ++u) {
+                const int a = decltype(idx)::at(u);
+                lg[a] += wr * J[a];
+                if (MODE == 2) {
+                    const double wa = rho1 * J[a];
+#pragma unroll
+                    for (int v = 0; v <= u; ++v) { const int b = decltype(idx)::at(v); lA[a * (a + 1) / 2 + b] += wa * J[b]; }
+                }
+            }
+        };
+        if (LAB == 1) {
+            if (!(sx[0] == 0.0)) {
+                double J[4];
+                J[0] = sx[0] * (ax * d00 + bx * d20); J[1] = sx[0] * ax; J[2] = 0.0; J[3] = sx[0] * bx;
+                add_row(ParamSet<0, 1, 3>(), J, rv[0]);
+            }
+            if (!(sy[1] == 0.0)) {
+                double J[4];
+                J[0] = sy[1] * (by * d20); J[1] = 0.0; J[2] = sy[1] * ay; J[3] = sy[1] * by;
+                add_row(ParamSet<0, 2, 3>(), J, rv[1]);
+            }
+            if (!(sz[2] == 0.0)) {
+                double J[4];
+                J[0] = sz[2] * d20; J[1] = 0.0; J[2] = 0.0; J[3] = sz[2];
+                add_row(ParamSet<0, 3>(), J, rv[2]);
+            }
+        } else {
+            double J[4];
+            J[0] = sx[0] * (ax * d00 + bx * d20) + sy[0] * (by * d20); J[1] = sx[0] * ax; J[2] = sy[0] * ay; J[3] = sx[0] * bx + sy[0] * by;
+            add_row(ParamSet<0, 1, 2, 3>(), J, rv[0]);
+        }
+        return;
+    }
+    double dp0[NP], dp1[NP], dp2[NP];
+    {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             dp0[i] = rot.dR[i][0] * X + rot.dR[i][1] * Y + rot.dR[i][2] * Z;

@@ -107,18 +107,44 @@ def draw_restarts(rng, R, ry_sigma, init_t_amplitude, F=None):
     return ry, Ts
 
 
+def restart_list(init_y_angle, ry_sigma, init_t_amplitude, iteration_num, thread_num=None, rng=None):
+    """The restart list of the reference's driver (registration_lsq.py:147-164), as arrays: ry = init_y_angle + gauss(0, ry_sigma),
+    t = (0, 0, uniform(-amp, amp)), drawn in that order restart by restart.
+    * ``thread_num`` given: the reference's wave arithmetic decides how many restarts there are -- ceil(n / threads) waves, the last one
+      with n - threads * floor(n / threads) processes (:150-156), i.e. ``n % threads == 0`` silently DROPS the last wave (64 restarts on
+      8 threads run 56); ``None`` runs all ``iteration_num``.
+    * ``rng``: an object with ``gauss`` / ``uniform`` (Python's ``random`` module or a ``random.Random``) is consumed exactly as the
+      reference consumes ``random`` -- the list is then the reference's, draw for draw (tests/golden/lsq_restart_golden.npz); a numpy
+      Generator (or None) draws normal / uniform vectors instead."""
+    n = int(iteration_num)
+    if thread_num is not None:
+        batch_num = math.ceil(n / thread_num)
+        last = n - thread_num * math.floor(n / thread_num)
+        n = max(batch_num - 1, 0) * thread_num + (last if batch_num > 0 else 0)
+    if rng is not None and hasattr(rng, "gauss"):
+        ys, Ts = np.zeros(n), np.zeros((n, 3))
+        for i in range(n):
+            ys[i] = init_y_angle + rng.gauss(0, ry_sigma)
+            Ts[i, 2] = rng.uniform(-init_t_amplitude, init_t_amplitude)
+        return ys, Ts
+    rng = rng if rng is not None else np.random.default_rng()
+    noise, Ts = draw_restarts(rng, n, ry_sigma, init_t_amplitude)
+    return init_y_angle + noise, Ts
+
+
 def solve_P_random_perturb(pc_np, coarse_predictions_np, K_np, H, W, init_t_amplitude, init_y_angle, ry_sigma,
                            t_lowerbound, t_upperbound, iteration_num, is_2d, thread_num=None, rng=None,
                            restarts=None, max_iter=500):
-    """Reference signature (registration_lsq.py:142-145).  All `iteration_num` restarts run in one launch
-    (thread_num is accepted and ignored; note the reference silently drops restarts when
-    iteration_num % thread_num == 0).  -> (P, cost, residuals) of the minimum-cost restart."""
+    """Reference signature (registration_lsq.py:142-145).  All restarts run in ONE launch; ``thread_num`` only enters the number of
+    restarts (see restart_list: the reference's wave arithmetic, including the dropped last wave).  max_iter = 500 is what the reference
+    hard-codes (:176).  -> (P, cost, residuals) of the minimum-cost restart, the FIRST one on ties (the reference keeps a result only
+    when it is strictly smaller, :137); (None, 1e20, None) when no restart runs, like the reference's untouched dictionary."""
     if restarts is None:
-        rng = rng if rng is not None else np.random.default_rng()
-        noise, Ts = draw_restarts(rng, iteration_num, ry_sigma, init_t_amplitude)
-        ys = init_y_angle + noise
+        ys, Ts = restart_list(init_y_angle, ry_sigma, init_t_amplitude, iteration_num, thread_num, rng)
     else:
         ys, Ts = restarts
+    if len(ys) == 0:
+        return None, 1e20, None
     P, cost, best, params, _ = solvePGivenK_batched(pc_np, coarse_predictions_np, K_np, ys, Ts, H, W, t_lowerbound,
                                                     t_upperbound, max_iter, is_2d, return_all=True)
     dev = _dev()

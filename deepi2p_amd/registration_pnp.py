@@ -28,6 +28,17 @@ def draw_samples(rng, F, iters):
     return rng.integers(0, 2 ** 30, size=(F, iters, SAMPLE_SIZE), dtype=np.int64).astype(np.int32)
 
 
+def pack_correspondences(pc, coarse, fine, W_fine, pixels=None):
+    """What solve_PnP hands to cv2.solvePnPRansac (registration_pnp.py:97-110,125-127), packed on the device.
+    pc f32[F,3,N], coarse/fine i32[F,N] -> (corr f32[F,N,8] = {x, y, z, u, v, 0, 0, 0}, n_corr i32[F]); the first n_corr[f] records are valid."""
+    require_cuda(pc, coarse, fine, pixels)
+    F, _, N = pc.shape
+    corr = torch.zeros((F, N, 8), dtype=torch.float32, device=pc.device)
+    n_corr = torch.empty((F,), dtype=torch.int32, device=pc.device)
+    call("di2p_pnp_pack", ptr(pc), ptr(coarse), ptr(fine), ptr(pixels), int(W_fine), F, N, ptr(corr), ptr(n_corr), stream())
+    return corr, n_corr
+
+
 def pnp_ransac(pc, coarse, fine, K_scaled, W_fine, samples, reproj_err=0.6, refine_rounds=20, refine_iters=5, pixels=None,
                method="epnp"):
     """Batched device entry.  pc f32[F,3,N], coarse/fine i32[F,N], K_scaled f64[F,3,3], samples i32[F,iters,6]

@@ -276,6 +276,12 @@ int di2p_pack_pc_label(const float* pc, const int32_t* coarse_pred, const int32_
  *   -> P f64[F,4,4] (identity when rejected), outlier_ratio f64[F] (1 when rejected), n_inliers, n_corr, best i32[F].
  *   workspace: di2p_pnp_workspace_bytes(F, N, iters). */
 long long di2p_pnp_workspace_bytes(int F, int N, int iters);
+/* The correspondence list alone: what solve_PnP (evaluation/registration_pnp.py:97-110) hands to cv2.solvePnPRansac (:125-127) -- points =
+ * pc[:, coarse == 1], pixels = (fine - floor(fine / W) * W, floor(fine / W)), in point order.  corr f32[F][N][8] = {x, y, z, u, v, 0, 0, 0},
+ * the first n_corr[f] records of frame f valid.  (The RANSAC entry points below pack internally; this one exists so the packing can be
+ * compared with what the reference's own function passes to OpenCV: tests/golden/pnp_frontend_golden.npz.) */
+int di2p_pnp_pack(const float* pc, const int32_t* coarse, const int32_t* fine, const float* pixels, int W_fine, int F, int N,
+                  float* corr, int32_t* n_corr, void* stream);
 int di2p_pnp_ransac(const float* pc, const int32_t* coarse, const int32_t* fine, const float* pixels,
                     const double* K_scaled, int W_fine, const int32_t* samples, int iters, double reproj_err,
                     int refine_rounds, int refine_iters, int F, int N, double* P_out, double* outlier_ratio, int32_t* n_inliers,

@@ -21,6 +21,16 @@ def correspondences(pc, coarse, fine, W_fine, pixels=None):
     return X, uv
 
 
+def accept(R, t, n_inliers, n_corr, success=True):
+    """evaluation/registration_pnp.py:133-141: the pose is kept iff the estimator succeeded and |t| < 14.14; "cost" = outlier ratio.
+    PINNED by tests/golden/pnp_frontend_golden.npz (the reference's solve_PnP run against a recording cv2)."""
+    P = np.identity(4)
+    if success and np.linalg.norm(t) < 14.14:
+        P[:3, :3], P[:3, 3] = R, np.asarray(t).reshape(3)
+        return P, 1.0 - n_inliers / n_corr
+    return P, 1.0
+
+
 def dlt6(X, uv, K):
     """X 3x6, uv 2x6 -> (R, t) or None."""
     fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
@@ -129,8 +139,5 @@ def pnp_ransac(pc, coarse, fine, K_scaled, W_fine, samples, reproj_err=0.6, refi
         if c1 < nin:
             break
         R, t, nin = R1, t1, c1
-    P = np.eye(4)
-    if np.linalg.norm(t) < 14.14:
-        P[:3, :3], P[:3, 3] = R, t
-        return P, 1.0 - nin / cnt, nin, cnt, best, counts
-    return P, 1.0, nin, cnt, best, counts
+    P, ratio = accept(R, t, nin, cnt)
+    return P, ratio, nin, cnt, best, counts

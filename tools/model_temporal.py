@@ -89,6 +89,7 @@ def main():
             # cache per ring size: recorded sweep index and slack per cluster
             rec_it = {g: np.full(nc, -1) for g in ring}
             rec_sl = {g: np.zeros(nc) for g in ring}
+            rec2_it = np.full(nc, -1); rec2_sl = np.zeros((nc, 2))         # two-group variant (ring 8): slack towards {L, R, Z} and {T, B}
             for s, xi in enumerate(tr):
                 Rm = synthetic.ry_matrix(xi[0]); t = xi[1:4]
                 pc = (Rm @ cc.T).T + t
@@ -108,6 +109,7 @@ def main():
                 tot["nc"] = tot.get("nc", 0) + nc
                 # slack of the clusters that need per-point work
                 sl = np.zeros(nc)
+                sl2 = np.zeros((nc, 2))
                 for c in work:
                     p = (Rm @ pts[:, clusters[c][1]]).T + t
                     fp = np.abs(p @ normals.T) / n1
@@ -120,6 +122,31 @@ def main():
                     else:
                         slp = fp.min(1)
                     sl[c] = slp.min()
+                    # two groups: planes L, R, Z do not see t_y, planes T, B see the rotation only through their (small) p2 coefficient
+                    gA, gB = [0, 1, 4], [2, 3]
+                    if labs[c] == 1:
+                        mnA, mnB = sg[:, gA].min(1), sg[:, gB].min(1)
+                        useA = mnA <= mnB
+                        sA = np.where(out, np.where(useA, -mnA, np.inf), mnA)
+                        sB = np.where(out, np.where(useA, np.inf, -mnB), mnB)
+                    else:
+                        sA, sB = fp[:, gA].min(1), fp[:, gB].min(1)
+                    sl2[c] = (sA.min(), sB.min())
+                cT = max(normals[2, 1] / n1[2], normals[3, 1] / n1[3] * -1 if normals[3, 1] < 0 else normals[3, 1] / n1[3])
+                bT = max(abs(normals[2, 2]) / n1[2], abs(normals[3, 2]) / n1[3])
+                aT = max(abs(normals[2, 1]) / n1[2], abs(normals[3, 1]) / n1[3])
+                for c in work:
+                    hit = False
+                    if rec2_it[c] >= 0 and s - rec2_it[c] < 8:
+                        xr = tr[rec2_it[c]]
+                        rot = abs(xi[0] - xr[0]) * rho[c]
+                        muA = rot + max(abs(xi[1] - xr[1]), abs(xi[3] - xr[3]))
+                        muB = aT * abs(xi[2] - xr[2]) + bT * (rot + abs(xi[3] - xr[3]))
+                        hit = muA * 1.0001 < rec2_sl[c, 0] and muB * 1.0001 < rec2_sl[c, 1]
+                    key = ("hit" if hit else "miss", int(st[c]), "2grp")
+                    tot[key] = tot.get(key, 0) + 1
+                    if not hit:
+                        rec2_it[c] = s; rec2_sl[c] = sl2[c]
                 for g in ring:
                     ri, rs = rec_it[g], rec_sl[g]
                     for c in work:
@@ -135,10 +162,10 @@ def main():
     sw = tot["sweeps"]
     print("sweeps per hypothesis: mean %.1f median %.0f max %d ; clusters per frame %.0f" % (np.mean(nsweeps), np.median(nsweeps), max(nsweeps), tot["nc"] / sw))
     print("per sweep: classify %.1f guard-only %.1f clusters" % (tot[("n", 1)] / sw, tot[("n", 3)] / sw))
-    for g in ring:
+    for g in ring + ["2grp"]:
         for kind, nm in ((1, "classify"), (3, "guard")):
             h, m = tot.get(("hit", kind, g), 0), tot.get(("miss", kind, g), 0)
-            print("ring %-10s %-9s hit rate %.3f  (%d / %d)" % (g if g < 10 ** 9 else "unbounded", nm, h / max(h + m, 1), h, h + m))
+            print("ring %-10s %-9s hit rate %.3f  (%d / %d)" % (g if (g == "2grp" or g < 10 ** 9) else "unbounded", nm, h / max(h + m, 1), h, h + m))
 
 
 main()
