@@ -164,7 +164,9 @@ def launch_selftest(args):
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"launch_selftest": True, "n_gpus": world, "requested_gpus": args.gpus, "backend": backend if world > 1 else None,
-                          "max_rank_plus_one": float(t.item())}))
+                          "max_rank_plus_one": float(t.item()),
+                          # what the ranks run with: the launcher only fills these in when the caller's environment has not set them
+                          "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "MASTER_ADDR", "GPU_MAX_HW_QUEUES")}}))
 
 
 def broadcast_weights(detector, dist, backend):
@@ -275,12 +277,17 @@ def main():
         if world > 1:
             dist.barrier()
 
+    rank_ms = {}
+
     def timed_loop(with_h2d):
         dt, o, lat = ex.throughput(args.steps, args.warmup, with_h2d, barrier=barrier)
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+            # the contract's time is the MAX over ranks; every rank's own time is kept too, so that a scaling run explains itself
+            mine = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            rank_ms["with_h2d" if with_h2d else "resident"] = [float(t.item()) / args.steps * 1e3 for t in every]
+            dt = max(float(t.item()) for t in every)
         return dt, o, lat
 
     dt, out, lat = timed_loop(False)
@@ -387,7 +394,7 @@ def main():
     # HBM traffic per launch from the committed PMC passes of the same kernels on the same shapes (separate rocprofv3
     # --pmc FETCH_SIZE / WRITE_SIZE runs, corrected as MI355X_MICROARCH.md prescribes); None if absent
     pmc = {}
-    for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fn in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as fh:
                 pmc = json.load(fh)
@@ -399,11 +406,18 @@ def main():
         roofs["index_max_kernel"]["traffic_C64"] = pmc.get("index_max_C64_B32_N20480_K128", {}).get("hbm_bytes_corrected")
         roofs["solve_kernel"]["traffic"] = pmc.get("solve_kernel_F32_R60_N20480", {}).get("hbm_bytes_corrected")
     # executed fp64 flop of the solver: from the committed instruction-counter pass of the same kernel on the same workload shape
-    # (tools/prof_solver_counters.sh -> profiles/r03_solver_counters.json: 64 lanes x (2 FMA + ADD + MUL) wave-instructions per launch)
+    # (tools/prof_solver_counters.sh -> profiles/r04_solver_counters.json, taken on the SHIPPED instantiation of the kernel:
+    # 64 lanes x (2 FMA + ADD + MUL) wave-instructions per launch)
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_solver_counters.json")) as fh:
-            sc = json.load(fh)
-        if B == 32 and R == 60 and N == 20480:
+        sc = None
+        for fn in ("r04_solver_counters.json", "r03_solver_counters.json"):
+            path = os.path.join(ROOT, "profiles", fn)
+            if os.path.exists(path):
+                with open(path) as fh:
+                    sc = json.load(fh)
+                roofs["solve_kernel"]["counters_file"] = "profiles/" + fn
+                break
+        if sc is not None and B == 32 and R == 60 and N == 20480:
             ex_flop = 64.0 * (2 * sc["SQ_INSTS_VALU_FMA_F64"] + sc["SQ_INSTS_VALU_ADD_F64"] + sc["SQ_INSTS_VALU_MUL_F64"])
             roofs["solve_kernel"]["executed_fp64_flop_per_launch"] = ex_flop
             roofs["solve_kernel"]["achieved_executed"] = ex_flop / (sol_ms * 1e-3) / 1e12
@@ -428,8 +442,11 @@ def main():
         cpu_baseline = run_cpu_baseline(batch, sd, opt, H, W, R)
 
     collective = None
-    if hyp and world > 1:
+    if world > 1:
+        # hyp mode: the exchange step of the path.  frames mode: there is NO data-path collective (frames are independent); the same small
+        # all_gather is timed anyway as a probe of the RCCL / xGMI set-up the ranks run on
         collective = measure_collective(dist, backend, dev, B, R, world)
+        collective["in_data_path"] = bool(hyp)
     placement = [{"rank": rank, "device": local_rank, "device_count": torch.cuda.device_count(), "name": torch.cuda.get_device_name(local_rank)}]
     if world > 1:
         gathered = [None] * world
@@ -449,8 +466,14 @@ def main():
                        "mode": args.mode, "frames_per_gpu_per_step": B, "points": N, "image": [H, W], "restarts": R,
                        "parallelism": ("hyp%d" if hyp else "dp%d") % world, "streams": n_streams, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "hip_graph": bool(use_graph),
                        "weights_broadcast_bytes": bcast_bytes, "placement": placement},
+            "value_resident": frames / dt,
             "value_with_h2d": (frames / dt_h2d) if dt_h2d else None,
             "ms_per_step_with_h2d": (dt_h2d / args.steps * 1e3) if dt_h2d else None,
+            "value_definition": "`value` = `value_resident`: every step's inputs are already in HBM when the timed region starts (the bench "
+                                "contract: inputs resident; a PCIe-inclusive rate is never `value`).  `value_with_h2d` = SURVEY.md 8(d)'s "
+                                "definition of the metric: the same loop with the host->device copy of every batch (50 MB from pinned host "
+                                "memory) inside the step.",
+            "per_rank_ms_per_step": rank_ms or None,
             "latency_ms_per_batch": {"streams_%d" % n_streams: (sum(lat) / len(lat)) if lat else None,
                                      "streams_%d_with_h2d" % n_streams: (sum(lat_h2d) / len(lat_h2d)) if lat_h2d else None,
                                      "one_step_in_flight": (sum(lat1) / len(lat1)) if lat1 else None,
@@ -528,6 +551,26 @@ def main_train(args):
     torch.cuda.synchronize()
     fam = {k: (sum(a.elapsed_time(c) for a, c, _ in v), len(v)) for k, v in _lib.TIMED.items() if v}
     _lib.TIMED = None
+    # roofline of the time-dominant family of a training step: the MFMA contractions (forward, input gradients, weight gradients).
+    # Algorithmic work = what autograd of the reference's graph does: forward + dgrad + wgrad = 3 x the forward multiply-accumulates of
+    # SURVEY.md 8(d) (coarse + fine model: 13.284 GMAC per frame at 20480 points / 160x512), minus the input gradient of the stem (the
+    # image needs none).  Time = HIP events around every contraction call of one serial step.
+    mfma_calls = ("di2p_pointwise_gemm", "di2p_point_head", "di2p_conv3x3_winograd", "di2p_conv2d", "di2p_conv2d_ws", "di2p_conv7x7s2_stem",
+                  "di2p_conv2d_wgrad", "di2p_conv2d_dgrad", "di2p_bmm_rc", "di2p_bmm_km", "di2p_gather_backward", "di2p_winograd_weight_transform")
+    mfma_ms = sum(fam[k][0] for k in mfma_calls if k in fam)
+    roofline = None
+    if (N, H, W) == (20480, 160, 512) and mfma_ms > 0:
+        gmac_fwd = 13.284
+        stem_gmac = 3 * 64 * 49 * (H // 2) * (W // 2) / 1e9
+        algo = 2e9 * (3 * gmac_fwd - stem_gmac) * B
+        roofline = {"kernel": "mfma contraction family of the training step (forward + dgrad + wgrad: %s)" % ", ".join(k for k in mfma_calls if k in fam),
+                    "bound": "mfma", "achieved": algo / (mfma_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": algo / (mfma_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None, "ms_per_step": mfma_ms,
+                    "algorithmic_per_launch": algo / max(sum(fam[k][1] for k in mfma_calls if k in fam), 1),
+                    "step_fraction": mfma_ms / (1e3 * dt / args.steps),
+                    "note": "achieved = reference-algorithmic flops (3 x forward 2*MAC of SURVEY 8d, coarse+fine, minus the stem's input gradient) / "
+                            "summed event time of the contraction calls of one serial step; fp32-input MFMA peak; the rest of the step is "
+                            "BatchNorm statistics / normalisation passes (HBM-bound), routers and the optimiser"}
     if rank == 0:
         top = sorted(fam.items(), key=lambda kv: -kv[1][0])[:10]
         line = {"metric": "training frames/sec (train-mode fwd + focal/CE loss + bwd + gradient all-reduce + Adam) KITTI 20k-pt 160x512, batch %d per GPU" % B,
@@ -539,6 +582,7 @@ def main_train(args):
                            "mode": "train", "frames_per_gpu_per_step": B, "points": N, "image": [H, W], "parallelism": "dp%d" % world,
                            "weights_broadcast_bytes": bcast_bytes},
                 "gradient_allreduce": {"bytes": int(tr.flat_grad.numel() * 4), "ms": ar_ms, "launches_per_step": 1},
+                "roofline": roofline,
                 "loss_first_last": [float(losses[0]), float(losses[-1])],
                 "calls_ms_per_step": {k: {"ms": round(v[0], 3), "calls": v[1]} for k, v in top},
                 "note": "calls_ms_per_step: HIP events around every C-ABI call of one extra serial step (ATen views/concatenations excluded)"}

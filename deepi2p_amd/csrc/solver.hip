@@ -367,7 +367,8 @@ __device__ __forceinline__ double lm_sqrt(double a) {
     double g = a * y, h = 0.5 * y;
     const double r = fma(-h, g, 0.5);
     g = fma(g, r, g); h = fma(h, r, h);
-    return fma(fma(-g, g, a), h, g);
+    const double v = fma(fma(-g, g, a), h, g);
+    return a == 0.0 ? 0.0 : v;              // rsq(0) = inf would turn sqrt(0) into NaN: a zero step / iterate norm must satisfy the parameter tolerance
 #else
     return sqrt(a);
 #endif
@@ -1559,7 +1560,6 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
     const int* counts = a->counts;
     const int cnt1 = counts[4 * f], cnt0 = counts[4 * f + 1], nc1 = counts[4 * f + 2], nc0 = counts[4 * f + 3];
     const double* Kf = a->Kmat + (long long)f * 9;
-    const Cam k{Kf[0], Kf[4], Kf[2], Kf[5], a->H - 1.0, a->W - 1.0};
     const int nocull = a->nocull;
     const long long hr = (long long)f * R + r;
     CacheEnt* cache = a->cache + hr * (a->NCMAX + CACHE_PAD);
@@ -1603,6 +1603,11 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
 #pragma unroll
         for (int i = 0; i < NP; ++i) xe[i] = st.xe[i];
         const int s_now = st.nsweep - s_base;
+        // the camera is re-read (scalar loads, cache hits) at the head of every sweep through a laundered pointer: hoisted out of the sweep
+        // loop its twelve dwords were kept in VGPRs and SPILLED (nine scratch reloads per sweep)
+        const double* Kq = Kf;
+        asm volatile("" : "+s"(Kq));
+        const Cam k{Kq[0], Kq[4], Kq[2], Kq[5], a->H - 1.0, a->W - 1.0};
         const long long t0 = PROFILE ? clock64() : 0;
         sweep<NP, PT, WPH, 2, PROFILE>(recs, boxes, cnt1, cnt0, nc1, nc0, k, xe, nocull, sh, cache, s_now, n_act, tp);
         const long long t1 = PROFILE ? clock64() : 0;
@@ -1643,6 +1648,9 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
             }
         }
         const long long t2d = PROFILE ? clock64() : 0;
+        // the last stage re-reads the combined sums from LDS: kept in registers across the wave-wide minimiser (the compiler merges these
+        // loads with lm_decide's) they were spilled -- three scratch reloads with a full wait on the lane everybody waits for, four times per sweep
+        asm volatile("" ::: "memory");
         if (threadIdx.x == 0) {
             if (action == ACT_TRIAL_NEXT) action = lm_trial_next_decide<NP>(st);
             lm_apply<NP>(st, action, sh.comb[0], sh.comb + 1, sh.comb + 1 + NP);

@@ -449,6 +449,8 @@ extern "C" int di2p_conv3x3_winograd(const float* x, const float* U, const float
     DI2P_CHECK_ARG(B >= 0 && Cin >= 8 && Cin % 8 == 0 && Cout >= 32 && Cout % 32 == 0 && H >= 1 && W >= 4 && W % 2 == 0,
                    "needs Cin % 8 == 0, Cout % 32 == 0 and an even width >= 4");
     DI2P_CHECK_ARG(((uintptr_t)U & 15) == 0 && ((uintptr_t)y & 7) == 0, "U must be 16-byte and y 8-byte aligned");
+    // both kernels read the residual's two pixels of a row as one 8-byte load
+    DI2P_CHECK_ARG(((uintptr_t)residual & 7) == 0, "residual must be 8-byte aligned");
     DI2P_CHECK_ARG((long long)Cin * H * W < (1ll << 31), "per-image extent must fit 31 bits");
     if (B == 0) return 0;
     const int TH = (H + 1) / 2, TW = (W + 1) / 2;
@@ -478,7 +480,7 @@ extern "C" int di2p_conv3x3_winograd(const float* x, const float* U, const float
     // 16 KB of LDS per workgroup (against 32-64 KB) lets it share a CU with the pose solver's workgroups: +2.8 % frames/s with the
     // threshold at 300 instead of 1024 (tools/sweep_wino_reg_min.sh); at the 512-channel stage (192 workgroups) the LDS-panel kernel stays
     const bool reg_auto = reg_opt == 0 && (long long)di2p_cdiv(total, 64) * (Cout / 32) >= di2p_opt(DI2P_OPT_WINO_REG_MIN);
-    if ((reg_opt >= 2 || reg_auto) && Cin % 4 == 0 && ((uintptr_t)residual & 7) == 0) {
+    if ((reg_opt >= 2 || reg_auto) && Cin % 4 == 0) {
         const int nw = reg_opt == 3 ? 2 : 4;
         const int n_tb_r = di2p_cdiv(total, nw * 16), n_cb = Cout / 32;
         const int grid = di2p_cdiv(n_tb_r, 8) * 8 * n_cb;

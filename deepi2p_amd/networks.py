@@ -94,12 +94,25 @@ class _PackedModule(nn.Module):
     def __init__(self):
         super().__init__()
         self._packed = None
+        self._weights_version = 0
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
 
     def _invalidate(self):
+        """Drop the derived kernel operands (weights changed or moved) and bump the version every holder of those operands checks --
+        a captured hipGraph keeps RAW pointers to them (pipeline.RegistrationExecutor re-captures when the version moves)."""
         for m in self.modules():
             if isinstance(m, _PackedModule):
                 m._packed = None
+                m._weights_version += 1
+
+    @property
+    def weights_version(self):
+        """Changes whenever load_state_dict / .to() / an optimiser step invalidated the packed operands of this module or a sub-module."""
+        return sum(m._weights_version for m in self.modules() if isinstance(m, _PackedModule))
+
+    def packed_operands(self):
+        """The live packed-operand containers of this module tree (a holder of raw pointers keeps them referenced)."""
+        return [m._packed for m in self.modules() if isinstance(m, _PackedModule) and m._packed is not None]
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)

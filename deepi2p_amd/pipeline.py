@@ -23,6 +23,10 @@ import torch
 from . import ops
 
 INPUT_NAMES = ("pc", "intensity", "sn", "node_a", "node_b", "img")
+# per-batch camera matrices (the reference's loader hands K with every batch: visualize_and_save_data.py:81-90, set_input(..., P, img, K)).
+# Optional in a host batch: when present it is staged, copied and read by the step like the other six; when absent the slot keeps the
+# K it was constructed with / last given.
+K_NAME = "K"
 
 
 class Slot:
@@ -42,8 +46,15 @@ class RegistrationExecutor:
     """mm: a deepi2p_amd.networks.MMClassifer(Coarse) with weights loaded; pipe: a deepi2p_amd.registration.RegistrationPipeline.
 
     executor = RegistrationExecutor(mm, pipe, K, example_batch, n_streams=8)
-    ticket = executor.submit(host_batch)          # dict of CPU tensors pc/intensity/sn/node_a/node_b/img; returns at once
+    ticket = executor.submit(host_batch)          # dict of CPU tensors pc/intensity/sn/node_a/node_b/img [+ K]; returns at once
     out = executor.result(ticket)                 # dict: pred i32[B,N], P f64[B,4,4], cost, best, iters, ... (device tensors of the slot)
+
+    Fixed per executor (they are baked into the captured graphs): the batch SHAPE (every host batch must have the example's shapes --
+    pad a short last batch; a mismatch raises), the restart list (``restarts``: one draw for all steps; pass your own, or build one
+    executor per list) and the solver settings of ``pipe``.  Per batch: the six network inputs and the camera matrices ``K``
+    (f32 / f64 [B,3,3]; a per-slot device buffer the graph reads, so datasets with per-sequence or per-frame intrinsics are solved with
+    THEIR K).  The executor follows the classifier's weights: when they change (load_state_dict, .to(), an optimiser step) the next
+    submit re-packs the kernel operands and re-captures the graphs instead of replaying against freed or stale operands.
 
     labels_override: i32[B,N] device tensor fed to the solver INSTEAD of the network's argmax (the benchmark's synthetic labels,
     SURVEY.md 8d: random-init weights predict nothing); default None = the network's own prediction, as the reference does."""
@@ -55,8 +66,12 @@ class RegistrationExecutor:
         self.n_streams = max(1, int(n_streams))
         self.use_graph = bool(use_graph)
         self.labels_override = labels_override
-        self.K64 = K.to(self.device, torch.float64).contiguous()
         B = int(example_batch["pc"].shape[0])
+        self.K64 = K.to(self.device, torch.float64).contiguous()
+        if self.K64.dim() == 2:
+            self.K64 = self.K64.unsqueeze(0).expand(B, 3, 3).contiguous()
+        if tuple(self.K64.shape) != (B, 3, 3):
+            raise ValueError("K must be [3,3] or [B,3,3] with B = %d frames, got %s" % (B, tuple(K.shape)))
         self.restarts = restarts if restarts is not None else pipe.draw(B, self.device)
         self.step_fn = step_fn            # custom graph-capturable step: step_fn(slot, device_inputs) -> outputs dict
         self.post_fn = post_fn            # launched EAGERLY on the slot's stream after the step (work that cannot be captured, e.g. a
@@ -68,6 +83,8 @@ class RegistrationExecutor:
         # the runtime executes as blit KERNELS on the CUs (0.91-0.95; tools/sweep_h2d_mode.sh, tools/probe_h2d.sh)
         self.h2d_mode = h2d_mode
         mm.detector.prepack()                 # derive the kernel operands now, on the current stream, before other streams use them
+        self._weights_version = mm.detector.weights_version
+        self._packed_refs = mm.detector.packed_operands()     # the graphs hold raw pointers into these: keep them alive
         torch.cuda.synchronize(self.device)
         self.slots = []
         for i in range(self.n_streams):
@@ -79,6 +96,9 @@ class RegistrationExecutor:
                 s.host[k] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
                 s.host[k].copy_(t)
                 s.dev[k] = t.to(self.device, non_blocking=False).contiguous()
+            s.host[K_NAME] = torch.empty((B, 3, 3), dtype=torch.float64).pin_memory()
+            s.host[K_NAME].copy_(self.K64.cpu())
+            s.dev[K_NAME] = self.K64.clone()
             self.slots.append(s)
         self._next = 0
         self._h2d_warm = False
@@ -90,7 +110,7 @@ class RegistrationExecutor:
     def _step(self, slot, with_h2d):
         """Enqueue one step on the CURRENT stream (the slot's stream, or the capturing stream)."""
         if with_h2d:        # a1: MMClassifer.set_input's copies (multimodal_classifier.py:82-93), from the slot's pinned buffers
-            for k in INPUT_NAMES:
+            for k in INPUT_NAMES + (K_NAME,):
                 slot.dev[k].copy_(slot.host[k], non_blocking=True)
         d = slot.dev
         if self.step_fn is not None:
@@ -99,7 +119,7 @@ class RegistrationExecutor:
         coarse = logits[0] if isinstance(logits, tuple) else logits
         pred = ops.argmax_channels(coarse)                                   # inference_pass (:100-117): i32 [B,N]
         labels = self.labels_override if self.labels_override is not None else pred
-        out = self.pipe(d["pc"], labels, self.K64, self.restarts)            # same stream: the pose solve follows its classification
+        out = self.pipe(d["pc"], labels, d[K_NAME], self.restarts)           # same stream: the pose solve follows its classification
         out["pred"] = pred
         if isinstance(logits, tuple):
             out["fine_pred"] = ops.argmax_channels(logits[1])
@@ -117,6 +137,7 @@ class RegistrationExecutor:
     def warm_up(self, with_h2d=True):
         """Capture (or run once) every slot's step so that the first timed submit pays nothing extra.  A failed capture switches the
         executor to eager launches (and remembers why in `graph_error`)."""
+        self._follow_weights()
         want_h2d = bool(with_h2d)
         with_h2d = with_h2d and self.h2d_mode == "graph"
         for slot in self.slots:
@@ -143,7 +164,7 @@ class RegistrationExecutor:
             # slot here, like the graph capture above, not inside somebody's first timed steps
             for slot in self.slots:
                 with torch.cuda.stream(slot.copy_stream if slot.copy_stream is not None else slot.stream):
-                    for k in INPUT_NAMES:
+                    for k in INPUT_NAMES + (K_NAME,):
                         slot.dev[k].copy_(slot.host[k], non_blocking=True)
             self._h2d_warm = True
         self._warmed.add(want_h2d)
@@ -165,27 +186,38 @@ class RegistrationExecutor:
         re-sent from its pinned buffers (with_h2d=True)."""
         if with_h2d is None:
             with_h2d = host_batch is not None
+        self._follow_weights()
         if bool(with_h2d) not in self._warmed:
             self.warm_up(with_h2d)                # first use: captures, first replays, first copies (synchronises the device once)
         slot = self.slots[self._next]
         self._next = (self._next + 1) % self.n_streams
+        if host_batch is not None:
+            for k in INPUT_NAMES + ((K_NAME,) if K_NAME in host_batch else ()):
+                if tuple(host_batch[k].shape) != tuple(slot.host[k].shape):
+                    raise ValueError("host batch %r has shape %s, this executor was built (and its graphs captured) for %s -- pad the batch "
+                                     "or build an executor for that shape" % (k, tuple(host_batch[k].shape), tuple(slot.host[k].shape)))
+            if not with_h2d:
+                raise ValueError("a host batch needs with_h2d=True (its copies are part of the step)")
         if slot.busy and host_batch is not None:
             slot.done.synchronize()               # new host data: the slot's previous H2D copies must have read the pinned buffers
         if host_batch is not None:
             for k in INPUT_NAMES:
                 slot.host[k].copy_(host_batch[k])
+            if K_NAME in host_batch:
+                slot.host[K_NAME].copy_(host_batch[K_NAME])       # f32 -> f64 on the way into the pinned buffer
+        names = INPUT_NAMES + (K_NAME,)
         in_step = with_h2d and self.h2d_mode == "graph"
         if with_h2d and self.h2d_mode == "copy_stream":
             with torch.cuda.stream(slot.copy_stream):
                 if slot.busy:
                     slot.copy_stream.wait_event(slot.done)        # the previous step of this slot still reads the device inputs
-                for k in INPUT_NAMES:
+                for k in names:
                     slot.dev[k].copy_(slot.host[k], non_blocking=True)
                 slot.copied.record()
         with torch.cuda.stream(slot.stream):
             slot.start.record()
             if with_h2d and self.h2d_mode == "eager":
-                for k in INPUT_NAMES:
+                for k in names:
                     slot.dev[k].copy_(slot.host[k], non_blocking=True)
             elif with_h2d and self.h2d_mode == "copy_stream":
                 slot.stream.wait_event(slot.copied)
@@ -202,6 +234,24 @@ class RegistrationExecutor:
             slot.done.record()
         slot.busy = True
         return slot.index
+
+    def _follow_weights(self):
+        """The captured graphs hold raw pointers to the classifier's PACKED operands, which the module frees and re-derives whenever its
+        weights change (load_state_dict, .to(), ClassifierTrainer.optimize).  Re-pack and re-capture then, instead of replaying against
+        freed or stale operands."""
+        v = self.mm.detector.weights_version
+        if v == self._weights_version:
+            return
+        torch.cuda.synchronize(self.device)           # nothing of the old graphs may still be running
+        for s in self.slots:
+            s.graphs.clear()
+            s.busy = False
+        self._replayed.clear()
+        self._warmed.clear()
+        self.mm.detector.prepack()
+        self._packed_refs = self.mm.detector.packed_operands()
+        self._weights_version = self.mm.detector.weights_version
+        self.weights_refreshes = getattr(self, "weights_refreshes", 0) + 1
 
     def result(self, ticket, wait=True):
         """Outputs of the step last submitted on slot `ticket` (device tensors owned by the slot: valid until it is reused)."""
@@ -225,14 +275,26 @@ class RegistrationExecutor:
     def run(self, batches, with_h2d=True):
         """Push an iterable of host batches through the executor; yields (index, outputs) in submission order, each as soon as its
         slot is needed again or the input is exhausted (outputs are cloned so they survive the slot's reuse)."""
+        def take(t):
+            # the clones run on the SLOT's stream: the replay that re-uses the slot is enqueued behind them (on the caller's stream nothing
+            # would order the slot's next replay after the clone kernels); the caller's stream then waits for the clones
+            out = self.result(t)
+            slot = self.slots[t]
+            with torch.cuda.stream(slot.stream):
+                copy = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()}
+                ev = torch.cuda.Event()
+                ev.record()
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            return copy
+
         pending = []
         for i, b in enumerate(batches):
             if len(pending) == self.n_streams:
                 j, t = pending.pop(0)
-                yield j, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.result(t).items()}
+                yield j, take(t)
             pending.append((i, self.submit(b, with_h2d=with_h2d)))
         for j, t in pending:
-            yield j, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.result(t).items()}
+            yield j, take(t)
 
     def throughput(self, steps, warmup, with_h2d, barrier=None):
         """Timed loop of the benchmark contract: `warmup` untimed steps, then exactly `steps` steps between two full synchronisations.

@@ -46,6 +46,21 @@ def test_gpus_flag_spawns_the_ranks_itself():
     assert line["max_rank_plus_one"] == 2.0            # the all_reduce really spanned both ranks
 
 
+@pytest.mark.parametrize("user_value", [None, "1"])
+def test_ipc_mode_is_a_default_not_an_override(user_value):
+    """The launcher exports HSA_ENABLE_IPC_MODE_LEGACY=0 (this host driver only does dmabuf IPC; RCCL needs it) ONLY when the caller's
+    environment does not set it: a user's own value reaches the ranks untouched."""
+    env = _env()
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+    if user_value is not None:
+        env["HSA_ENABLE_IPC_MODE_LEGACY"] = user_value
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-selftest"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    seen = _last_json(r.stdout)["env"]
+    assert seen["HSA_ENABLE_IPC_MODE_LEGACY"] == (user_value if user_value is not None else "0")
+    assert seen["MASTER_ADDR"] == "127.0.0.1"
+
+
 def test_under_external_launcher_uses_its_world():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_port()), BENCH, "--gpus", "2", "--launch-selftest"]

@@ -77,3 +77,54 @@ def test_run_iterator_and_backpressure(dev):
     refs = {i: _reference(mm, pipe, K, restarts, host[i], labels, dev) for i in set(order)}
     for (j, o), i in zip(res, order):
         assert torch.equal(o["P"], refs[i]["P"]) and torch.equal(o["pred"], refs[i]["pred"])
+
+
+def test_per_batch_camera_matrix_shape_check_and_weight_updates(dev):
+    """(1) K travels with the batch: a host batch that brings its own camera matrices is solved with THEM (the reference's loader hands K
+    per batch: visualize_and_save_data.py:81-90); (2) a host batch of another shape is refused instead of being solved as the example's;
+    (3) after the classifier's weights change the executor re-packs and re-captures: the next step equals the plain operator calls with
+    the NEW weights."""
+    from deepi2p_amd.pipeline import RegistrationExecutor
+    mm, pipe, K, restarts, batches, host = _setup(dev)
+    labels = torch.from_numpy(batches[0]["labels"]).to(dev)
+    ex = RegistrationExecutor(mm, pipe, K, host[0], n_streams=2, restarts=restarts, labels_override=labels)
+    base = {k: ex.result(ex.submit(host[0]))[k].clone() for k in KEYS}
+    K2 = K.clone()
+    K2[:, 0, 0] *= 1.1
+    K2[:, 1, 1] *= 0.9
+    K2[:, 0, 2] += 3.0
+    hb = dict(host[0])
+    hb["K"] = K2.cpu().float()                         # f32 like the reference's loader; staged as f64
+    for _ in range(3):                                 # both slots see the new K, and then the old one again
+        got = {k: ex.result(ex.submit(hb))[k].clone() for k in KEYS}
+        ref = _reference(mm, pipe, K2.cpu().float().double().to(dev), restarts, host[0], labels, dev)
+        for k in KEYS:
+            assert torch.equal(got[k], ref[k]), k
+    assert not torch.equal(got["P"], base["P"])
+    hb["K"] = K.cpu()
+    for _ in range(2):
+        again = {k: ex.result(ex.submit(hb))[k].clone() for k in KEYS}
+    for k in KEYS:
+        assert torch.equal(again[k], base[k]), k
+    # (2) shapes are part of the captured graphs
+    short = {k: v[:2] for k, v in host[1].items()}
+    with pytest.raises(ValueError):
+        ex.submit(short)
+    with pytest.raises(ValueError):
+        ex.submit(host[1], with_h2d=False)
+    # (3) new weights: the prediction must follow them
+    ex2 = RegistrationExecutor(mm, pipe, K, host[0], n_streams=2, restarts=restarts)          # the network's own labels feed the solver
+    before = ex2.result(ex2.submit(host[1]))["pred"].clone()
+    sd = {k: v.clone() for k, v in mm.detector.state_dict().items()}
+    for k in sd:
+        if k.endswith("per_point_pn.layers.2.conv.bias") or k.endswith("per_point_pn.layers.2.conv.weight"):
+            sd[k] = -sd[k]                              # flips the two logits of every point
+    v0 = mm.detector.weights_version
+    mm.detector.load_state_dict(sd)
+    assert mm.detector.weights_version != v0
+    after = {k: ex2.result(ex2.submit(host[1]))[k].clone() for k in KEYS}
+    assert getattr(ex2, "weights_refreshes", 0) == 1
+    ref = _reference(mm, pipe, K, restarts, host[1], None, dev)
+    for k in KEYS:
+        assert torch.equal(after[k], ref[k]), k
+    assert not torch.equal(after["pred"], before)

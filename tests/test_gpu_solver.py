@@ -3,8 +3,9 @@
 The solver path is PARITY-UNPINNED w.r.t. Ceres (see oracle header); what is checked here is HIP == oracle:
   * residuals / cost at given parameters: 1e-9 relative (pure fp64 formula evaluation);
   * per-hypothesis solutions: the objective is discontinuous, so an LM trajectory can fork on a 1-ulp
-    difference in a reduction; required: >= 90 % of hypotheses agree to |dt| <= 1e-3 m, |dR| <= 1e-3 rad and
-    the best-of-R cost agrees to 1e-6 relative (stated tolerance)."""
+    difference in a reduction.  The bar is what is MEASURED on these fixed seeds: EVERY hypothesis agrees to |dt| <= 1e-3 m,
+    |dR| <= 1e-3 rad (with equal iteration counts) except the ones enumerated in KNOWN_FORKS, and the best-of-R cost agrees to
+    1e-6 relative (stated tolerance).  A regression that makes one more hypothesis fork fails the test."""
 import math
 
 import numpy as np
@@ -57,6 +58,18 @@ def test_initial_guess_matches_oracle(dev):
     np.testing.assert_allclose(P0, P1, atol=1e-12)
 
 
+# hypotheses (by index) whose HIP trajectory ends in another local minimum than the oracle's on these fixed seeds -- the two
+# implementations differ by an ulp per residual and by summation order, and the objective jumps where a point crosses a frustum plane.
+# Measured on MI355X (tools/solver_oracle_agreement.py prints the same lists); everything not listed must agree.
+KNOWN_FORKS = {
+}
+
+
+def _check_forks(key, ok):
+    bad = sorted(np.nonzero(~ok)[0].tolist())
+    assert bad == KNOWN_FORKS.get(key, []), "hypotheses that disagree with the oracle on case %r: %s (expected %s)" % (key, bad, KNOWN_FORKS.get(key, []))
+
+
 def _agreement(po, pg, is_2d):
     toff = 1 if is_2d else 3
     dt = np.linalg.norm(po[:, toff:] - pg[:, toff:], axis=1)
@@ -74,10 +87,11 @@ def test_solver_matches_oracle_per_hypothesis(dev, is_2d, N, R):
     Po, co, it_o, term_o, par_o = flm.solve_restarts(pcf, labf, f["K"], ys, Ts, H, W, LB, UB, 500, is_2d, nthreads=8)
     Pg, cg, best, par_g, it_g = registration.solvePGivenK_batched(pcf, labf, f["K"], ys, Ts, H, W, LB, UB, 500, is_2d, return_all=True)
     ok = _agreement(par_o, par_g, is_2d)
-    assert ok.mean() >= 0.95, "only %.0f%% of hypotheses agree (iters oracle %s, hip %s)" % (100 * ok.mean(), it_o, it_g)     # measured: all of them (tools/solver_oracle_agreement.py)
+    _check_forks(("per_hypothesis", is_2d, N, R), ok)
     np.testing.assert_allclose(cg[ok], co[ok], rtol=1e-6)
     assert abs(cg.min() - co.min()) <= 1e-6 * co.min()
     np.testing.assert_allclose(Pg[ok], Po[ok], atol=2e-3)
+    np.testing.assert_array_equal(it_g[ok], it_o[ok])
     # bounds respected
     toff = 1 if is_2d else 3
     assert np.all(par_g[:, toff:] >= np.array(LB) - 1e-12) and np.all(par_g[:, toff:] <= np.array(UB) + 1e-12)
@@ -219,7 +233,7 @@ def test_small_and_ragged_frames(dev, N):
     # tiny problems are rank-deficient / flat: require agreement of the COST wherever the iterates agree, and of the best cost
     np.testing.assert_allclose(cg[ok], co[ok], rtol=1e-6, atol=1e-12)
     assert abs(cg.min() - co.min()) <= 1e-6 * max(co.min(), 1e-9) + 1e-12
-    assert ok.mean() >= 0.5
+    _check_forks(("ragged", N), ok)
 
 
 @pytest.mark.parametrize("seed,is_2d,N,HW,flip", [(31, True, 8192, (384, 640), 0.1), (32, False, 3000, (64, 128), 0.02),
@@ -238,7 +252,7 @@ def test_solver_matches_oracle_other_cameras(dev, seed, is_2d, N, HW, flip):
     Po, co, it_o, term_o, par_o = flm.solve_restarts(pcf, labf, f["K"], ys, Ts, h, w, LB, UB, 500, is_2d, nthreads=8)
     Pg, cg, best, par_g, it_g = registration.solvePGivenK_batched(pcf, labf, f["K"], ys, Ts, h, w, LB, UB, 500, is_2d, return_all=True)
     ok = _agreement(par_o, par_g, is_2d)
-    assert ok.mean() >= 0.95, "only %.0f%% of hypotheses agree (iters oracle %s, hip %s)" % (100 * ok.mean(), it_o, it_g)     # measured: all of them (tools/solver_oracle_agreement.py)
+    _check_forks(("other_cameras", seed), ok)
     np.testing.assert_allclose(cg[ok], co[ok], rtol=1e-6)
     assert abs(cg.min() - co.min()) <= 1e-6 * co.min()
     np.testing.assert_array_equal(it_g[ok], it_o[ok])            # same number of LM iterations where the iterates agree
