@@ -335,6 +335,7 @@ struct SweepShared {
     int acc_e[WPH][64];
     alignas(16) float btest[WPH][BOXTEST_WORDS];   // the wave's box-test table of the current sweep (wave-uniform, re-read per cluster round)
     alignas(16) double ring[8][NP];                // iterates of the last RING sweeps (slot = sweep number % RING), see the classification cache
+    double rot_cs[2];                              // 2-D solver: cos / sin of the iterate about to be swept, computed ONCE per sweep by the LM lane
 };
 
 // v_rcp_f64 + two Newton steps: <= 1 ulp for finite non-zero inputs; 0 / inf / NaN give inf / 0 / NaN-like values that the
@@ -1000,7 +1001,13 @@ __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Bo
     constexpr int TOFF = NP == 4 ? 1 : 3;
     static_assert(sizeof(BoxAbs) == BOXTEST_WORDS * 4, "box-test table is copied as float4s");
     Rot<NP> rot;
-    make_rot<NP>(x, rot);
+    if (NP == 4) {
+        // the rotation of the iterate comes from the LM lane (one fp64 sincos per sweep and workgroup instead of one per wave; same bits)
+        const double c = sh.rot_cs[0], s = sh.rot_cs[1];
+        rot.R[0] = c; rot.R[1] = 0; rot.R[2] = s; rot.R[3] = 0; rot.R[4] = 1; rot.R[5] = 0; rot.R[6] = -s; rot.R[7] = 0; rot.R[8] = c;
+    } else {
+        make_rot<NP>(x, rot);
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int* queue = sh.queue[wave];
     double (*acc)[64] = sh.acc[wave];
@@ -1591,15 +1598,17 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
     int n_act[6] = {0, 0, 0, 0, 0, 0};   // wave 0: phase-B evaluations, clusters classified per point / all active / guard-only, cache hits {classification, guard}
     // sweep numbers of the classification cache count from this launch's first sweep (resume: the cache and the ring start empty)
     const int s_base = a->resume ? st.nsweep : 0;
-    if (a->resume) {
-        if (threadIdx.x == 0)
-            for (int i = 0; i < NP; ++i) sh.ring[0][i] = st.xe[i];
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        double xn[NP];
+        for (int i = 0; i < NP; ++i) { xn[i] = st.xe[i]; sh.ring[0][i] = xn[i]; }
+        if (NP == 4) { Rot<NP> r0; make_rot<NP>(xn, r0); sh.rot_cs[0] = r0.R[0]; sh.rot_cs[1] = r0.R[2]; }
     }
+    __syncthreads();
     long long tp[4] = {0, 0, 0, 0}; // wave 0, inside the sweep: cluster-test rounds, drains (phase B), set-up, reduction
     long long c_decide = 0, c_poly = 0, c_apply = 0;
     for (;;) {
         double xe[NP];
+        asm volatile("" ::: "memory");          // the iterate is READ from LDS here by every thread (nothing carried in registers around the loop)
 #pragma unroll
         for (int i = 0; i < NP; ++i) xe[i] = st.xe[i];
         const int s_now = st.nsweep - s_base;
@@ -1639,6 +1648,7 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
             action = lm_decide<NP>(st, ok, sh.comb[0], sh.comb + 1, sh.comb + 1 + NP);
         }
         const long long t2c = PROFILE ? clock64() : 0;
+        asm volatile("" ::: "memory");          // the interpolant is read back from LDS by all 64 lanes (not forwarded from lane 0's registers)
         if (threadIdx.x < 64) {                 // wave 0: a failed trial left an interpolant to minimise (wave-uniform branch)
             __builtin_amdgcn_wave_barrier();
             if (st.poly_req) {
@@ -1656,8 +1666,10 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
             lm_apply<NP>(st, action, sh.comb[0], sh.comb + 1, sh.comb + 1 + NP);
             // the iterate of the NEXT sweep enters the ring of the classification cache (slot = its sweep number % RING)
             const int slot = (st.nsweep - s_base) & (RING - 1);
+            double xn[NP];
 #pragma unroll
-            for (int i = 0; i < NP; ++i) sh.ring[slot][i] = st.xe[i];
+            for (int i = 0; i < NP; ++i) { xn[i] = st.xe[i]; sh.ring[slot][i] = xn[i]; }
+            if (NP == 4 && !st.done) { Rot<NP> r0; make_rot<NP>(xn, r0); sh.rot_cs[0] = r0.R[0]; sh.rot_cs[1] = r0.R[2]; }
         }
         const long long t3 = PROFILE ? clock64() : 0;
         c_comb += t2b - t2; c_decide += t2c - t2b; c_poly += t2d - t2c; c_apply += t3 - t2d;
