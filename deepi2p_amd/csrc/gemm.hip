@@ -151,7 +151,10 @@ struct EpiDev {
 // (scale/shift/bias, the gathered tables stored [B][nodes][M]) are fetched as one float4 per group g from clamped
 // addresses, before any arithmetic, so the epilogue is a handful of independent loads instead of 16 serial
 // load -> wait -> store rounds.  Needs M % 4 == 0 whenever float4 operands are used (host-checked).
-struct EpiPointwise {
+// GK0 / GK1 >= 0: the neighbour counts of the two gathered tables are compile-time constants AND M % 32 == 0 (the fused head: 3 + 3 on 128 rows);
+// -1: run-time counts (any k, any M % 4 == 0).
+template <int GK0 = -1, int GK1 = -1>
+struct EpiPointwiseT {
     EpiDev e;
     float* Y;
     int b, M, N;
@@ -168,26 +171,68 @@ struct EpiPointwise {
             for (int r = 0; r < 16; ++r) v[r] += e.batch_bias[(long long)b * M + min(mrow0 + (r & 3) + 8 * (r >> 2), M - 1)];
         }
         // gathered add (per_point_pn layer 0): v[m] += sum_j w_j * G[b][idx_j][m]
+        if (GK0 >= 0 && GK1 >= 0) {
+            // The neighbours' products are summed FIRST, row group by row group, in fresh registers (t = sum_j w_j G_j: tables in order,
+            // neighbours in order) and added to the accumulators ONCE.  With the accumulators as the running sum hipcc moved all sixteen of
+            // them between the accumulation registers and the vector registers around every neighbour (32 moves per 16 fused multiply-adds)
+            // and re-derived every 64-bit row address: ~1300 instructions per tile where ~200 do the work -- the fused head ran 12 vector
+            // instructions per matrix instruction.  Row offsets are constants here (M % 32 == 0: every row group lies inside M).
+            constexpr int NG = GK0 + GK1;
+            const float* gp[NG > 0 ? NG : 1];
+            float gw[NG > 0 ? NG : 1];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-            if (e.g_table[t]) {
-                const float* gt = e.g_table[t] + (long long)b * e.g_nodes[t] * M;
-                const int gk = e.g_k[t];
-                auto add_neighbour = [&](int j) {
-                    const int gi = e.g_idx[t][((long long)b * N + nc) * gk + j];
-                    const float gw = e.g_w[t] ? e.g_w[t][((long long)b * N + nc) * gk + j] : 1.0f;
-                    const float* gp = gt + (long long)gi * M;
+            for (int t = 0; t < 2; ++t) {
+                const int gk = t == 0 ? GK0 : GK1;
+                if (gk == 0) continue;
+                const long long col = ((long long)b * N + nc) * gk;
+                const float* gt = e.g_table[t] + (long long)b * e.g_nodes[t] * M + mrow0;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 q = *reinterpret_cast<const float4*>(gp + min(mrow0 + 8 * g, M - 4));
-                        v[4 * g + 0] += gw * q.x; v[4 * g + 1] += gw * q.y; v[4 * g + 2] += gw * q.z; v[4 * g + 3] += gw * q.w;
-                    }
-                };
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < gk) add_neighbour(j);
-                for (int j = 4; j < gk; ++j) add_neighbour(j);       // k > 4 (the reference accepts any k): same order, rolled
+                for (int j = 0; j < gk; ++j) {
+                    const int s = (t == 0 ? 0 : GK0) + j;
+                    gp[s] = gt + (long long)e.g_idx[t][col + j] * M;
+                    gw[s] = e.g_w[t] ? e.g_w[t][col + j] : 1.0f;
+                }
             }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 q[NG > 0 ? NG : 1];
+#pragma unroll
+                for (int s = 0; s < NG; ++s) q[s] = *reinterpret_cast<const float4*>(gp[s] + 8 * g);
+                float4 t4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);          // the same chain as the run-time path below: fma from zero, then one add
+#pragma unroll
+                for (int s = 0; s < NG; ++s) {
+                    t4.x = fmaf(gw[s], q[s].x, t4.x); t4.y = fmaf(gw[s], q[s].y, t4.y); t4.z = fmaf(gw[s], q[s].z, t4.z); t4.w = fmaf(gw[s], q[s].w, t4.w);
+                }
+                v[4 * g + 0] += t4.x; v[4 * g + 1] += t4.y; v[4 * g + 2] += t4.z; v[4 * g + 3] += t4.w;
+            }
+        } else if (e.g_table[0] || e.g_table[1]) {
+            float t16[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t16[r] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                if (e.g_table[t]) {
+                    const float* gt = e.g_table[t] + (long long)b * e.g_nodes[t] * M;
+                    const int gk = e.g_k[t];
+                    auto add_neighbour = [&](int j) {
+                        const int gi = e.g_idx[t][((long long)b * N + nc) * gk + j];
+                        const float gw = e.g_w[t] ? e.g_w[t][((long long)b * N + nc) * gk + j] : 1.0f;
+                        const float* gp = gt + (long long)gi * M;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 q = *reinterpret_cast<const float4*>(gp + min(mrow0 + 8 * g, M - 4));
+                            t16[4 * g + 0] = fmaf(gw, q.x, t16[4 * g + 0]); t16[4 * g + 1] = fmaf(gw, q.y, t16[4 * g + 1]);
+                            t16[4 * g + 2] = fmaf(gw, q.z, t16[4 * g + 2]); t16[4 * g + 3] = fmaf(gw, q.w, t16[4 * g + 3]);
+                        }
+                    };
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < gk) add_neighbour(j);
+                    for (int j = 4; j < gk; ++j) add_neighbour(j);       // k > 4 (the reference accepts any k): same order, rolled
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += t16[r];
+        }
         if (e.scale) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] *= e.scale[min(mrow0 + (r & 3) + 8 * (r >> 2), M - 1)];
@@ -234,6 +279,7 @@ struct EpiPointwise {
         }
     }
 };
+using EpiPointwise = EpiPointwiseT<-1, -1>;
 
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::THREADS) void pointwise_gemm_kernel(SrcDev srcs, const float* __restrict__ Wt, float* __restrict__ Y,
@@ -287,6 +333,7 @@ struct HeadTail {
 using HeadCfg = TileCfg<2, 2, 2, 1, DI2P_HEAD_BK>;       // 128 rows x 64 points, 4 waves of 64 x 32
 constexpr int HEAD_M = 128, HEAD_BN = 64;
 
+template <bool G33>       // G33: layer 0 gathers 3 + 3 neighbours (both tables present): compile-time epilogue
 __global__ __launch_bounds__(HeadCfg::THREADS) void point_head_kernel(SrcDev srcs, const float* __restrict__ W0t, int K0, EpiDev e0,
                                                                        HeadTail tl, float* __restrict__ out, int N) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -297,7 +344,7 @@ __global__ __launch_bounds__(HeadCfg::THREADS) void point_head_kernel(SrcDev src
         LoaderWt4 la{W0t, K0, HEAD_M};
         LoaderConcat4<true> lb;
         lb.s = srcs; lb.b = b; lb.N = N; lb.K = K0;
-        EpiPointwise ep{e0, nullptr, b, HEAD_M, N};
+        EpiPointwiseT<G33 ? 3 : -1, G33 ? 3 : -1> ep{e0, nullptr, b, HEAD_M, N};
         ep.lds_tile = hbuf; ep.lds_n0 = j_blk; ep.lds_ld = HEAD_BN;
         mfma_gemm_block_vec<HeadCfg>(stage, la, lb, ep, K0, 0, j_blk);
     }
@@ -554,8 +601,13 @@ extern "C" int di2p_point_head(const di2p_src_t* srcs, int n_src, const float* W
     HeadTail tl{W1t, scale1, shift1, W2t, scale2, shift2, relu1, relu2, P};
     const size_t lds = (HeadCfg::LDS_FLOATS + HEAD_M * HEAD_BN) * sizeof(float);
     // > 64 KB of dynamic LDS needs the opt-in (per device; the call is cheap, so it is simply made every time)
-    (void)hipFuncSetAttribute((const void*)point_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(point_head_kernel, dim3(di2p_cdiv(N, HEAD_BN), B), dim3(HeadCfg::THREADS), lds, (hipStream_t)stream, s, W0t, K0, e, tl, out, N);
+    if (e.g_table[0] && e.g_table[1] && e.g_k[0] == 3 && e.g_k[1] == 3) {      // the reference's configuration (k_interp_point_a = k_interp_point_b = 3)
+        (void)hipFuncSetAttribute((const void*)point_head_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(point_head_kernel<true>, dim3(di2p_cdiv(N, HEAD_BN), B), dim3(HeadCfg::THREADS), lds, (hipStream_t)stream, s, W0t, K0, e, tl, out, N);
+    } else {
+        (void)hipFuncSetAttribute((const void*)point_head_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(point_head_kernel<false>, dim3(di2p_cdiv(N, HEAD_BN), B), dim3(HeadCfg::THREADS), lds, (hipStream_t)stream, s, W0t, K0, e, tl, out, N);
+    }
     DI2P_RETURN_LAUNCH();
 }
 
