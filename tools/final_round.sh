@@ -1,21 +1,33 @@
 #!/bin/bash
-# Everything the round's profiles/ directory is built from, in one gpurun call (GPU box, repo root):  tools/final_round.sh <tag>
+# Everything the round's profiles/ directory is built from, in TWO gpurun calls (GPU box, repo root):
+#   tools/final_round.sh <tag> counters   hardware-counter passes (solver counters, FETCH / WRITE traffic, per-kernel instruction counts);
+#                                         then, in the build container:  python tools/make_profiles.py <tag> counters   (commits the json files)
+#   tools/final_round.sh <tag> bench      GPU tests, the bench lines (which read the counter files just committed), micro-benchmarks,
+#                                         kernel-trace statistics;   then:  python tools/make_profiles.py <tag>
+# The bench line is produced AFTER the counter files it quotes.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
+STAGE=${2:-bench}
 OUT=gpurun_out
 mkdir -p $OUT
-timeout 600 python -m pytest tests -q -m gpu 2>&1 | tail -3 > $OUT/${TAG}_gputest_tail.txt
+if [ "$STAGE" = "counters" ]; then
+  bash tools/profile_round.sh $TAG pmc > $OUT/${TAG}_profile_round_pmc.log 2>&1
+  bash tools/prof_solver_counters.sh $TAG > $OUT/${TAG}_solver_counters.log 2>&1
+  bash tools/prof_step_instructions.sh $TAG > $OUT/${TAG}_step_instructions.log 2>&1
+  ls $OUT | grep "^${TAG}_" | tr '\n' ' '
+  exit 0
+fi
+timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -3 > $OUT/${TAG}_gputest_tail.txt
 timeout 400 python bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench.err
 timeout 200 python bench.py --mode train --steps 6 --warmup 2 > $OUT/${TAG}_train_line.json 2>> $OUT/${TAG}_bench.err
 timeout 100 python tools/bench_index_max.py > $OUT/${TAG}_index_max_cold.txt 2>&1
 LAYERS=1 timeout 150 python tools/bench_conv.py > $OUT/${TAG}_conv_layers.txt 2>&1
 timeout 150 python tools/bench_winograd.py > $OUT/${TAG}_winograd_layers.txt 2>&1
 PROF=1 timeout 150 python tools/bench_solver.py > $OUT/${TAG}_solver_phases.txt 2>&1
-bash tools/profile_round.sh $TAG > $OUT/${TAG}_profile_round.log 2>&1
-bash tools/prof_solver_counters.sh $TAG > $OUT/${TAG}_solver_counters.log 2>&1
+bash tools/profile_round.sh $TAG stats > $OUT/${TAG}_profile_round.log 2>&1
 timeout 200 python tools/call_times.py 15 > $OUT/${TAG}_call_times.txt 2>&1
 timeout 200 bash tools/sweep_streams2.sh > $OUT/${TAG}_sweep_streams.txt 2>&1
-bash tools/prof_step_instructions.sh $TAG > $OUT/${TAG}_step_instructions.log 2>&1
+timeout 200 bash tools/probe_additivity.sh > $OUT/${TAG}_additivity.txt 2>&1
 export TMPDIR=/tmp; ROOT=$(pwd); cd /tmp; rm -rf /tmp/pt
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -- python $ROOT/bench.py --mode train --steps 4 --warmup 2 > /tmp/pt.log 2>&1
 f=$(find /tmp/pt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $ROOT/$OUT/${TAG}_train_kernel_stats.csv

@@ -1,9 +1,10 @@
 """Builds profiles/<tag>_* from the outputs of tools/final_round.sh in gpurun_out/ (run in the build container):
 copies the evidence files, derives <tag>_pmc_traffic.json from the counter passes and writes <tag>_README.md.
-    python tools/make_profiles.py r03"""
+    python tools/make_profiles.py r04 counters      after `tools/final_round.sh r04 counters` (counter files only; commit them)
+    python tools/make_profiles.py r04               after `tools/final_round.sh r04 bench`"""
 import csv, json, os, shutil, sys
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out") + "/", os.path.join(ROOT, "profiles") + "/"
 KEEP_OLD = ("%s_sweep_solver_cfg.txt" % TAG, "%s_winograd_counters.txt" % TAG)
@@ -59,12 +60,15 @@ out = {"units": r1["units"] + "; solver records and the 16-byte staged convoluti
        "index_max_C64_B32_N20480_K128": im64, "index_max_C32_B32_N20480_K128": im32,
        "solve_kernel_F32_R60_N20480": {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "fetch_bytes_corrected": fk * 2048, "hbm_bytes_corrected": fk * 2048 + wk * 1024,
                                        "compulsory_bytes": 32 * 20480 * 16 + 32 * 320 * 32, "launches": int(sol_f["launches"]),
-                                       "note": "one launch = 32 frames x 60 hypotheses; a frame's records + boxes (338 KB) are read ~64 sweeps x 60 hypotheses times but stay cache resident; the kernel has no private segment since round 3 (round 2: 48.7 MiB of spill write-back per launch)"},
+                                       "note": "one launch = 32 frames x 60 hypotheses; a frame's records + boxes (338 KB) are read ~64 sweeps x 60 hypotheses times but stay cache resident; WRITE_SIZE = the outputs + the classification cache entries that leave L2 + the write-back of the kernel's private segment (a few dozen bytes per lane of per-sweep straight-line spill code: tools/kernel_resources.py prints the exact size)"},
        "conv2d_resnet34_B32_160x512": {"FETCH_SIZE_KiB_per_encoder_pass_raw": fr, "FETCH_SIZE_KiB_per_encoder_pass_corrected": fc, "WRITE_SIZE_KiB_per_encoder_pass_raw": wr,
                                        "kernel_launches_per_pass": launches, "conv_calls_per_pass": 36, "hbm_bytes_per_call_corrected": (fc + wr) * 1024 / 36,
                                        "hbm_bytes_per_call_raw": (fr + wr) * 1024 / 36, "per_kernel": per_kernel,
                                        "note": "sum over the convolution kernels of one image-encoder pass (Winograd launches, implicit-GEMM launches + split-K reduce, the direct stem); FETCH x2 for the kernels that load 16 B per lane, stem raw (dword loads: uncalibrated)"}}
 json.dump(out, open(P + TAG + "_pmc_traffic.json", "w"), indent=1)
+if len(sys.argv) > 2 and sys.argv[2] == "counters":       # stage 1: the counter files only (commit them, THEN run the bench stage)
+    print("profiles/%s_pmc_traffic.json, %s_solver_counters.json, %s_step_instructions.txt rebuilt" % (TAG, TAG, TAG))
+    sys.exit(0)
 
 
 # ---- README
@@ -102,6 +106,8 @@ if sc:
               % (TAG, sc["SQ_INSTS_VALU"], sc["SQ_INSTS_SALU"], sc["SQ_INSTS_LDS"], sc["SQ_INSTS_VMEM_RD"], sc["SQ_INSTS_VALU_FMA_F64"], sc["SQ_INSTS_VALU_MUL_F64"],
                  sc["SQ_INSTS_VALU_ADD_F64"], flop, 100 * sc["SQ_WAIT_ANY"] / sc["SQ_WAVE_CYCLES"], 100 * sc["SQ_WAIT_INST_ANY"] / sc["SQ_WAVE_CYCLES"],
                  100 * sc["SQ_ACTIVE_INST_ANY"] / sc["SQ_WAVE_CYCLES"], sc["TCC_HIT_sum"] / (sc["TCC_HIT_sum"] + sc["TCC_MISS_sum"]), sc["FETCH_SIZE"] / 1024, sc["WRITE_SIZE"] / 1024))
+wino_counters_txt = ("* `%s_winograd_counters.txt` -- `tools/prof_winograd.sh`: SQ / TA / TCP / TCC counters of `wino_conv_kernel` on the stage-3 shape.\n" % TAG
+                     if os.path.exists(P + TAG + "_winograd_counters.txt") else "")
 txt = f"""# Round-{RN} profiles (1x MI355X, ROCm 7.2)
 
 Everything here was produced by ONE gpurun call of `tools/final_round.sh {TAG}` (GPU tests, `bench.py`, `bench.py --mode train`, the
@@ -128,15 +134,14 @@ files listed in KEEP_OLD (if present) come from earlier calls of the round.
   of once-through records + boxes (the working set is cache resident), {sp['WRITE_SIZE_KiB']/1024:.1f} MiB written (round 2: 48.7 MiB of spill write-back).  Convolution family of one
   encoder pass: FETCH {cvp['FETCH_SIZE_KiB_per_encoder_pass_raw']/1024:.0f} MiB raw / {cvp['FETCH_SIZE_KiB_per_encoder_pass_corrected']/1024:.0f} MiB corrected, WRITE {cvp['WRITE_SIZE_KiB_per_encoder_pass_raw']/1024:.0f} MiB = {cvp['hbm_bytes_per_call_corrected']/1e6:.0f} MB per convolution call against
   52 MB compulsory (the Winograd workgroups re-stream their slice of the transformed filters: under 1 TB/s over the family's time
-  -- not a limiter).  index_max (fresh passes on cold inputs): C = 64 {pm['index_max_C64_B32_N20480_K128']['hbm_bytes_corrected']/1e6:.0f} MB against {pm['index_max_C64_B32_N20480_K128']['algorithmic_bytes']/1e6:.0f} MB algorithmic, C = 32 {pm['index_max_C32_B32_N20480_K128']['hbm_bytes_corrected']/1e6:.0f} / {pm['index_max_C32_B32_N20480_K128']['algorithmic_bytes']/1e6:.0f} MB.  (`{TAG}_bench_line.json` was written before
-  this file was rebuilt: its `traffic` fields show the previous counter file's values.)
+  -- not a limiter).  index_max (fresh passes on cold inputs): C = 64 {pm['index_max_C64_B32_N20480_K128']['hbm_bytes_corrected']/1e6:.0f} MB against {pm['index_max_C64_B32_N20480_K128']['algorithmic_bytes']/1e6:.0f} MB algorithmic, C = 32 {pm['index_max_C32_B32_N20480_K128']['hbm_bytes_corrected']/1e6:.0f} / {pm['index_max_C32_B32_N20480_K128']['algorithmic_bytes']/1e6:.0f} MB.  (`{TAG}_bench_line.json` was produced AFTER
+  these counter files were committed: its `traffic` / `frac_executed` fields are computed from them -- `counters_file` in the line names the file.)
 * `{TAG}_conv_layers.txt`, `{TAG}_winograd_layers.txt` -- per-layer timings: the remaining implicit-GEMM layers (stride-2 3x3, 1x1
   downsample) and, for the four 3x3 stride-1 shapes at B = 32, direct vs the Winograd variants:
 ```
 {chr(10).join(wl[-7:])}
 ```
-* `{TAG}_winograd_counters.txt` -- `tools/prof_winograd.sh`: SQ / TA / TCP / TCC counters of `wino_conv_kernel` on the stage-3 shape.
-* `{TAG}_solver_phases.txt` -- `PROF=1 python tools/bench_solver.py`: clock64() phase counters, cluster / line-search statistics, sweep-count
+{wino_counters_txt}* `{TAG}_solver_phases.txt` -- `PROF=1 python tools/bench_solver.py`: clock64() phase counters, cluster / line-search statistics, sweep-count
   percentiles.
 {sc_txt}* `{TAG}_call_times.txt` -- `tools/call_times.py`: HIP events around every C-ABI call of one serial step, with the contraction shapes.
 * `{TAG}_sweep_streams.txt` -- the headline against streams / hardware queues.

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Hardware counters of the pose-solver kernel (GPU box; separate --pmc passes, kernel-trace only):  tools/prof_solver_counters.sh r03
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
@@ -22,16 +22,18 @@ agg = collections.defaultdict(lambda: [0, 0.0])
 dur = []
 for f in sorted(glob.glob("/tmp/sc_pass*.csv")):
     rows = list(csv.DictReader(open(f)))
-    # bench_solver: launches 1-6 run with solver_nocull = 1, launches 7-12 with the cluster test (then one more per PROF/tier option)
+    # bench_solver (without PROF / TIERS): 2 launches with solver_nocull = 1, 6 with solver_nocache = 1, then 6 as shipped -- the LAST six count
     solves = [r for r in rows if "solve_kernel" in r.get("Kernel_Name", "")]
     ids = sorted({int(r["Dispatch_Id"]) for r in solves})
-    keep = set(ids[6:12])
+    keep = set(ids[-6:])
+    kernel_names = sorted({r.get("Kernel_Name", "")[:90] for r in solves if int(r["Dispatch_Id"]) in keep})
     for r in solves:
         if int(r["Dispatch_Id"]) in keep:
             a = agg[r["Counter_Name"]]
             a[0] += 1; a[1] += float(r["Counter_Value"])
 out = {k: v[1] / v[0] for k, v in agg.items()}
-out["_note"] = "per launch of solve_kernel<4,float,3,4,false> with the cluster test (bench_solver.py: 32 frames x 60 hypotheses x 20480 points), mean of 6 launches; SQ_* cycle counters are quad-cycles summed over the device; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them (FETCH_SIZE x2 on gfx950 for wide streaming reads, MI355X_MICROARCH.md)"
+out["_kernel"] = kernel_names
+out["_note"] = "per launch of the SHIPPED instantiation of solve_kernel (named in _kernel: <NP, point type, min waves per SIMD, waves per hypothesis, instrumented>) as bench.py runs it (bench_solver.py: 32 frames x 60 hypotheses x 20480 points), mean of the last 6 launches of every pass; SQ_* cycle counters are quad-cycles summed over the device; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them (FETCH_SIZE x2 on gfx950 for wide streaming reads, MI355X_MICROARCH.md)"
 json.dump(out, open(sys.argv[1], "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))
 PY

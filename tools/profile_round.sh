@@ -4,7 +4,8 @@
 # Writes gpurun_out/<tag>_*.csv (kernel-trace statistics of the bench command, default streams ("pipelined") and serial; separate --pmc passes
 # for the solver and index_max -- counters are never combined with other trace domains).  Copy what should be judged into profiles/.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
+WHAT=${2:-all}          # stats | pmc | all
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT/prof_$TAG
@@ -18,8 +19,11 @@ stats() {  # name, args...
   [ -n "$f" ] && cp $f $OUT/${TAG}_bench_kernel_stats_$name.csv
   grep '^{' $OUT/prof_$TAG/$name.log | tail -1 > $OUT/${TAG}_bench_line_$name.json
 }
+if [ "$WHAT" != "pmc" ]; then
 stats pipelined --no-h2d-pass
 stats serial --streams 1 --no-h2d-pass
+fi
+[ "$WHAT" = "stats" ] && { ls -la $OUT | grep ${TAG}_; exit 0; }
 pmc() {  # counter, tool, name [, env assignment]
   local c=$1 tool=$2 name=$3
   rm -rf $OUT/prof_$TAG/pmc_${name}_$c
