@@ -46,6 +46,9 @@ _SIGS = {
     "di2p_argmax_channels": [c_void_p, c_void_p, c_int, c_int, c_int, c_ll, c_void_p],
     "di2p_pointwise_gemm": [ctypes.POINTER(SrcT), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                             ctypes.POINTER(EpilogueT), c_void_p],
+    "di2p_pointwise_gemm_x3": [ctypes.POINTER(SrcT), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                               ctypes.POINTER(EpilogueT), c_void_p],
+    "di2p_bf16x3_pack": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "di2p_batch_gemv": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "di2p_batch_gemv2": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "di2p_attention_pool": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
@@ -100,6 +103,7 @@ _WS_SIGS = {        # <name>_workspace_bytes helpers returning long long
     "di2p_bmm_rc_workspace_bytes": [c_int] * 4,
     "di2p_gather_backward_workspace_bytes": [c_int] * 4,
     "di2p_conv2d_wgrad_workspace_bytes": [c_int] * 9,
+    "di2p_bf16x3_packed_bytes": [c_int] * 2,
 }
 EXPORTS = sorted(list(_SIGS) + ["di2p_last_error", "di2p_version", "di2p_solve_workspace_bytes", "di2p_solver_set_profile_buffer", "di2p_pnp_workspace_bytes",
                  "di2p_conv2d_workspace_bytes", "di2p_set_option", "di2p_get_option", "di2p_random_choice_workspace_bytes", "di2p_classifier_loss_workspace_bytes"] + list(_WS_SIGS))

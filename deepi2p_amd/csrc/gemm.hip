@@ -473,6 +473,155 @@ void launch_pw_vec(bool dense, const SrcDev& s, const float* Wt, float* Y, int B
         hipLaunchKernelGGL((pointwise_gemm_vec_kernel<Cfg, false>), grid, dim3(Cfg::THREADS), Cfg::LDS_FLOATS * sizeof(float), st, s, Wt, Y, M, K, N, e);
 }
 
+
+// ----------------------------------------------------------------------------------------------------------------------------------
+// "bf16x3": fp32 contractions through bf16 matrix instructions with an EXACT three-way operand split.
+//   x = x1 + x2 + x3 (three truncated bf16 terms of 8 significand bits each: 24 bits, nothing is lost), and
+//   a * b = a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1) + terms below 2^-24 |a| |b|        -- six bf16 products, fp32 accumulation,
+// smallest terms first.  v_mfma_f32_32x32x16_bf16 does K = 16 in 32 cycles where v_mfma_f32_32x32x2_f32 needs 8 x 64: six of them are
+// 2.67x the fp32-MFMA rate.  Against an fp64 contraction the result is as accurate as the fp32-MFMA kernel's (the dropped terms are below the
+// rounding of the fp32 accumulation; tests/test_gpu_contractions.py asserts err_bf16x3 <= err_fp32mfma on the golden operands).
+// Used for the GEMM-shaped layers (K >= 128, M % 128 == 0: the kNN-fusion layers and the node-level PointNets); narrow point layers are
+// memory-bound and stay on the fp32 kernels.  Non-finite inputs: x = +-inf splits into (inf, NaN, NaN), i.e. the output is NaN where the
+// fp32 kernel gives +-inf or NaN -- non-finite either way.
+//   weights: split ONCE (di2p_bf16x3_pack) into [Kp/8][Mp][3] x 8 bf16 (Kp = K rounded up to 32, Mp = M rounded up to 128, zero filled) and read
+//            straight from L2 as MFMA A fragments;
+//   activations: fp32 in memory, loaded through the SAME loaders as the fp32 kernels and split while they are staged into LDS
+//            (5.5 vector instructions per value); LDS layout [plane][k-group of 8][k-half][column] x 8 bytes: a thread stores 32 contiguous
+//            bytes per plane (its 4 columns x 4 consecutive k), a fragment read is two conflict-free 8-byte reads.
+// Workgroup 128 x 128, 4 waves of 64 x 64 (2 x 2 MFMA tiles), K-step 32, 48 KB of LDS, two workgroups per CU.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float x3_hi16(float x) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffff0000u); }
+// the bf16 (high halves) of two floats in one word: low half <- x0, high half <- x1
+__device__ __forceinline__ unsigned x3_pack_hi(float x0, float x1) {
+    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, x1), __builtin_bit_cast(unsigned, x0), 0x07060302u);
+}
+// four consecutive k of one column -> three planes of 4 x bf16
+__device__ __forceinline__ void x3_split4(float f0, float f1, float f2, float f3, u32x2_t& p1, u32x2_t& p2, u32x2_t& p3) {
+    const float r0 = f0 - x3_hi16(f0), r1 = f1 - x3_hi16(f1), r2 = f2 - x3_hi16(f2), r3 = f3 - x3_hi16(f3);
+    const float q0 = r0 - x3_hi16(r0), q1 = r1 - x3_hi16(r1), q2 = r2 - x3_hi16(r2), q3 = r3 - x3_hi16(r3);
+    p1 = u32x2_t{x3_pack_hi(f0, f1), x3_pack_hi(f2, f3)};
+    p2 = u32x2_t{x3_pack_hi(r0, r1), x3_pack_hi(r2, r3)};
+    p3 = u32x2_t{x3_pack_hi(q0, q1), x3_pack_hi(q2, q3)};
+}
+
+constexpr int X3_BM = 128, X3_BN = 128, X3_BK = 32, X3_KG = X3_BK / 8;
+
+template <bool DENSE>
+__global__ __launch_bounds__(256, 2) void pointwise_gemm_x3_kernel(SrcDev srcs, const u32x4_t* __restrict__ Wp, float* __restrict__ Y, int M, int K,
+                                                                    int N, int Mp, EpiDev epi) {
+    __shared__ __attribute__((aligned(16))) u32x2_t Bs[2][3][X3_KG][2][X3_BN];        // 2 x 24 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m_blk = blockIdx.y * X3_BM, n_blk = blockIdx.x * X3_BN, b = blockIdx.z;
+    const int T = (K + X3_BK - 1) / X3_BK;
+    LoaderConcat4<DENSE> lb;
+    lb.s = srcs; lb.b = b; lb.N = N; lb.K = K;
+    // staging role: 4 columns (tid & 31), 4 consecutive k: k-group (tid >> 6), half (tid >> 5) & 1
+    const int cq = tid & 31, skg = tid >> 6, shh = (tid >> 5) & 1;
+    lb.column4(n_blk + 4 * cq);
+    float4 st[4];
+    auto gload = [&](int t) {
+        const int k0 = t * X3_BK;
+        lb.begin_tile(k0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[r] = lb.load4(k0 + skg * 8 + shh * 4 + r);      // rows k >= K re-read row K-1 and meet zero weights
+    };
+    auto sstore = [&](int buf) {
+        u32x2_t p1[4], p2[4], p3[4];
+        x3_split4(st[0].x, st[1].x, st[2].x, st[3].x, p1[0], p2[0], p3[0]);
+        x3_split4(st[0].y, st[1].y, st[2].y, st[3].y, p1[1], p2[1], p3[1]);
+        x3_split4(st[0].z, st[1].z, st[2].z, st[3].z, p1[2], p2[2], p3[2]);
+        x3_split4(st[0].w, st[1].w, st[2].w, st[3].w, p1[3], p2[3], p3[3]);
+        u32x4_t* d1 = reinterpret_cast<u32x4_t*>(&Bs[buf][0][skg][shh][4 * cq]);
+        u32x4_t* d2 = reinterpret_cast<u32x4_t*>(&Bs[buf][1][skg][shh][4 * cq]);
+        u32x4_t* d3 = reinterpret_cast<u32x4_t*>(&Bs[buf][2][skg][shh][4 * cq]);
+        d1[0] = u32x4_t{p1[0].x, p1[0].y, p1[1].x, p1[1].y}; d1[1] = u32x4_t{p1[2].x, p1[2].y, p1[3].x, p1[3].y};
+        d2[0] = u32x4_t{p2[0].x, p2[0].y, p2[1].x, p2[1].y}; d2[1] = u32x4_t{p2[2].x, p2[2].y, p2[3].x, p2[3].y};
+        d3[0] = u32x4_t{p3[0].x, p3[0].y, p3[1].x, p3[1].y}; d3[1] = u32x4_t{p3[2].x, p3[2].y, p3[3].x, p3[3].y};
+    };
+    // A fragments straight from memory: [Kp/8][Mp][3] x 16 bytes; lane = row (l31), k-group (half)
+    u32x4_t af[2][2][3];                                     // [stage][tile i][plane]
+    auto aload = [&](int kg_global, int stg) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const u32x4_t* p = Wp + ((long long)(kg_global + half) * Mp + m_blk + wm * 64 + i * 32 + l31) * 3;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) af[stg][i][q] = p[q];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    // one k16 sub-step: B fragments from LDS, the A fragments of the NEXT sub-step requested first
+    auto substep = [&](int buf, int sub, int next_kg, bool has_next) __attribute__((always_inline)) {
+        if (has_next) aload(next_kg, sub ^ 1);
+        u32x4_t bf[2][3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int n = wn * 64 + j * 32 + l31;
+                const u32x2_t lo = Bs[buf][q][2 * sub + half][0][n], hi = Bs[buf][q][2 * sub + half][1][n];
+                bf[j][q] = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+            }
+        DI2P_MFMA_BEGIN();
+        // smallest terms first; four independent accumulators between two matrix instructions of one chain
+#define DI2P_X3_PROD(QA, QB)                                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                                      \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[sub][i][QA]), __builtin_bit_cast(bf16x8_t, bf[j][QB]), acc[i][j], 0, 0, 0);
+        DI2P_X3_PROD(2, 0) DI2P_X3_PROD(1, 1) DI2P_X3_PROD(0, 2)
+        DI2P_X3_PROD(1, 0) DI2P_X3_PROD(0, 1)
+        DI2P_X3_PROD(0, 0)
+#undef DI2P_X3_PROD
+        DI2P_MFMA_END();
+    };
+    gload(0);
+    sstore(0);
+    aload(0, 0);
+    __syncthreads();
+    // steady state without branches (a branch arm without loads turns every wait of the other arm into vmcnt(0))
+    for (int t = 0; t + 1 < T; ++t) {
+        const int buf = t & 1;
+        gload(t + 1);
+        substep(buf, 0, t * X3_KG + 2, true);
+        substep(buf, 1, t * X3_KG + 4, true);
+        sstore(buf ^ 1);
+        __syncthreads();
+    }
+    substep((T - 1) & 1, 0, (T - 1) * X3_KG + 2, true);
+    substep((T - 1) & 1, 1, 0, false);
+    EpiPointwise ep{epi, Y, b, M, N};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ep.tile(m_blk + wm * 64 + i * 32 + 4 * half, n_blk + wn * 64 + j * 32 + l31, acc[i][j]);
+}
+
+// Wt f32 [K][M] (k-major, what the fp32 kernels read) -> [Kp/8][Mp][3][8] bf16, zero filled outside K x M.  One thread per (k-group, m).
+__global__ __launch_bounds__(256) void bf16x3_pack_kernel(const float* __restrict__ Wt, unsigned short* __restrict__ Wp, int K, int M, int Kp, int Mp) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)(Kp / 8) * Mp) return;
+    const int kg = (int)(t / Mp), m = (int)(t - (long long)kg * Mp);
+    unsigned short* d = Wp + t * 24;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = kg * 8 + i;
+        const float a = (k < K && m < M) ? Wt[(long long)k * M + m] : 0.0f;
+        const float a1 = x3_hi16(a), r1 = a - a1, a2 = x3_hi16(r1), r2 = r1 - a2;
+        d[0 * 8 + i] = (unsigned short)(__builtin_bit_cast(unsigned, a1) >> 16);
+        d[1 * 8 + i] = (unsigned short)(__builtin_bit_cast(unsigned, a2) >> 16);
+        d[2 * 8 + i] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+    }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Sources i >= n_src become aliases of source 0 with an empty channel range [K, K): addressable, never selected.
@@ -561,6 +710,75 @@ extern "C" int di2p_pointwise_gemm(const di2p_src_t* srcs, int n_src, const floa
     if (M <= 32) launch_pw<Cfg32x128>(s, Wt, Y, B, M, K, N, e, st);
     else if (M <= 64 || (long long)B * di2p_cdiv(N, 128) * di2p_cdiv(M, 128) < 256) launch_pw<Cfg64x128>(s, Wt, Y, B, M, K, N, e, st);
     else launch_pw<Cfg128x128>(s, Wt, Y, B, M, K, N, e, st);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" long long di2p_bf16x3_packed_bytes(int K, int M) {
+    if (K < 1 || M < 1) return 0;
+    return (long long)(di2p_cdiv(K, X3_BK) * X3_BK / 8) * (di2p_cdiv(M, X3_BM) * X3_BM) * 48;
+}
+
+extern "C" int di2p_bf16x3_pack(const float* Wt, int K, int M, void* Wp, void* stream) {
+    DI2P_CHECK_ARG(Wt && Wp && K >= 1 && M >= 1, "bad args");
+    DI2P_CHECK_ARG(aligned16(Wp), "packed weights must be 16-byte aligned");
+    const int Kp = di2p_cdiv(K, X3_BK) * X3_BK, Mp = di2p_cdiv(M, X3_BM) * X3_BM;
+    hipLaunchKernelGGL(bf16x3_pack_kernel, dim3(di2p_cdiv((long long)(Kp / 8) * Mp, 256)), dim3(256), 0, (hipStream_t)stream, Wt,
+                       (unsigned short*)Wp, K, M, Kp, Mp);
+    DI2P_RETURN_LAUNCH();
+}
+
+// Same contract as di2p_pointwise_gemm with the weights given as di2p_bf16x3_pack's output (of the SAME [K][M] matrix).  Needs N % 4 == 0;
+// every epilogue of the fp32 entry point is available.
+extern "C" int di2p_pointwise_gemm_x3(const di2p_src_t* srcs, int n_src, const void* Wp, float* Y, int B, int M, int K, int N,
+                                      const di2p_epilogue_t* epi, void* stream) {
+    DI2P_CHECK_ARG(srcs && n_src >= 1 && n_src <= DI2P_MAX_SRC, "1..3 sources");
+    DI2P_CHECK_ARG(Wp && Y && aligned16(Wp), "null / misaligned pointer");
+    DI2P_CHECK_ARG(B >= 0 && M >= 4 && M % 4 == 0 && K >= 1 && N >= 4 && N % 4 == 0, "needs M % 4 == 0 and N % 4 == 0");
+    if (B == 0) return 0;
+    SrcDev s{};
+    int ctot = 0;
+    for (int i = 0; i < DI2P_MAX_SRC; ++i) {
+        if (i < n_src) {
+            DI2P_CHECK_ARG(srcs[i].ptr && srcs[i].channels > 0, "bad source");
+            DI2P_CHECK_ARG(srcs[i].mode != DI2P_SRC_GATHER || srcs[i].gidx, "gather source without index");
+            DI2P_CHECK_ARG(srcs[i].mode != DI2P_SRC_GROUP || srcs[i].group >= 1, "group source without group");
+            DI2P_CHECK_ARG((long long)srcs[i].channels * srcs[i].row_stride < (1ll << 31), "per-frame source extent must fit 31 bits");
+            s.ptr[i] = srcs[i].ptr; s.gidx[i] = srcs[i].gidx; s.batch_stride[i] = srcs[i].batch_stride;
+            s.row_stride[i] = srcs[i].row_stride; s.mode[i] = srcs[i].mode; s.group[i] = srcs[i].group > 0 ? srcs[i].group : 1;
+            ctot += srcs[i].channels;
+        }
+        s.c_end[i] = ctot;
+    }
+    s.n_src = n_src;
+    alias_absent_sources(s, n_src);
+    DI2P_CHECK_ARG(ctot == K, "source channels do not sum to K");
+    EpiDev e{};
+    e.group_max = 1;
+    if (epi) {
+        e.scale = epi->scale; e.shift = epi->shift; e.batch_bias = epi->batch_bias; e.relu = epi->relu;
+        e.group_max = epi->group_max > 1 ? epi->group_max : 1;
+        for (int t = 0; t < 2; ++t) { e.g_table[t] = epi->g_table[t]; e.g_idx[t] = epi->g_idx[t]; e.g_w[t] = epi->g_w[t]; e.g_nodes[t] = epi->g_nodes[t]; }
+        e.transpose_out = epi->transpose_out;
+        e.gmax_out = epi->group_max > 1 ? epi->group_max_out : nullptr;
+        e.gmax_dst = e.gmax_out ? e.gmax_out : Y;
+        for (int t = 0; t < 2; ++t) {
+            e.g_k[t] = e.g_table[t] ? epi->g_k[t] : 0;
+            DI2P_CHECK_ARG(e.g_k[t] >= 0 && e.g_k[t] <= DI2P_MAX_GK, "g_k must be in [0, DI2P_MAX_GK]");
+            DI2P_CHECK_ARG(!e.g_table[t] || (e.g_idx[t] && e.g_k[t] >= 1 && e.g_nodes[t] >= 1), "gathered table without index / k / nodes");
+        }
+        DI2P_CHECK_ARG(!e.transpose_out || e.group_max == 1, "transpose_out excludes group_max");
+    }
+    if (e.group_max > 1) {
+        const int g = e.group_max;
+        DI2P_CHECK_ARG((g & (g - 1)) == 0 && g <= 32 && N % g == 0, "group_max must be a power of two <= 32 dividing N");
+    }
+    bool dense = true;
+    for (int i = 0; i < n_src; ++i)
+        dense = dense && srcs[i].mode == DI2P_SRC_DENSE && srcs[i].row_stride % 4 == 0 && srcs[i].batch_stride % 4 == 0 && aligned16(srcs[i].ptr);
+    const int Mp = di2p_cdiv(M, X3_BM) * X3_BM;
+    const dim3 grid(di2p_cdiv(N, X3_BN), di2p_cdiv(M, X3_BM), B);
+    if (dense) hipLaunchKernelGGL(pointwise_gemm_x3_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, s, (const u32x4_t*)Wp, Y, M, K, N, Mp, e);
+    else hipLaunchKernelGGL(pointwise_gemm_x3_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, s, (const u32x4_t*)Wp, Y, M, K, N, Mp, e);
     DI2P_RETURN_LAUNCH();
 }
 

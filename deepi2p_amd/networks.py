@@ -104,6 +104,7 @@ class _PackedModule(nn.Module):
             if isinstance(m, _PackedModule):
                 m._packed = None
                 m._weights_version += 1
+        ops.x3_invalidate()          # the split (bf16x3) copies are keyed by the addresses of the operands just dropped
 
     @property
     def weights_version(self):
@@ -179,10 +180,10 @@ def _run_split_layer(dense_srcs, dense_rows, node_feats, node_rows, idx, layer, 
                               gathered=[(G, idx.reshape(B, N, 1), None)], **kw)
 
 
-def _run_pn(x, layers):
+def _run_pn(x, layers, **kw):
     N = x.shape[2]
     for layer in layers:
-        x = _run_layer([Src(x)], layer, N)
+        x = _run_layer([Src(x)], layer, N, **kw)
     return x
 
 
@@ -421,7 +422,8 @@ class KeypointDetector(_PackedModule):
             scores = ops.point_head([Src(first), Src(second)], (Wt[640:736], sc, sh, act), l1, l2, N, gathered=gathered)
         else:
             h = ops.pointwise_gemm([Src(first), Src(second)], Wt[640:736], M0, N, scale=sc, shift=sh, relu=act, gathered=gathered)
-            scores = _run_pn(h, p["per_point_pn"][1:])
+            # the coarse chain is the bit-exact reference of the fused kernel (fp32 matrix instructions): not on the bf16x3 kernel
+            scores = _run_pn(h, p["per_point_pn"][1:], x3=False if M0 == 128 else None)
         coarse = scores[:, 0:2, :]
         if self.opt.is_fine_resolution:
             return coarse, scores[:, 2:, :]

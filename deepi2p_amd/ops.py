@@ -172,13 +172,59 @@ def _fill_gathered(e, gathered, B, M, N):
         e.g_k[t] = k
 
 
+# bf16x3 operand cache: packed (split) weights of the GEMM-shaped layers, keyed by the fp32 operand they were made from.  The fp32 operands
+# are themselves derived tensors that networks._PackedModule frees and re-derives when the weights change -- it calls x3_invalidate() then,
+# so a recycled address can never return a stale split.  Filled by the first eager call of a layer (the executor runs one eager step before
+# it captures a graph); a call under stream capture with a cold cache packs on the capturing stream, which is valid too (the pack kernel
+# becomes a graph node), only slower.
+_X3_CACHE = {}
+X3_MIN_K = 128
+
+
+def x3_invalidate():
+    _X3_CACHE.clear()
+
+
+def bf16x3_pack(Wt):
+    """Wt f32[K,M] (contiguous) -> the split operand of di2p_pointwise_gemm_x3 (uint8 storage)."""
+    require_cuda(Wt)
+    K, M = Wt.shape
+    Wp = torch.empty((_lib.load().di2p_bf16x3_packed_bytes(K, M),), dtype=torch.uint8, device=Wt.device)
+    call("di2p_bf16x3_pack", ptr(Wt), K, M, ptr(Wp), stream())
+    return Wp
+
+
+def _x3_operand(Wt, B, M, N, x3):
+    """The packed operand if this layer runs on the bf16x3 kernel, else None.  x3: None = by shape and the library knob `pw_x3`; True / False force.
+    Automatic rule: K >= 128, M % 128 == 0 and at least eight 128 x 128 workgroups PER FRAME -- a rule on the layer's shape only: a frame's
+    result must not depend on the batch it is in (measured per layer of a 32-frame step,
+    tools/call_times.py: 256x256x2048 135 -> 124 us, 512x256x2048 198 -> 139, 256x512x2048 211 -> 166, 1024x768x128 70 -> 55; the node-level
+    layers with 128 workgroups or fewer are FASTER on the fp32 kernel's 64 x 64 tiles: 512x1024x128 48 vs 63 us, 128x512x128 19 vs 35)."""
+    K = Wt.shape[0]
+    if x3 is None:
+        x3 = (K >= X3_MIN_K and M % 128 == 0 and N % 4 == 0 and ((N + 127) // 128) * (M // 128) >= 8 and not Wt.requires_grad
+              and _lib.get_option("pw_x3") != 0)
+    if not x3:
+        return None
+    if M % 4 or N % 4 or not Wt.is_contiguous():
+        raise RuntimeError("bf16x3 needs M % 4 == 0, N % 4 == 0 and a contiguous [K,M] weight")
+    key = (Wt.data_ptr(), K, M, Wt.device.index)
+    Wp = _X3_CACHE.get(key)
+    if Wp is None:
+        Wp = _X3_CACHE[key] = bf16x3_pack(Wt)
+    return Wp
+
+
 def pointwise_gemm(srcs, Wt, M, N, scale=None, shift=None, batch_bias=None, relu=False, group_max=1, gathered=None,
-                   transpose_out=False, also_full=False):
+                   transpose_out=False, also_full=False, x3=None):
     """Y[b] = epi(Wt^T @ concat(srcs)[b]).  srcs: list of Src; Wt f32[K,M].  gathered: optional list of up
     to two (table f32[B,nodes,M] node-major, idx i32[B,N,k], w f32[B,N,k]).  transpose_out: Y is f32[B,N,M].
-    group_max > 1 returns the group maxima; with also_full=True it returns (full Y, maxima) from the same launch."""
+    group_max > 1 returns the group maxima; with also_full=True it returns (full Y, maxima) from the same launch.
+    x3: run the contraction on the bf16x3 kernel (exact three-way bf16 split of both operands, fp32 accumulation; None = for the GEMM-shaped
+    layers, K >= 128 and M % 128 == 0, unless the knob `pw_x3` is 0)."""
     B = srcs[0].t.shape[0]
     K = Wt.shape[0]
+    Wp = _x3_operand(Wt, B, M, N, x3)
     arr = _fill_srcs(srcs)
     e = EpilogueT()
     e.scale, e.shift, e.batch_bias = ptr(scale), ptr(shift), ptr(batch_bias)
@@ -193,6 +239,11 @@ def pointwise_gemm(srcs, Wt, M, N, scale=None, shift=None, batch_bias=None, relu
         e.group_max_out = ptr(Ymax)
     else:
         Y = torch.empty((B, Nout, M) if transpose_out else (B, M, Nout), dtype=_f32, device=Wt.device)
+    if Wp is not None:
+        if _lib.WORK is not None:
+            _lib.WORK["di2p_pointwise_gemm_x3"] = _lib.WORK.get("di2p_pointwise_gemm_x3", 0) + B * M * K * N
+        call("di2p_pointwise_gemm_x3", arr, len(srcs), ptr(Wp), ptr(Y), B, M, K, N, ctypes.byref(e), stream())
+        return (Y, Ymax) if Ymax is not None else Y
     if _lib.WORK is not None:
         _lib.WORK["di2p_pointwise_gemm"] = _lib.WORK.get("di2p_pointwise_gemm", 0) + B * M * K * N
     call("di2p_pointwise_gemm", arr, len(srcs), ptr(Wt), ptr(Y), B, M, K, N, ctypes.byref(e), stream())

@@ -61,7 +61,7 @@ class _Linear(Function):
         B, K, N = x.shape
         M = W.shape[0]
         W2 = W.reshape(M, K)
-        y = ops.pointwise_gemm([Src(x)], W2.t().contiguous(), M, N, shift=bias)
+        y = ops.pointwise_gemm([Src(x)], W2.t().contiguous(), M, N, shift=bias, x3=False)
         ctx.save_for_backward(x, W2)
         ctx.has_bias = bias is not None
         ctx.wshape = W.shape
@@ -77,7 +77,7 @@ class _Linear(Function):
         lib = _lib.load()
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.pointwise_gemm([Src(dy)], _c(W2), K, N)          # W[m][k] is the k-major operand of the reduction over m
+            dx = ops.pointwise_gemm([Src(dy)], _c(W2), K, N, x3=False)          # W[m][k] is the k-major operand of the reduction over m
         if ctx.needs_input_grad[1]:
             dW = ctx.sinks[0] if ctx.sinks[0] is not None else torch.empty((M, K), dtype=_f32, device=x.device)
             nb = lib.di2p_bmm_rc_workspace_bytes(B, M, K, N)

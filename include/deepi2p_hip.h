@@ -134,6 +134,15 @@ typedef struct {
 
 int di2p_pointwise_gemm(const di2p_src_t* srcs_host, int n_src, const float* Wt, float* Y,
                         int B, int M, int K, int N, const di2p_epilogue_t* epi_host, void* stream);
+/* The same contraction on the bf16 matrix instructions with an EXACT three-way split of both fp32 operands (x = x1 + x2 + x3, three truncated
+ * bf16 terms; six bf16 products per fp32 product, fp32 accumulation): as accurate against an fp64 contraction as the fp32-MFMA kernel, 2.67x
+ * its matrix-pipe rate.  For the GEMM-shaped layers (Conv1d / Conv2d(1x1) of models/layers_pc.py:259-408,779-818 with K >= 128 input
+ * channels); the weights are split once:  Wp = di2p_bf16x3_pack(Wt [K][M])  (di2p_bf16x3_packed_bytes(K, M) bytes, 16-byte aligned).
+ * Same sources, epilogues and output layouts as di2p_pointwise_gemm; needs M % 4 == 0 and N % 4 == 0. */
+long long di2p_bf16x3_packed_bytes(int K, int M);
+int di2p_bf16x3_pack(const float* Wt, int K, int M, void* Wp, void* stream);
+int di2p_pointwise_gemm_x3(const di2p_src_t* srcs_host, int n_src, const void* Wp, float* Y,
+                           int B, int M, int K, int N, const di2p_epilogue_t* epi_host, void* stream);
 
 /* Y[b,m] = sum_k Wt[k0+k, m] * v[b,k]  (the broadcast part of a concatenated input, folded into
  * batch_bias: networks_united.py:139-155,170-187 expand()s).  v f32[B,Kv]. */

@@ -219,3 +219,51 @@ def test_pools(dev):
     assert torch.equal(ops.maxpool3x3s2(x2.to(dev)).cpu(), F.max_pool2d(x2, 3, 2, 1))
     y = torch.randn(3, 512, 5, 16)
     torch.testing.assert_close(ops.global_avgpool(y.to(dev)).cpu(), F.adaptive_avg_pool2d(y, 1), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,chans,M,N,mode", [(2, (256,), 256, 2048, "dense"), (2, (256,), 512, 2048, "gather"), (2, (512,), 256, 2048, "gmax"),
+                                              (3, (256, 512), 1024, 128, "bias"), (2, (64, 512, 256), 512, 128, "dense"), (1, (1024,), 512, 128, "transpose"),
+                                              (2, (130,), 128, 132, "dense"), (1, (128,), 384, 20, "dense")])
+def test_pointwise_gemm_bf16x3_as_accurate_as_fp32_mfma(dev, B, chans, M, N, mode):
+    """The GEMM-shaped layers run on bf16 matrix instructions with both fp32 operands split EXACTLY into three bf16 terms (six bf16
+    products per fp32 product, fp32 accumulation).  Against an fp64 contraction of the same fp32 operands the result must be as accurate as
+    the fp32-MFMA kernel's -- err_bf16x3 <= err_fp32mfma up to the run-to-run spread of two different summation orders (max error within
+    1.25x, rms error within 1.1x) -- and inside the tolerance of every other contraction test.  Shapes: the kNN-fusion layers, the node-level
+    PointNets with concatenated sources, ragged K / N, every epilogue the fp32 entry point has."""
+    from deepi2p_amd import ops
+    g = torch.Generator().manual_seed(5 + M + N)
+    xs = [torch.randn(B, c, N, generator=g) * (1.0 + 3.0 * torch.rand(1, c, 1, generator=g)) for c in chans]
+    K = sum(chans)
+    W = torch.randn(M, K, generator=g) / K ** 0.5
+    scale, shift = torch.rand(M, generator=g) + 0.5, torch.randn(M, generator=g)
+    Wt = W.t().contiguous().to(dev)
+    kw = dict(scale=scale.to(dev), shift=shift.to(dev), relu=False)
+    srcs = [ops.Src(x.to(dev)) for x in xs]
+    x64 = torch.cat(xs, 1).double()
+    if mode == "gather":
+        idx = torch.randint(0, N, (B, N), generator=g, dtype=torch.int32)
+        srcs = [ops.Src(xs[0].to(dev), mode=_lib.SRC_GATHER, gidx=idx.to(dev))]
+        x64 = torch.gather(xs[0].double(), 2, idx.long().unsqueeze(1).expand(B, K, N))
+    ref = torch.einsum("mk,bkn->bmn", W.double(), x64)
+    if mode == "bias":
+        bias = torch.randn(B, M, generator=g)
+        kw["batch_bias"] = bias.to(dev)
+        ref = ref + bias.double().unsqueeze(2)
+    ref = ref * scale.double().view(1, M, 1) + shift.double().view(1, M, 1)
+    if mode == "gmax":
+        kw["group_max"] = 16
+        ref = ref.view(B, M, N // 16, 16).max(dim=3)[0]
+    if mode == "transpose":
+        kw["transpose_out"] = True
+        ref = ref.transpose(1, 2)
+    y3 = ops.pointwise_gemm(srcs, Wt, M, N, x3=True, **kw).double().cpu()
+    y1 = ops.pointwise_gemm(srcs, Wt, M, N, x3=False, **kw).double().cpu()
+    e3, e1 = (y3 - ref).abs(), (y1 - ref).abs()
+    assert float(e3.max()) <= _tol(ref, K) and float(e1.max()) <= _tol(ref, K)
+    assert float(e3.max()) <= 1.25 * float(e1.max()) + 1e-9, (float(e3.max()), float(e1.max()))
+    assert float(e3.pow(2).mean().sqrt()) <= 1.1 * float(e1.pow(2).mean().sqrt()) + 1e-12, (float(e3.pow(2).mean().sqrt()), float(e1.pow(2).mean().sqrt()))
+    # the automatic choice takes the bf16x3 kernel for K >= 128, M % 128 == 0 and at least 8 workgroups of 128 x 128 per frame (and the knob switches it off)
+    auto = ops.pointwise_gemm(srcs, Wt, M, N, **kw).double().cpu()
+    assert torch.equal(auto, y3 if (K >= 128 and M % 128 == 0 and ((N + 127) // 128) * (M // 128) >= 8) else y1)
+    with _lib.option("pw_x3", 0):
+        assert torch.equal(ops.pointwise_gemm(srcs, Wt, M, N, **kw).double().cpu(), y1)
