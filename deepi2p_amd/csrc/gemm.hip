@@ -251,6 +251,45 @@ struct EpiPointwiseT {
                 const int m = mrow0 + (r & 3) + 8 * (r >> 2);
                 if (m < M) lds_tile[m * lds_ld + (n - lds_n0)] = v[r];
             }
+        } else if (e.group_max == 16) {
+            // max over 16 consecutive columns = the 16 lanes of a DPP row (k_ab = 16 neighbours, layers_pc.py:809-816).  Four
+            // v_max_f32 with the DPP modifier per value, four values interleaved per asm block (a DPP read needs two wait states after a
+            // write of the same register) -- instead of four ds_bpermute round trips with NaN bookkeeping per value (~40 instructions and four
+            // LDS latencies each: the epilogue of a 256-channel layer cost as much as its K loop).  torch.max semantics (NaN propagates):
+            // the NaN flags of the lane's 16 values travel as ONE bit mask, OR-ed over the row the same way.
+            float mx[16];
+            unsigned nanbits = 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+                const bool ok = col_ok && m < M;
+                if (e.gmax_out && ok) Y[((long long)b * M + m) * N + n] = v[r];
+                mx[r] = ok ? v[r] : -__builtin_inff();
+                nanbits |= (mx[r] != mx[r]) ? (1u << r) : 0u;
+            }
+#define DI2P_OR_DPP(CTRL) nanbits |= (unsigned)__builtin_amdgcn_update_dpp((int)nanbits, (int)nanbits, CTRL, 0xf, 0xf, false)
+            DI2P_OR_DPP(0xB1); DI2P_OR_DPP(0x4E); DI2P_OR_DPP(0x141); DI2P_OR_DPP(0x140);
+#undef DI2P_OR_DPP
+#define DI2P_MAX4(CTRL)                                 \
+    "v_max_f32_dpp %0, %0, %0 " CTRL "\n\t"            \
+    "v_max_f32_dpp %1, %1, %1 " CTRL "\n\t"            \
+    "v_max_f32_dpp %2, %2, %2 " CTRL "\n\t"            \
+    "v_max_f32_dpp %3, %3, %3 " CTRL "\n\t"
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                asm volatile("s_nop 1\n\t"
+                             DI2P_MAX4("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                             DI2P_MAX4("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                             DI2P_MAX4("row_half_mirror row_mask:0xf bank_mask:0xf")
+                             DI2P_MAX4("row_mirror row_mask:0xf bank_mask:0xf")
+                             : "+v"(mx[4 * q]), "+v"(mx[4 * q + 1]), "+v"(mx[4 * q + 2]), "+v"(mx[4 * q + 3]));
+#undef DI2P_MAX4
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+                const float val = ((nanbits >> r) & 1u) ? __builtin_nanf("") : mx[r];
+                if (col_ok && m < M && (n & 15) == 0) e.gmax_dst[((long long)b * M + m) * (N / 16) + n / 16] = val;
+            }
         } else if (e.group_max > 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

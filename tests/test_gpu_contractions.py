@@ -267,3 +267,23 @@ def test_pointwise_gemm_bf16x3_as_accurate_as_fp32_mfma(dev, B, chans, M, N, mod
     assert torch.equal(auto, y3 if (K >= 128 and M % 128 == 0 and ((N + 127) // 128) * (M // 128) >= 8) else y1)
     with _lib.option("pw_x3", 0):
         assert torch.equal(ops.pointwise_gemm(srcs, Wt, M, N, **kw).double().cpu(), y1)
+
+
+@pytest.mark.parametrize("grp,x3", [(16, False), (16, True), (8, False), (32, False)])
+def test_group_max_epilogue_torch_max_semantics(dev, grp, x3):
+    """max over groups of consecutive columns in the epilogue == torch.max(dim): exact on the kernel's own full output (also_full), NaN
+    propagates to its group only; groups of 16 take the DPP path, other sizes the shuffle path."""
+    from deepi2p_amd import ops
+    g = torch.Generator().manual_seed(grp)
+    B, K, M, N = 2, 256, 256, 2048
+    x = torch.randn(B, K, N, generator=g)
+    x[0, 5, 37] = float("nan")                       # poisons column 37 of frame 0 in every row
+    x[1, :, 100] = -1e30                             # a very negative column must not win or lose anything
+    Wt = (torch.randn(K, M, generator=g) / K ** 0.5).to(dev)
+    full, mx = ops.pointwise_gemm([ops.Src(x.to(dev))], Wt, M, N, group_max=grp, also_full=True, x3=x3)
+    only = ops.pointwise_gemm([ops.Src(x.to(dev))], Wt, M, N, group_max=grp, x3=x3)
+    ref = full.view(B, M, N // grp, grp).max(dim=3)[0]
+    assert torch.equal(torch.isnan(mx), torch.isnan(ref)) and bool(torch.isnan(mx[0, :, 37 // grp]).all())
+    assert int(torch.isnan(mx).sum()) == M
+    assert torch.equal(torch.nan_to_num(mx, nan=0.0), torch.nan_to_num(ref, nan=0.0))
+    assert torch.equal(torch.nan_to_num(only, nan=0.0), torch.nan_to_num(mx, nan=0.0))
