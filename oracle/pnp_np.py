@@ -2,7 +2,9 @@
 
 Replaces cv2.solvePnPRansac as called by evaluation/registration_pnp.py:95-148.  PARITY UNPINNED: OpenCV is neither in
 the reference tree nor in this image and its RANSAC sampling is internal; the reference holds no vector for this path.
-This restatement is pinned by pose recovery on synthetic exact correspondences (tests/test_pnp.py) and uses independent
+The FRONT END around the OpenCV call IS pinned (tests/golden/pnp_frontend_golden.npz: the reference's solve_PnP extracted with ``ast`` and
+run against a recording cv2): `correspondences` (what reaches solvePnPRansac), camera_matrix_scaling, the >= 4 rule, `accept` (|t| < 14.14,
+outlier ratio).  The estimator itself is pinned by pose recovery on synthetic exact correspondences (tests/test_pnp.py) and uses independent
 numerics for the two linear-algebra steps (SVD null vector, SVD polar factor) so it cross-checks the kernel's Gaussian
 elimination and Newton polar iteration.
 """

@@ -3,9 +3,12 @@
 farthest_point_sampling   data/kitti_helper.py:231-243 (FarthestSampler.sample).  PINNED by
                           tests/golden/prep_golden.npz generated from the reference class itself.
 project_labels / accuracy / pc_label record
-                          evaluation/visualize_and_save_data.py:100-115,138-147,174-181.  That code is inline in a
-                          script (needs datasets/cv2), not a function: restated from the cited lines, PARITY UNPINNED
-                          beyond that (checked against an independent fp64 evaluation away from the frustum edges).
+                          models/multimodal_classifier.py:135-156,194-199 (foraward_pass) and
+                          evaluation/visualize_and_save_data.py:100-115,138-147,174-181 (the evaluation script's loop body).
+                          PINNED by tests/golden/forward_pass_golden.npz and eval_script_golden.npz: the reference's own method /
+                          loop body, extracted with ``ast`` and run against stub collaborators (tests/golden/make_golden.py
+                          make_forward_pass / make_eval_script) -- coarse labels, fine labels of the inside points, pixel
+                          coordinates, accuracies (sums and the printed lines) and the saved 7 x N records.
 """
 import numpy as np
 
