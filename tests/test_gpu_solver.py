@@ -256,3 +256,36 @@ def test_solver_matches_oracle_other_cameras(dev, seed, is_2d, N, HW, flip):
     np.testing.assert_allclose(cg[ok], co[ok], rtol=1e-6)
     assert abs(cg.min() - co.min()) <= 1e-6 * co.min()
     np.testing.assert_array_equal(it_g[ok], it_o[ok])            # same number of LM iterations where the iterates agree
+
+
+@pytest.mark.parametrize("scene", ["scan", "patchy", "collapsed", "duplicates"])
+@pytest.mark.parametrize("N", [777, 20480])
+def test_frame_preparation_sort_paths_agree(dev, scene, N):
+    """Frame preparation sorts the records by (label, Hilbert cell, index).  The counting sort + per-bucket ranking (buckets of <= 64 keys by one
+    wavefront, 65..1024 by the workgroup, anything denser falls back) must produce the SAME order as the bitonic network: params, costs,
+    iteration and sweep counts bit-identical.  Scenes: a scan (small buckets), patchy (dense patches: workgroup-ranked buckets), collapsed
+    (a far outlier stretches the grid so that everything shares a few cells: fallback), duplicates (equal coordinates, unique keys by index)."""
+    from deepi2p_amd import _lib, ops
+    f, rng = _frame(900 + N, N)
+    pts, lab = f["pc"].astype(np.float32).copy(), f["labels"].astype(np.int32).copy()
+    if scene == "patchy":
+        m = N // 3
+        pts[0, :m] = 10.0 + rng.uniform(0, 4.0, m); pts[2, :m] = 20.0 + rng.uniform(0, 4.0, m)          # one 4 m patch holds a third of the points
+    elif scene == "collapsed":
+        pts[:, 0] = [4e4, 0.0, 4e4]
+    elif scene == "duplicates":
+        pts[:, N // 2:] = pts[:, :N - N // 2]
+    R = 6
+    ys = rng.normal(f["yaw_gt"], 0.2, R)
+    Ts = np.stack((np.zeros(R), np.zeros(R), rng.uniform(-5, 5, R)), axis=1)
+    args = (torch.from_numpy(pts).to(dev).unsqueeze(0), torch.from_numpy(lab).to(dev).unsqueeze(0), torch.from_numpy(f["K"]).to(dev).view(1, 3, 3),
+            torch.from_numpy(ys).to(dev).view(1, R), torch.from_numpy(Ts).to(dev).view(1, R, 3), H, W, LB, UB, 40, True)
+
+    def run():
+        sweeps = torch.zeros((1, R), dtype=torch.int32, device=dev)
+        params, cost, iters = ops.solve_batched(*args, sweeps=sweeps)
+        return [t.cpu().numpy().tobytes() for t in (params, cost, iters, sweeps)]
+    a = run()
+    with _lib.option("solver_prep_bitonic", 1):
+        b = run()
+    assert a == b
