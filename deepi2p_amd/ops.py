@@ -6,6 +6,7 @@ index_max_cuda.cu:75,93) and never synchronises, so sequences of these calls can
 ``torch.cuda.CUDAGraph``.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -177,7 +178,7 @@ def _fill_gathered(e, gathered, B, M, N):
 # so a recycled address can never return a stale split.  Filled by the first eager call of a layer (the executor runs one eager step before
 # it captures a graph); a call under stream capture with a cold cache packs on the capturing stream, which is valid too (the pack kernel
 # becomes a graph node), only slower.
-_X3_CACHE = {}
+_X3_CACHE = {}            # (address, K, M, device) -> (weak reference to the fp32 operand's base tensor, split operand)
 X3_MIN_K = 128
 
 
@@ -208,10 +209,15 @@ def _x3_operand(Wt, B, M, N, x3):
         return None
     if M % 4 or N % 4 or not Wt.is_contiguous():
         raise RuntimeError("bf16x3 needs M % 4 == 0, N % 4 == 0 and a contiguous [K,M] weight")
+    # an address is only an identity while the tensor that owns it is alive: the entry remembers (weakly) the base tensor it was made from --
+    # a deleted module's operand whose memory the allocator hands to the next module must not find the old split
+    base = Wt._base if Wt._base is not None else Wt
     key = (Wt.data_ptr(), K, M, Wt.device.index)
-    Wp = _X3_CACHE.get(key)
-    if Wp is None:
-        Wp = _X3_CACHE[key] = bf16x3_pack(Wt)
+    ent = _X3_CACHE.get(key)
+    if ent is not None and ent[0]() is base:
+        return ent[1]
+    Wp = bf16x3_pack(Wt)
+    _X3_CACHE[key] = (weakref.ref(base), Wp)
     return Wp
 
 

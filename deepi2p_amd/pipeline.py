@@ -129,7 +129,7 @@ class RegistrationExecutor:
         with torch.cuda.stream(slot.stream):
             self._step(slot, with_h2d)                                       # eager once: lazily created constants, allocator warm-up
         slot.stream.synchronize()
-        self._x3_refs = list(ops._X3_CACHE.values())                         # the graph will hold raw pointers to these split weights too
+        self._x3_refs = [e[1] for e in ops._X3_CACHE.values()]               # the graph will hold raw pointers to these split weights too
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=slot.stream):
             out = self._step(slot, with_h2d)

@@ -287,3 +287,27 @@ def test_group_max_epilogue_torch_max_semantics(dev, grp, x3):
     assert int(torch.isnan(mx).sum()) == M
     assert torch.equal(torch.nan_to_num(mx, nan=0.0), torch.nan_to_num(ref, nan=0.0))
     assert torch.equal(torch.nan_to_num(only, nan=0.0), torch.nan_to_num(mx, nan=0.0))
+
+
+def test_bf16x3_split_cache_follows_the_operand_not_the_address(dev):
+    """The split weights are cached per fp32 operand.  A freed operand's address is handed to the next allocation of the same size: the
+    entry must not survive its tensor (it remembers the tensor weakly), and _PackedModule._invalidate() drops everything."""
+    import gc
+    from deepi2p_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, K, M, N = 1, 256, 256, 2048
+    x = torch.randn(B, K, N, generator=g).to(dev)
+    seen = set()
+    for trial in range(4):
+        Wt = (torch.randn(K, M, generator=g) / K ** 0.5).to(dev)
+        seen.add(Wt.data_ptr())
+        y3 = ops.pointwise_gemm([ops.Src(x)], Wt, M, N, x3=True)
+        y1 = ops.pointwise_gemm([ops.Src(x)], Wt, M, N, x3=False)
+        assert float((y3 - y1).abs().max()) <= 2 * _tol(y1, K), trial          # a stale split would be off by O(1)
+        xh = x[:, 0:128].contiguous()         # a row slice of the operand (a view: same base tensor) is its own cache entry
+        assert torch.equal(ops.pointwise_gemm([ops.Src(xh)], Wt[0:128], M, N, x3=True), ops.pointwise_gemm([ops.Src(xh)], Wt[0:128].clone(), M, N, x3=True))
+        del Wt, y3, y1
+        gc.collect()
+    assert len(seen) < 4              # the allocator did recycle an address: the case the weak reference exists for
+    ops.x3_invalidate()
+    assert not ops._X3_CACHE
