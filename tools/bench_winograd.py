@@ -43,8 +43,9 @@ for (C, H, W, calls) in ((64, 40, 128, 6), (128, 20, 64, 7), (256, 10, 32, 11), 
                 same = bool(torch.equal(y0, ops.conv3x3_winograd(x, U, sc, sh, True, residual=res)))
     best = min(v for v in out if v == v)
     tot[0] += td * calls; tot[1] += best * calls
-    print("%-22s %10.1f %8.1f | LDS panels K-step 8 %6.1f K-step 4 %6.1f | register-resident 4 waves %6.1f 2 waves %6.1f pipelined %6.1f (bit-identical %s) | best %.1f TF" % (
-        "%d,%d,%d,%d" % (C, H, W, C), td, fl / td / 1e6, out[0], out[1], out[2], out[3], pipe, same, fl / best / 1e6))
+    print("%-22s %10.1f %8.1f | LDS panels K-step 8 %6.1f K-step 4 %6.1f | register-resident 4 waves %6.1f 2 waves %6.1f%s | best %.1f TF" % (
+        "%d,%d,%d,%d" % (C, H, W, C), td, fl / td / 1e6, out[0], out[1], out[2], out[3],
+        (" pipelined %6.1f (bit-identical %s)" % (pipe, same)) if same is not None else "", fl / best / 1e6))
 print("26 layers per 32-frame step: direct %.3f ms, Winograd (better blocking per shape) %.3f ms" % (tot[0] / 1e3, tot[1] / 1e3))
 
 x = torch.rand(B, 3, 160, 512, device=dev) * 255

@@ -117,7 +117,8 @@ files listed in KEEP_OLD (if present) come from earlier calls of the round.
 * `{TAG}_gputest_tail.txt` -- `python -m pytest tests -q -m gpu`: {gt}.
 * `{TAG}_bench_line.json` -- the JSON line of `python bench.py` ({line['steps']} steps, {line['warmup']} warm-up, {line['config']['streams']} streams on {line['config']['hw_queues']} hardware queues, one hipGraph per stream, CPU baseline
   leg included): **{line['value']:.0f} frames/s** resident ({line['ms_per_step']:.2f} ms per 32-frame step), {line['value_with_h2d']:.0f} frames/s with the
-  host->device copy of every batch inside the step; per-batch device latency {line['latency_ms_per_batch']}.  Roofline object = time-dominant family = `solve_kernel`:
+  host->device copy of every batch inside the step; device time of one batch {line['latency_ms_per_batch']['streams_%d' % line['config']['streams']]:.1f} ms with all streams busy,
+  {line['latency_ms_per_batch']['one_step_in_flight']:.1f} ms with a single step in flight.  Roofline object = time-dominant family = `solve_kernel`:
   {k['solve_kernel']['ms_per_step']:.2f} ms per step, {k['solve_kernel']['achieved']:.1f} TFLOP/s by SURVEY 8(d)'s unit = {k['solve_kernel']['frac']:.2f} of the 78.6 TFLOP/s fp64 vector peak.
   Per family (`kernels`): convolution {cv['ms_per_step']:.2f} ms = {cv['achieved']:.1f} TFLOP/s algorithmic = **{cv['frac']:.2f}** of the fp32-MFMA peak (26 Winograd
   launches {cv['winograd']['ms_per_step']:.2f} ms, whose MFMA units issue {cv['winograd']['executed_mfma_tflops']:.0f} TFLOP/s; 9 implicit-GEMM launches {cv['winograd']['direct_kernel_ms_per_step']:.2f} ms; stem
@@ -128,10 +129,11 @@ files listed in KEEP_OLD (if present) come from earlier calls of the round.
   contention.
 * `{TAG}_bench_kernel_stats_serial.csv` / `{TAG}_bench_line_serial.json` -- the same with `--streams 1` ({ser['value']:.0f} frames/s): durations without
   contention.  `solve_kernel` averages {avg('solve_kernel')/1e3:.2f} ms (rocprof) against {ser['kernels']['solve_kernel']['ms_per_step']:.2f} ms from the HIP events of the same run's JSON
-  line; `wino_conv_kernel<32, true, 4>` {avg('wino_conv_kernel<32, true, 4>'):.1f} us, `<32, true, 8>` {avg('wino_conv_kernel<32, true, 8>'):.1f} us, `wino_reg_kernel<4>` {avg('wino_reg_kernel<4>'):.1f} us per call; `knn_nodes_kernel<3>` {avg('knn_nodes_kernel<3>'):.1f} us, `index_max` {avg('index_max'):.1f} us.
+  line; `wino_conv_kernel<32, true, 8>` {avg('wino_conv_kernel<32, true, 8>'):.1f} us, `wino_reg_kernel<4>` {avg('wino_reg_kernel<4>'):.1f} us per call; `knn_nodes_kernel<3>` {avg('knn_nodes_kernel<3>'):.1f} us, `index_max` {avg('index_max'):.1f} us.
 * `{TAG}_pmc_{{solver,conv}}_{{FETCH,WRITE}}_SIZE.csv`, `{TAG}_pmc_traffic.json` -- separate `--pmc` passes (kernel-trace only) on
   `tools/bench_solver.py` and `tools/bench_conv.py`.  solve_kernel: {sp['FETCH_SIZE_KiB']/1024:.1f} MiB fetched raw (x2 = {sp['fetch_bytes_corrected']/1e6:.1f} MB) per launch against 10.8 MB
-  of once-through records + boxes (the working set is cache resident), {sp['WRITE_SIZE_KiB']/1024:.1f} MiB written (round 2: 48.7 MiB of spill write-back).  Convolution family of one
+  of once-through records + boxes (the working set is cache resident), {sp['WRITE_SIZE_KiB']/1024:.1f} MiB written (round 3: 34 MiB; the classification-cache entries -- 16 B per missed cluster and sweep --
+  are written back several times: 20 GB/s over the launch, DESIGN.md section 4 "Round 4 on the solver").  Convolution family of one
   encoder pass: FETCH {cvp['FETCH_SIZE_KiB_per_encoder_pass_raw']/1024:.0f} MiB raw / {cvp['FETCH_SIZE_KiB_per_encoder_pass_corrected']/1024:.0f} MiB corrected, WRITE {cvp['WRITE_SIZE_KiB_per_encoder_pass_raw']/1024:.0f} MiB = {cvp['hbm_bytes_per_call_corrected']/1e6:.0f} MB per convolution call against
   52 MB compulsory (the Winograd workgroups re-stream their slice of the transformed filters: under 1 TB/s over the family's time
   -- not a limiter).  index_max (fresh passes on cold inputs): C = 64 {pm['index_max_C64_B32_N20480_K128']['hbm_bytes_corrected']/1e6:.0f} MB against {pm['index_max_C64_B32_N20480_K128']['algorithmic_bytes']/1e6:.0f} MB algorithmic, C = 32 {pm['index_max_C32_B32_N20480_K128']['hbm_bytes_corrected']/1e6:.0f} / {pm['index_max_C32_B32_N20480_K128']['algorithmic_bytes']/1e6:.0f} MB.  (`{TAG}_bench_line.json` was produced AFTER
