@@ -310,7 +310,7 @@ def main():
 
     # per-kernel-family durations: HIP events on the launch stream, in a SERIAL pass right after the timed region
     # (with several batches in flight, events inside the timed region would measure contention, not the kernels)
-    timed_names = ("di2p_conv2d", "di2p_conv2d_ws", "di2p_conv3x3_winograd", "di2p_conv7x7s2_stem", "di2p_pointwise_gemm", "di2p_pointwise_gemm_x3", "di2p_point_head", "di2p_index_max_values",
+    timed_names = ("di2p_conv2d", "di2p_conv2d_ws", "di2p_conv3x3_winograd", "di2p_conv7x7s2_stem", "di2p_pointwise_gemm", "di2p_pointwise_gemm_x3", "di2p_point_head", "di2p_point_chain", "di2p_index_max_values",
                    "di2p_solve_batched_f32", "di2p_knn_nodes")
     prof_steps = 2
     _lib.TIMED = {n: [] for n in timed_names}
@@ -338,9 +338,10 @@ def main():
     # ... and the GEMM-shaped layers that run on the bf16 matrix instructions with exact three-way fp32 splits (priced separately below)
     x3_ms, x3_calls = fam_ms.pop("di2p_pointwise_gemm_x3"), launches.pop("di2p_pointwise_gemm_x3")
     x3_mac = work.get("di2p_pointwise_gemm_x3", 0) / prof_steps
-    fam_ms["di2p_pointwise_gemm"] += fam_ms.pop("di2p_point_head") + x3_ms
-    launches["di2p_pointwise_gemm"] += launches.pop("di2p_point_head") + x3_calls
-    pw_exec_flops = 2.0 * (work.get("di2p_pointwise_gemm", 0) + work.get("di2p_point_head", 0)) / prof_steps + 2.0 * x3_mac
+    chain_ms, chain_calls = fam_ms.pop("di2p_point_chain"), launches.pop("di2p_point_chain")     # fused narrow PointNet chains (HBM-bound)
+    fam_ms["di2p_pointwise_gemm"] += fam_ms.pop("di2p_point_head") + x3_ms + chain_ms
+    launches["di2p_pointwise_gemm"] += launches.pop("di2p_point_head") + x3_calls + chain_calls
+    pw_exec_flops = 2.0 * (work.get("di2p_pointwise_gemm", 0) + work.get("di2p_point_head", 0) + work.get("di2p_point_chain", 0)) / prof_steps + 2.0 * x3_mac
     conv_flops = conv_flops_per_frame(H, W) * B
     knn_bytes = 2 * B * (12 * N + 24 * N + 3 * 4 * 128)          # the two point-level calls (pc -> node_a, pc -> node_b); node-level calls are negligible
     idx_bytes = B * (4 * 32 * N + 4 * N + 2 * 4 * 32 * 128) + B * (4 * 64 * N + 4 * N + 2 * 4 * 64 * 128)
@@ -373,6 +374,10 @@ def main():
             "achieved_executed": pw_exec_flops / (fam_ms["di2p_pointwise_gemm"] * 1e-3) / 1e12,
             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "ms_per_step": fam_ms["di2p_pointwise_gemm"],
             "launches_per_step": launches["di2p_pointwise_gemm"],
+            "fused_chains": {"calls_per_step": chain_calls, "ms_per_step": chain_ms,
+                             "hbm_tb_per_s": B * N * 4.0 * ((7 + 32) + (32 + 64)) / max(chain_ms, 1e-9) / 1e9,
+                             "note": "first_pointnet (7->32->32->32) and second_pointnet (32+32->64->64) as one launch each: compulsory "
+                                     "traffic = inputs once + outputs once, hidden activations in LDS"},
             "bf16x3": {"calls_per_step": x3_calls, "ms_per_step": x3_ms, "fp32_equivalent_tflops": 2.0 * x3_mac / max(x3_ms, 1e-9) / 1e9,
                        "frac_of_fp32_mfma_peak": 2.0 * x3_mac / max(x3_ms, 1e-9) / 1e9 / MFMA_F32_PEAK_TFLOPS,
                        "executed_bf16_tflops": 12.0 * x3_mac / max(x3_ms, 1e-9) / 1e9, "bf16_mfma_peak_tflops": MFMA_BF16_PEAK_TFLOPS,
@@ -567,7 +572,7 @@ def main_train(args):
     # Algorithmic work = what autograd of the reference's graph does: forward + dgrad + wgrad = 3 x the forward multiply-accumulates of
     # SURVEY.md 8(d) (coarse + fine model: 13.284 GMAC per frame at 20480 points / 160x512), minus the input gradient of the stem (the
     # image needs none).  Time = HIP events around every contraction call of one serial step.
-    mfma_calls = ("di2p_pointwise_gemm", "di2p_point_head", "di2p_conv3x3_winograd", "di2p_conv2d", "di2p_conv2d_ws", "di2p_conv7x7s2_stem",
+    mfma_calls = ("di2p_pointwise_gemm", "di2p_point_head", "di2p_point_chain", "di2p_conv3x3_winograd", "di2p_conv2d", "di2p_conv2d_ws", "di2p_conv7x7s2_stem",
                   "di2p_conv2d_wgrad", "di2p_conv2d_dgrad", "di2p_bmm_rc", "di2p_bmm_km", "di2p_gather_backward", "di2p_winograd_weight_transform")
     mfma_ms = sum(fam[k][0] for k in mfma_calls if k in fam)
     roofline = None

@@ -54,6 +54,8 @@ _SIGS = {
     "di2p_attention_pool": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "di2p_point_head": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                         c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "di2p_point_chain": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                         c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "di2p_conv2d": [c_void_p] * 6 + [c_int] * 11 + [c_void_p],
     "di2p_conv2d_ws": [c_void_p] * 6 + [c_int] * 11 + [c_void_p, c_ll, c_void_p],
     "di2p_maxpool3x3s2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],

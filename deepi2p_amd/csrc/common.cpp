@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 
 static thread_local char g_err[512] = "ok";
@@ -33,7 +34,7 @@ const OptDef kOpts[DI2P_OPT_COUNT] = {
     {"pw_cfg", "DI2P_PW_CFG", 0},                   {"wino_reg", "DI2P_WINO_REG", 0},                 {"wino_reg_min", "DI2P_WINO_REG_MIN", 256},
     {"solver_lds_pad", "DI2P_SOLVER_LDS_PAD", 0},   {"solver_nocache", "DI2P_SOLVER_NOCACHE", 0},
     {"solver_prep_bitonic", "DI2P_SOLVER_PREP_BITONIC", 0},
-    {"pw_x3", "DI2P_PW_X3", 1},
+    {"pw_x3", "DI2P_PW_X3", 1},                     {"pw_nochain", "DI2P_PW_NOCHAIN", 0},
 };
 long long g_opt[DI2P_OPT_COUNT];
 std::once_flag g_opt_once;
@@ -44,6 +45,18 @@ void opts_init() {
     }
 }
 }  // namespace
+
+int di2p_cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
 
 long long di2p_opt(int id) {
     std::call_once(g_opt_once, opts_init);

@@ -57,6 +57,8 @@ enum Di2pOption {
     DI2P_OPT_SOLVER_NOCACHE,        // 1: no classification cache in the cluster walk (bit-identical by construction)
     DI2P_OPT_SOLVER_PREP_BITONIC,   // 1: frame preparation always sorts with the bitonic network (default: counting sort + per-bucket ranking; same order)
     DI2P_OPT_PW_X3,                 // 1 (default): the host layer runs the GEMM-shaped pointwise layers (K >= 128, M % 128 == 0) on the bf16x3 kernel (read by ops.py)
+    DI2P_OPT_PW_NOCHAIN,            // 1: the host layer runs the narrow PointNet chains as separate launches instead of di2p_point_chain (bit-identical; read by ops.py)
     DI2P_OPT_COUNT
 };
 long long di2p_opt(int id);
+int di2p_cu_count();      // compute units of the current device (cached per device)

@@ -160,10 +160,8 @@ struct EpiPointwiseT {
     int b, M, N;
     float* lds_tile = nullptr;   // fused chains: write the tile to LDS as the next layer's [k = m][n - lds_n0] operand panel
     int lds_n0 = 0, lds_ld = 0;
-    __device__ __forceinline__ void tile(int mrow0, int n, const f32x16& acc) {
-        const bool col_ok = n < N;
-        const int nc = col_ok ? n : N - 1;
-        float v[16];
+    // the epilogue arithmetic proper (bias, gathered add, scale, shift, relu) on the 16 rows mrow0 + 8g + {0..3} of column nc (< N)
+    __device__ __forceinline__ void apply(int mrow0, int nc, const f32x16& acc, float (&v)[16]) const {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = acc[r];
         if (e.batch_bias) {
@@ -245,6 +243,12 @@ struct EpiPointwiseT {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
         }
+    }
+    __device__ __forceinline__ void tile(int mrow0, int n, const f32x16& acc) {
+        const bool col_ok = n < N;
+        const int nc = col_ok ? n : N - 1;
+        float v[16];
+        apply(mrow0, nc, acc, v);
         if (lds_tile) {          // columns past N hold clamped (finite) duplicates; they are never stored to memory
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -413,6 +417,168 @@ __global__ __launch_bounds__(HeadCfg::THREADS) void point_head_kernel(SrcDev src
         if (tl.sh2) a += tl.sh2[p];
         if (tl.relu2) a = fmaxf(a, 0.0f);
         if (n < N) out[((long long)b * tl.P + p) * N + n] = a;
+    }
+}
+
+// ---- fused narrow PointNet chains (first_pointnet 7 -> 32 -> 32 -> 32 and second_pointnet (32 + gathered 32) -> 64 -> 64 of
+// networks_pc.py:36-43,60-75): two or three pointwise layers of ONE width M in one launch, WAVE-AUTONOMOUS.  A wave owns all M channels
+// of 32 * TN points through the whole chain: the accumulator tile a layer leaves in a lane's registers (16 rows of one column per 32 x 32
+// block) IS the next layer's B operand for that column, up to which half-wave holds which row -- lanes l and l + 32 share a column and
+// hold rows 8g + {0..3} and 8g + {4..7}; one v_permlane32_swap per register pair puts rows (2s, 2s + 1) into the two halves of one
+// register, the operand of K-step s.  No LDS traffic for activations, no workgroup barrier after the weights (9-40 KB, staged to LDS
+// once per workgroup) are in place; layer 0 reads its operand rows straight from memory (coalesced 128 B per row and half-wave).
+// Same K order, same MFMA sequence and the same epilogue code as the separate launches: BIT-IDENTICAL to them (up to the sign of
+// zero: all-zero K-steps of a padded K are skipped), while the hidden activations (2 x 84 MB + 168 MB written and read back per
+// 32-frame step) never exist in memory.
+struct ChainTail {
+    const float* W1t;      // [M][M] k-major
+    const float* sc1;
+    const float* sh1;
+    const float* W2t;      // [M][M] (three-layer chain)
+    const float* sc2;
+    const float* sh2;
+    int relu1, relu2;
+};
+
+// v[16] (rows 8g + j + 4*half of one column, r = 4g + j) -> f[16] with f[s] = {row 2s in lanes 0-31, row 2s + 1 in lanes 32-63}
+__device__ __forceinline__ void chain_rows_to_ksteps(const float (&v)[16], float* f) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        // swap(X, Y): X' = {X.lo, Y.lo}, Y' = {X.hi, Y.hi}.  X = rows (8g, 8g + 4), Y = rows (8g + 1, 8g + 5) -> X' = rows (8g, 8g + 1), Y' = (8g + 4, 8g + 5)
+        auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[4 * g + 0]), __float_as_uint(v[4 * g + 1]), false, false);
+        auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[4 * g + 2]), __float_as_uint(v[4 * g + 3]), false, false);
+        f[4 * g + 0] = __uint_as_float(p[0]);      // K-step 4g    : rows 8g,     8g + 1
+        f[4 * g + 1] = __uint_as_float(q[0]);      // K-step 4g + 1: rows 8g + 2, 8g + 3
+        f[4 * g + 2] = __uint_as_float(p[1]);      // K-step 4g + 2: rows 8g + 4, 8g + 5
+        f[4 * g + 3] = __uint_as_float(q[1]);      // K-step 4g + 3: rows 8g + 6, 8g + 7
+    }
+}
+
+// M: width (32 / 64); KS0: K-steps (pairs of input channels) of layer 0, >= ceil(K0 / 2); NL: layers; TN: 32-point blocks per wave and trip
+#ifndef DI2P_CHAIN_WAVES
+#define DI2P_CHAIN_WAVES 2
+#endif
+template <int M, int KS0, int NL, int TN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DI2P_CHAIN_WAVES, 8))) void point_chain_kernel(const float* __restrict__ X, long long x_bs, int x_rs, const float* __restrict__ W0t,
+                                                           int K0, EpiDev e0, ChainTail tl, float* __restrict__ Y, int N, int nblk, int total) {
+    constexpr int TM = M / 32, KS = M / 2, KSMAX = KS0 > KS ? KS0 : KS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* w0 = lds;                       // [2 * KS0][M], rows >= K0 zero
+    float* w1 = w0 + 2 * KS0 * M;          // [M][M]
+    float* w2 = w1 + M * M;
+    float* ss = w2 + (NL == 3 ? M * M : 0);      // scale / shift rows of the layers: [6][M] (the epilogues read them from LDS, not through the texture path)
+    for (int i = threadIdx.x; i < 2 * KS0 * M; i += 256) w0[i] = i < K0 * M ? W0t[i] : 0.0f;
+    for (int i = threadIdx.x; i < M * M; i += 256) w1[i] = tl.W1t[i];
+    if (NL == 3)
+        for (int i = threadIdx.x; i < M * M; i += 256) w2[i] = tl.W2t[i];
+    {
+        const float* rows[6] = {e0.scale, e0.shift, tl.sc1, tl.sh1, NL == 3 ? tl.sc2 : nullptr, NL == 3 ? tl.sh2 : nullptr};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+            if (rows[q] && threadIdx.x < M) ss[q * M + threadIdx.x] = rows[q][threadIdx.x];
+    }
+    __syncthreads();
+    if (e0.scale) e0.scale = ss;
+    if (e0.shift) e0.shift = ss + M;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    EpiDev e1{}, e2{};
+    e1.scale = tl.sc1 ? ss + 2 * M : nullptr; e1.shift = tl.sh1 ? ss + 3 * M : nullptr; e1.relu = tl.relu1; e1.group_max = 1;
+    e2.scale = tl.sc2 ? ss + 4 * M : nullptr; e2.shift = tl.sh2 ? ss + 5 * M : nullptr; e2.relu = tl.relu2; e2.group_max = 1;
+
+    // The blocks of ALL frames form one list (block g = frame g / nblk, columns (g % nblk) * 32 * TN ...) that the waves of the launch walk
+    // with a common stride: the host sizes the grid to whole workgroups per compute unit and equal trip counts, so the weights are staged
+    // once per resident workgroup and no wave idles while another finishes.
+    // Layer 0's operand rows come straight from memory (rows >= K0: zero; their weights are zero too); the rows of the wave's NEXT block
+    // are requested before this block's arithmetic starts.
+    float fn[TN][KS0];
+    auto request = [&](int g) {
+        const int fb = g / nblk, blk = g - fb * nblk;
+        const float* Xb = X + (long long)fb * x_bs;
+#pragma unroll
+        for (int s = 0; s < KS0; ++s) {
+            const int k = 2 * s + half;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float x = Xb[(long long)min(k, K0 - 1) * x_rs + min((blk * TN + j) * 32 + l31, N - 1)];
+                fn[j][s] = k < K0 ? x : 0.0f;
+            }
+        }
+    };
+    const int g0 = blockIdx.x * 4 + wave, stride = gridDim.x * 4;
+    if (g0 < total) request(g0);
+    for (int g = g0; g < total; g += stride) {
+        const int b = g / nblk, blk = g - b * nblk;
+        EpiPointwise ep0{e0, nullptr, b, M, N}, ep1{e1, nullptr, b, M, N}, ep2{e2, nullptr, b, M, N};
+        int n[TN], nc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { n[j] = (blk * TN + j) * 32 + l31; nc[j] = min(n[j], N - 1); }
+        float f[TN][KSMAX];                 // B operands of the running layer, one register per K-step
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int s = 0; s < KS0; ++s) f[j][s] = fn[j][s];
+        request(min(g + stride, total - 1));
+        f32x16 acc[TM][TN];
+        auto zero = [&]() {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        };
+        auto layer = [&](const float* w, auto ks_tag) {
+            constexpr int STEPS = decltype(ks_tag)::value;
+            const float* wl = w + half * M + l31;
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                float a[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = wl[2 * s * M + i * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], f[j][s], acc[i][j], 0, 0, 0);
+            }
+        };
+        auto to_operands = [&](const EpiPointwise& ep) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float v[16];
+                    ep.apply(i * 32 + 4 * half, nc[j], acc[i][j], v);
+                    chain_rows_to_ksteps(v, &f[j][i * 16]);
+                }
+        };
+        auto to_memory = [&](const EpiPointwise& ep) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float v[16];
+                    ep.apply(i * 32 + 4 * half, nc[j], acc[i][j], v);
+                    if (n[j] < N) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            Y[((long long)b * M + i * 32 + 4 * half + (r & 3) + 8 * (r >> 2)) * N + n[j]] = v[r];
+                    }
+                }
+        };
+        zero();
+        layer(w0, std::integral_constant<int, KS0>{});
+        to_operands(ep0);
+        zero();
+        layer(w1, std::integral_constant<int, KS>{});
+        if (NL == 3) {
+            to_operands(ep1);
+            zero();
+            layer(w2, std::integral_constant<int, KS>{});
+            to_memory(ep2);
+        } else {
+            to_memory(ep1);
+        }
     }
 }
 
@@ -673,6 +839,18 @@ inline void alias_absent_sources(SrcDev& s, int n_src) {
 
 }  // namespace
 
+#ifndef DI2P_CHAIN_TN32
+#define DI2P_CHAIN_TN32 2
+#endif
+#ifndef DI2P_CHAIN_TN64
+#define DI2P_CHAIN_TN64 1
+#endif
+#ifndef DI2P_CHAIN_W32
+#define DI2P_CHAIN_W32 3          // resident workgroups per compute unit the chain kernels are launched with (<= what their registers allow)
+#endif
+#ifndef DI2P_CHAIN_W64
+#define DI2P_CHAIN_W64 2
+#endif
 using Cfg128x128 = TileCfg<2, 2, 2, 2>;
 using Cfg64x128 = TileCfg<2, 2, 1, 2>;
 using Cfg32x128 = TileCfg<1, 4, 1, 1>;
@@ -865,6 +1043,61 @@ extern "C" int di2p_point_head(const di2p_src_t* srcs, int n_src, const float* W
         (void)hipFuncSetAttribute((const void*)point_head_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(point_head_kernel<false>, dim3(di2p_cdiv(N, HEAD_BN), B), dim3(HeadCfg::THREADS), lds, (hipStream_t)stream, s, W0t, K0, e, tl, out, N);
     }
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" int di2p_point_chain(const di2p_src_t* srcs, int n_src, const float* W0t, int K0, const di2p_epilogue_t* epi0,
+                                const float* W1t, const float* scale1, const float* shift1, int relu1, const float* W2t,
+                                const float* scale2, const float* shift2, int relu2, float* Y, int B, int M, int N, void* stream) {
+    DI2P_CHECK_ARG(srcs && n_src == 1 && W0t && W1t && Y && epi0, "fused chain: one dense source");
+    DI2P_CHECK_ARG(M == 32 || M == 64, "fused chain: width 32 or 64 (use the separate layers otherwise)");
+    DI2P_CHECK_ARG(K0 <= M, "fused chain: at most M input channels");
+    DI2P_CHECK_ARG(B >= 0 && N >= 1 && K0 >= 1, "bad size");
+    DI2P_CHECK_ARG(epi0->group_max <= 1 && !epi0->transpose_out, "fused chain: layer 0 takes scale/shift/relu/bias/gathered only");
+    if (B == 0) return 0;
+    DI2P_CHECK_ARG(srcs[0].ptr && srcs[0].channels == K0 && srcs[0].mode == DI2P_SRC_DENSE, "fused chain: one dense source of K0 channels");
+    DI2P_CHECK_ARG((long long)srcs[0].channels * srcs[0].row_stride < (1ll << 31), "per-frame source extent must fit 31 bits");
+    EpiDev e{};
+    e.group_max = 1;
+    e.scale = epi0->scale; e.shift = epi0->shift; e.batch_bias = epi0->batch_bias; e.relu = epi0->relu;
+    for (int t = 0; t < 2; ++t) { e.g_table[t] = epi0->g_table[t]; e.g_idx[t] = epi0->g_idx[t]; e.g_w[t] = epi0->g_w[t]; e.g_nodes[t] = epi0->g_nodes[t]; }
+    for (int t = 0; t < 2; ++t) {
+        e.g_k[t] = e.g_table[t] ? epi0->g_k[t] : 0;
+        DI2P_CHECK_ARG(e.g_k[t] >= 0 && e.g_k[t] <= DI2P_MAX_GK, "g_k must be in [0, DI2P_MAX_GK]");
+        DI2P_CHECK_ARG(!e.g_table[t] || (e.g_idx[t] && e.g_k[t] >= 1 && e.g_nodes[t] >= 1), "gathered table without index / k / nodes");
+    }
+    ChainTail tl{W1t, scale1, shift1, W2t, scale2, shift2, relu1, relu2};
+    const float* X = srcs[0].ptr;
+    const long long x_bs = srcs[0].batch_stride;
+    const int x_rs = (int)srcs[0].row_stride;
+    hipStream_t st = (hipStream_t)stream;
+    // Grid: whole workgroups per compute unit (w = waves per SIMD the kernel's registers allow) and as few, equal trips per wave as possible
+    const int cus = di2p_cu_count();
+#define DI2P_CHAIN_LAUNCH(MM, KS0, NL, TN, WMAX)                                                                                    \
+    do {                                                                                                                            \
+        const int nblk = di2p_cdiv(N, 32 * (TN));                                                                                   \
+        const long long total = (long long)B * nblk;                                                                                \
+        DI2P_CHECK_ARG(total < (1ll << 30), "too many column blocks");                                                              \
+        int best_w = 1;                                                                                                             \
+        long long best_trips = 1ll << 62;                                                                                           \
+        for (int w = (WMAX); w >= 1; --w) {                                                                                         \
+            const long long trips = (total + 4ll * cus * w - 1) / (4ll * cus * w);                                                  \
+            if (trips < best_trips) { best_trips = trips; best_w = w; }                                                             \
+        }                                                                                                                           \
+        const int wgs = (int)std::min<long long>((long long)cus * best_w, (total + 3) / 4);                                         \
+        const size_t lds = (size_t)(2 * (KS0) * (MM) + ((NL) - 1) * (MM) * (MM) + 6 * (MM)) * sizeof(float);                        \
+        hipLaunchKernelGGL((point_chain_kernel<MM, KS0, NL, TN>), dim3(wgs), dim3(256), lds, st, X, x_bs, x_rs, W0t, K0, e, tl, Y, N, \
+                           nblk, (int)total);                                                                                       \
+    } while (0)
+    const bool three = W2t != nullptr;
+    if (M == 32) {
+        if (K0 <= 8) { if (three) DI2P_CHAIN_LAUNCH(32, 4, 3, DI2P_CHAIN_TN32, DI2P_CHAIN_W32); else DI2P_CHAIN_LAUNCH(32, 4, 2, DI2P_CHAIN_TN32, DI2P_CHAIN_W32); }
+        else           { if (three) DI2P_CHAIN_LAUNCH(32, 16, 3, DI2P_CHAIN_TN32, DI2P_CHAIN_W32); else DI2P_CHAIN_LAUNCH(32, 16, 2, DI2P_CHAIN_TN32, DI2P_CHAIN_W32); }
+    } else {
+        if (K0 <= 32) { if (three) DI2P_CHAIN_LAUNCH(64, 16, 3, DI2P_CHAIN_TN64, DI2P_CHAIN_W64); else DI2P_CHAIN_LAUNCH(64, 16, 2, DI2P_CHAIN_TN64, DI2P_CHAIN_W64); }
+        else           { if (three) DI2P_CHAIN_LAUNCH(64, 32, 3, DI2P_CHAIN_TN64, DI2P_CHAIN_W64); else DI2P_CHAIN_LAUNCH(64, 32, 2, DI2P_CHAIN_TN64, DI2P_CHAIN_W64); }
+    }
+#undef DI2P_CHAIN_LAUNCH
     DI2P_RETURN_LAUNCH();
 }
 

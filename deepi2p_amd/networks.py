@@ -182,9 +182,25 @@ def _run_split_layer(dense_srcs, dense_rows, node_feats, node_rows, idx, layer, 
 
 def _run_pn(x, layers, **kw):
     N = x.shape[2]
+    if not kw and ops.point_chain_ok([Src(x)], layers, N):       # narrow chains of one width: one launch, hidden activations in LDS
+        return ops.point_chain([Src(x)], layers, N)
     for layer in layers:
         x = _run_layer([Src(x)], layer, N, **kw)
     return x
+
+
+def _run_split_pn(dense_srcs, dense_rows, node_feats, node_rows, idx, layers, N):
+    """_run_split_layer for layers[0] followed by the rest of the chain -- in one launch when the chain is narrow."""
+    Wt, scale, shift, act = layers[0]
+    M = Wt.shape[1]
+    B = node_feats.shape[0]
+    head = (Wt[dense_rows[0]:dense_rows[1]], scale, shift, act)
+    chain = [head] + list(layers[1:])
+    if ops.point_chain_ok(dense_srcs, chain, N):
+        G = ops.pointwise_gemm([Src(node_feats)], Wt[node_rows[0]:node_rows[1]], M, node_feats.shape[2], transpose_out=True)
+        return ops.point_chain(dense_srcs, chain, N, gathered=[(G, idx.reshape(B, N, 1), None)])
+    x = _run_split_layer(dense_srcs, dense_rows, node_feats, node_rows, idx, layers[0], N)
+    return _run_pn(x, layers[1:])
 
 
 # ------------------------------------------------------------------ point-cloud encoder
@@ -231,8 +247,7 @@ class PCEncoder(_PackedModule):
         first = _run_pn(aug, p["first"])
         _, first_max = ops.index_max(first, min_idx, Ma, return_values=True, mask=mask)
         Ch = first.shape[1]
-        second = _run_split_layer([Src(first)], (0, Ch), first_max, (Ch, 2 * Ch), min_idx, p["second"][0], N)   # cat(first, first_max[min_idx])
-        second = _run_pn(second, p["second"][1:])
+        second = _run_split_pn([Src(first)], (0, Ch), first_max, (Ch, 2 * Ch), min_idx, p["second"], N)   # cat(first, first_max[min_idx])
         _, node_a_features = ops.index_max(second, min_idx, Ma, return_values=True, mask=mask)
         # GeneralKNNFusionModule (layers_pc.py:779-818)
         K = self.opt.k_ab

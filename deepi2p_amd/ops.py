@@ -277,6 +277,40 @@ def point_head(srcs, layer0, layer1, layer2, N, batch_bias=None, gathered=None):
     return out
 
 
+def point_chain_ok(srcs, layers, N):
+    """Can di2p_point_chain run these layers ((Wt, scale, shift, relu) tuples; layers[0].Wt holds the rows of the dense `srcs`)?"""
+    if len(layers) not in (2, 3) or len(srcs) != 1 or _lib.get_option("pw_nochain"):
+        return False
+    M = layers[0][0].shape[1]
+    if M not in (32, 64) or layers[0][0].shape[0] > M or any(tuple(l[0].shape) != (M, M) for l in layers[1:]):
+        return False
+    if any(l[0].requires_grad or not l[0].is_contiguous() for l in layers):
+        return False
+    return srcs[0].mode == _lib.SRC_DENSE and srcs[0].t.stride(2) == 1
+
+
+def point_chain(srcs, layers, N, batch_bias=None, gathered=None):
+    """Fused narrow PointNet chain (di2p_point_chain): two or three (Wt[K,M], scale, shift, relu) layers of one width
+    M in {32, 64}; layers[0]'s Wt holds only the rows of the dense `srcs`.  -> f32[B, M, N], bit-identical to the
+    separate pointwise_gemm calls."""
+    Wt0, sc0, sh0, act0 = layers[0]
+    Wt1, sc1, sh1, act1 = layers[1]
+    Wt2, sc2, sh2, act2 = layers[2] if len(layers) == 3 else (None, None, None, False)
+    B = srcs[0].t.shape[0]
+    M = Wt0.shape[1]
+    require_cuda(Wt0, Wt1, Wt2, sc0, sh0, sc1, sh1, sc2, sh2, batch_bias)
+    e = EpilogueT()
+    e.scale, e.shift, e.batch_bias = ptr(sc0), ptr(sh0), ptr(batch_bias)
+    e.relu, e.group_max, e.transpose_out = int(bool(act0)), 1, 0
+    _fill_gathered(e, gathered, B, M, N)
+    out = torch.empty((B, M, N), dtype=_f32, device=Wt0.device)
+    if _lib.WORK is not None:
+        _lib.WORK["di2p_point_chain"] = _lib.WORK.get("di2p_point_chain", 0) + B * N * (Wt0.shape[0] * M + (len(layers) - 1) * M * M)
+    call("di2p_point_chain", _fill_srcs(srcs), len(srcs), ptr(Wt0), Wt0.shape[0], ctypes.byref(e), ptr(Wt1), ptr(sc1), ptr(sh1),
+         int(bool(act1)), ptr(Wt2), ptr(sc2), ptr(sh2), int(bool(act2)), ptr(out), B, M, N, stream())
+    return out
+
+
 def batch_gemv(Wt, k0, v):
     """out[b,m] = sum_k Wt[k0+k, m] v[b,k]."""
     require_cuda(Wt, v)

@@ -156,6 +156,15 @@ int di2p_point_head(const di2p_src_t* srcs_host, int n_src, const float* W0t, in
                     const float* W2t, const float* scale2, const float* shift2, int relu2,
                     float* out, int B, int M, int P, int N, void* stream);
 
+/* Fused narrow PointNet chain (first_pointnet / second_pointnet of PCEncoder, networks_pc.py:36-43,60-75): two or three pointwise
+ * layers of one width M (32 or 64) in one launch, Y = L2(L1(L0(src))) or L1(L0(src)) when W2t == NULL, with
+ *   L0: ONE dense source of K0 <= M channels -> M, epilogue epi0 (scale/shift/relu, batch_bias, gathered node tables);
+ *   L1, L2: M -> M (W1t / W2t f32[M,M] k-major, scale/shift may be NULL).  Y f32[B,M,N].
+ * Bit-identical to the separate di2p_pointwise_gemm calls (up to the sign of zero); the hidden activations stay in registers. */
+int di2p_point_chain(const di2p_src_t* srcs_host, int n_src, const float* W0t, int K0, const di2p_epilogue_t* epi0_host,
+                     const float* W1t, const float* scale1, const float* shift1, int relu1, const float* W2t,
+                     const float* scale2, const float* shift2, int relu2, float* Y, int B, int M, int N, void* stream);
+
 int di2p_batch_gemv(const float* Wt, int M, int k0, const float* v, int Kv, float* out, int B, void* stream);
 /* Two broadcast inputs in one launch: Y[b,m] = (sum_k Wt[k0+k,m] v0[b,k]) + (sum_k Wt[k1+k,m] v1[b,k]), each sum formed
  * exactly as di2p_batch_gemv forms it (node_b_pn: global PC feature + global image feature, networks_united.py:152-155). */

@@ -141,6 +141,58 @@ def test_fused_point_head_is_bit_identical(dev, N):
     assert torch.equal(fused, chain)
 
 
+@pytest.mark.parametrize("N", [2048, 1000])
+def test_fused_pointnet_chains_are_bit_identical(dev, N):
+    """first_pointnet (7 -> 32 -> 32 -> 32) and second_pointnet ((32 + gathered 32) -> 64 -> 64) as ONE launch each
+    (di2p_point_chain: hidden activations in LDS) against the separate pointwise launches (knob pw_nochain): every output of
+    the point encoder bit for bit; N = 1000 leaves a ragged last tile."""
+    from deepi2p_amd import synthetic, _lib
+    H, W = 64, 128
+    det, opt = _detector(dev, N, H, W, False)
+    batch = synthetic.make_batch(6, 2, N=N, H=H, W=W)
+    x = [torch.from_numpy(batch[k]).to(dev) for k in ("pc", "intensity", "sn", "node_a", "node_b")]
+    _lib.WORK = {}
+    try:
+        fused = det.pc_encoder(*x)
+        assert "di2p_point_chain" in _lib.WORK
+        _lib.WORK = {}
+        with _lib.option("pw_nochain", 1):
+            chain = det.pc_encoder(*x)
+        assert "di2p_point_chain" not in _lib.WORK
+    finally:
+        _lib.WORK = None
+    assert len(fused) == len(chain) == 8
+    for a, b in zip(fused, chain):
+        assert a.shape == b.shape and torch.equal(a, b)
+
+
+def test_point_chain_argument_checks(dev):
+    """di2p_point_chain directly: 3- and 2-layer chains of widths 32 and 64 at K0 = 8 / 7 / 32 / 40, N a multiple of 64, of 4 and of neither,
+    bit-identical to the separate launches; unsupported shapes are refused (the host layer falls back to the separate layers)."""
+    from deepi2p_amd import ops
+    from deepi2p_amd._lib import DeepI2PHipError
+    g = torch.Generator(device="cpu").manual_seed(1)
+    mk = lambda k, m: (torch.randn(k, m, generator=g).to(dev), torch.rand(m, generator=g).to(dev) + 0.5, torch.randn(m, generator=g).to(dev), True)
+    for M, K0, N in ((32, 8, 256), (32, 7, 250), (32, 32, 1000), (64, 32, 256), (64, 40, 330), (64, 7, 64)):
+        x = torch.randn(3, K0, N, generator=g).to(dev)
+        layers = [mk(K0, M), mk(M, M), (mk(M, M)[0], None, mk(M, M)[2], False)]
+        for nl in (3, 2):
+            assert ops.point_chain_ok([ops.Src(x)], layers[:nl], N)
+            y = ops.point_chain([ops.Src(x)], layers[:nl], N)
+            ref = x
+            for l in layers[:nl]:
+                ref = ops.pointwise_gemm([ops.Src(ref)], l[0], M, N, scale=l[1], shift=l[2], relu=l[3])
+            assert torch.equal(y, ref), (M, K0, N, nl)
+    x = torch.randn(2, 8, 256, generator=g).to(dev)
+    layers = [mk(8, 32), mk(32, 32), mk(32, 32)]
+    assert not ops.point_chain_ok([ops.Src(x)], [mk(8, 48), mk(48, 48)], 256)        # width not 32 / 64
+    assert not ops.point_chain_ok([ops.Src(x)], [mk(8, 32), mk(32, 64)], 256)        # widths differ
+    assert not ops.point_chain_ok([ops.Src(x), ops.Src(x)], layers, 256)             # two sources
+    assert not ops.point_chain_ok([ops.Src(torch.randn(2, 40, 256, generator=g).to(dev))], [mk(40, 32), mk(32, 32)], 256)   # K0 > M
+    with pytest.raises(DeepI2PHipError):
+        ops.point_chain([ops.Src(x)], [mk(8, 48), mk(48, 48)], 256)
+
+
 def test_forward_and_pose_are_run_to_run_identical(dev):
     """No result depends on the order in which atomics or workgroups retire: segment maxima merge through order-free
     u64 max, cluster sums are fixed-point integers, split-K partials and the solver's wave partials are combined in a fixed
