@@ -160,8 +160,58 @@ struct EpiPointwiseT {
     int b, M, N;
     float* lds_tile = nullptr;   // fused chains: write the tile to LDS as the next layer's [k = m][n - lds_n0] operand panel
     int lds_n0 = 0, lds_ld = 0;
+    // compile-time gathered tables: the neighbours of ONE column (row pointers at channel 0, weights), and their weighted sum on 16 rows
+    static constexpr int NG = (GK0 > 0 ? GK0 : 0) + (GK1 > 0 ? GK1 : 0);
+    struct Gathered {
+        const float* gp[NG > 0 ? NG : 1];
+        float gw[NG > 0 ? NG : 1];
+    };
+    __device__ __forceinline__ void gather_setup(int nc, Gathered& G) const {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int gk = t == 0 ? GK0 : GK1;
+            if (gk <= 0) continue;
+            const long long col = ((long long)b * N + nc) * gk;
+            const float* gt = e.g_table[t] + (long long)b * e.g_nodes[t] * M;
+#pragma unroll
+            for (int j = 0; j < gk; ++j) {
+                const int s = (t == 0 ? 0 : GK0) + j;
+                G.gp[s] = gt + (long long)e.g_idx[t][col + j] * M;
+                G.gw[s] = e.g_w[t] ? e.g_w[t][col + j] : 1.0f;
+            }
+        }
+    }
+    // One row group (4 rows from mrow) of every neighbour: request, and later reduce to t4 = sum_s gw[s] * G_s[mrow + {0..3}] -- an fma
+    // chain from zero, tables in order, neighbours in order (the run-time path's chain).
+    __device__ __forceinline__ void gather_issue(const Gathered& G, int mrow, float4 (&q)[NG > 0 ? NG : 1]) const {
+#pragma unroll
+        for (int s = 0; s < NG; ++s) q[s] = *reinterpret_cast<const float4*>(G.gp[s] + mrow);
+    }
+    __device__ __forceinline__ float4 gather_reduce(const Gathered& G, const float4 (&q)[NG > 0 ? NG : 1]) const {
+        float4 t4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int s = 0; s < NG; ++s) {
+            t4.x = fmaf(G.gw[s], q[s].x, t4.x); t4.y = fmaf(G.gw[s], q[s].y, t4.y);
+            t4.z = fmaf(G.gw[s], q[s].z, t4.z); t4.w = fmaf(G.gw[s], q[s].w, t4.w);
+        }
+        return t4;
+    }
+    // t16 = the gathered sum on the 16 rows mrow0 + 8g + {0..3}
+    __device__ __forceinline__ void gather_sum(const Gathered& G, int mrow0, float (&t16)[16]) const {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 q[NG > 0 ? NG : 1];
+            gather_issue(G, mrow0 + 8 * g, q);
+            const float4 t4 = gather_reduce(G, q);
+            t16[4 * g + 0] = t4.x; t16[4 * g + 1] = t4.y; t16[4 * g + 2] = t4.z; t16[4 * g + 3] = t4.w;
+        }
+    }
     // the epilogue arithmetic proper (bias, gathered add, scale, shift, relu) on the 16 rows mrow0 + 8g + {0..3} of column nc (< N)
     __device__ __forceinline__ void apply(int mrow0, int nc, const f32x16& acc, float (&v)[16]) const {
+        apply_pre(mrow0, nc, acc, nullptr, v);
+    }
+    // pre != nullptr (compile-time tables only): the gathered sum of these rows, already computed by gather_sum
+    __device__ __forceinline__ void apply_pre(int mrow0, int nc, const f32x16& acc, const float* pre, float (&v)[16]) const {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = acc[r];
         if (e.batch_bias) {
@@ -175,33 +225,38 @@ struct EpiPointwiseT {
             // them between the accumulation registers and the vector registers around every neighbour (32 moves per 16 fused multiply-adds)
             // and re-derived every 64-bit row address: ~1300 instructions per tile where ~200 do the work -- the fused head ran 12 vector
             // instructions per matrix instruction.  Row offsets are constants here (M % 32 == 0: every row group lies inside M).
-            constexpr int NG = GK0 + GK1;
-            const float* gp[NG > 0 ? NG : 1];
-            float gw[NG > 0 ? NG : 1];
+            if (pre) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int gk = t == 0 ? GK0 : GK1;
-                if (gk == 0) continue;
-                const long long col = ((long long)b * N + nc) * gk;
-                const float* gt = e.g_table[t] + (long long)b * e.g_nodes[t] * M + mrow0;
+                for (int r = 0; r < 16; ++r) v[r] += pre[r];
+            } else {
+                constexpr int NG = GK0 + GK1;
+                const float* gp[NG > 0 ? NG : 1];
+                float gw[NG > 0 ? NG : 1];
 #pragma unroll
-                for (int j = 0; j < gk; ++j) {
-                    const int s = (t == 0 ? 0 : GK0) + j;
-                    gp[s] = gt + (long long)e.g_idx[t][col + j] * M;
-                    gw[s] = e.g_w[t] ? e.g_w[t][col + j] : 1.0f;
+                for (int t = 0; t < 2; ++t) {
+                    const int gk = t == 0 ? GK0 : GK1;
+                    if (gk == 0) continue;
+                    const long long col = ((long long)b * N + nc) * gk;
+                    const float* gt = e.g_table[t] + (long long)b * e.g_nodes[t] * M + mrow0;
+#pragma unroll
+                    for (int j = 0; j < gk; ++j) {
+                        const int s = (t == 0 ? 0 : GK0) + j;
+                        gp[s] = gt + (long long)e.g_idx[t][col + j] * M;
+                        gw[s] = e.g_w[t] ? e.g_w[t][col + j] : 1.0f;
+                    }
                 }
-            }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 q[NG > 0 ? NG : 1];
+                for (int g = 0; g < 4; ++g) {
+                    float4 q[NG > 0 ? NG : 1];
 #pragma unroll
-                for (int s = 0; s < NG; ++s) q[s] = *reinterpret_cast<const float4*>(gp[s] + 8 * g);
-                float4 t4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);          // the same chain as the run-time path below: fma from zero, then one add
+                    for (int s = 0; s < NG; ++s) q[s] = *reinterpret_cast<const float4*>(gp[s] + 8 * g);
+                    float4 t4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);          // the same chain as the run-time path below: fma from zero, then one add
 #pragma unroll
-                for (int s = 0; s < NG; ++s) {
-                    t4.x = fmaf(gw[s], q[s].x, t4.x); t4.y = fmaf(gw[s], q[s].y, t4.y); t4.z = fmaf(gw[s], q[s].z, t4.z); t4.w = fmaf(gw[s], q[s].w, t4.w);
+                    for (int s = 0; s < NG; ++s) {
+                        t4.x = fmaf(gw[s], q[s].x, t4.x); t4.y = fmaf(gw[s], q[s].y, t4.y); t4.z = fmaf(gw[s], q[s].z, t4.z); t4.w = fmaf(gw[s], q[s].w, t4.w);
+                    }
+                    v[4 * g + 0] += t4.x; v[4 * g + 1] += t4.y; v[4 * g + 2] += t4.z; v[4 * g + 3] += t4.w;
                 }
-                v[4 * g + 0] += t4.x; v[4 * g + 1] += t4.y; v[4 * g + 2] += t4.z; v[4 * g + 3] += t4.w;
             }
         } else if (e.g_table[0] || e.g_table[1]) {
             float t16[16];
@@ -578,6 +633,154 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DI2P_CHAIN_
             to_memory(ep2);
         } else {
             to_memory(ep1);
+        }
+    }
+}
+
+// ---- the fused per-point head, wave-autonomous (the design of point_chain_kernel at width 128): a wave owns all 128 channels of 32 points
+// through layer 0 (dense channels from memory + gathered node products), layer 1 (its operand = layer 0's accumulators after one
+// v_permlane32_swap per register pair) and the P-channel output layer (an ordered 128-term fma chain that alternates between the two
+// half-waves holding a column's rows).  ALL weights (K0 <= 96: 48 + 64 + 2 KB) and scale / shift rows sit in LDS for the lifetime of a
+// workgroup (one 8-wave workgroup per compute unit, two waves per SIMD), the block list of all frames is walked with a common stride:
+// no operand staging, no activation tile in LDS, no barrier after the first.  Same K order, MFMA sequence and epilogue code as
+// point_head_kernel and the three separate launches: bit-identical to both.
+template <bool G33, int KS0>
+__global__ __launch_bounds__(512) void point_head_reg_kernel(SrcDev srcs, const float* __restrict__ W0t, int K0, EpiDev e0, HeadTail tl,
+                                                              float* __restrict__ out, int N, int nblk, int total) {
+    constexpr int M = HEAD_M, TM = M / 32, KS = M / 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* w0 = lds;                       // [2 * KS0][M], rows >= K0 zero
+    float* w1 = w0 + 2 * KS0 * M;          // [M][M]
+    float* w2 = w1 + M * M;                // [M][4]  (P <= 4 output channels, row stride 4)
+    float* ss = w2 + M * 4;                // scale0, shift0, scale1, shift1: [4][M]
+    for (int i = threadIdx.x; i < 2 * KS0 * M; i += 512) w0[i] = i < K0 * M ? W0t[i] : 0.0f;
+    for (int i = threadIdx.x; i < M * M; i += 512) w1[i] = tl.W1t[i];
+    for (int i = threadIdx.x; i < M * 4; i += 512) w2[i] = (i & 3) < tl.P ? tl.W2t[(i >> 2) * tl.P + (i & 3)] : 0.0f;
+    {
+        const float* rows[4] = {e0.scale, e0.shift, tl.sc1, tl.sh1};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (rows[q] && threadIdx.x < M) ss[q * M + threadIdx.x] = rows[q][threadIdx.x];
+    }
+    __syncthreads();
+    if (e0.scale) e0.scale = ss;
+    if (e0.shift) e0.shift = ss + M;
+    EpiDev e1{};
+    e1.scale = tl.sc1 ? ss + 2 * M : nullptr; e1.shift = tl.sh1 ? ss + 3 * M : nullptr; e1.relu = tl.relu1; e1.group_max = 1;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int c0 = srcs.c_end[0];
+
+    // layer 0's operand rows come straight from memory (rows >= K0: zero; their weights are zero too).  The rows of a wave's NEXT block are
+    // requested as soon as this block's layer 0 is done with the registers -- a whole layer 1 (256 matrix instructions) ahead of their use:
+    // behind another wave's burst of gather loads in the texture-path queue a request can wait many microseconds.
+    constexpr int CH = 8;
+    static_assert(KS0 % CH == 0, "layer 0 = whole chunks");
+    float f0[KS0];
+    // (buffer loads: the frame's base in a descriptor, the K-step's row offset in a scalar register, one per-lane byte offset per source --
+    //  with 64-bit per-lane addresses the 48 requests of a block cost 96 address registers and 400 B of scratch per lane.  c0 is even
+    //  (host-checked): both half-waves of a K-step read the same source; rows past a source's end read as zero.)
+    auto request = [&](int g) {
+        const int fb = __builtin_amdgcn_readfirstlane(g / nblk);
+        const int col = min((g - fb * nblk) * 32 + l31, N - 1);
+        const int rs0 = srcs.row_stride[0], rs1 = srcs.row_stride[1];
+        const auto r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(srcs.ptr[0] + (long long)fb * srcs.batch_stride[0]), 0, c0 * rs0 * 4, 0x00020000);
+        const auto r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(srcs.ptr[1] + (long long)fb * srcs.batch_stride[1]), 0, (K0 - c0) * rs1 * 4, 0x00020000);
+        const int v0 = (col + half * rs0) * 4, v1 = (col + half * rs1) * 4;
+#pragma unroll
+        for (int s = 0; s < KS0; ++s) {
+            if (2 * s < c0) f0[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r0, v0, 2 * s * rs0 * 4, 0));
+            else f0[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, v1, (2 * s - c0) * rs1 * 4, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const int g_first = blockIdx.x * 8 + wave, stride = gridDim.x * 8;
+    if (g_first < total) request(g_first);
+    for (int g = g_first; g < total; g += stride) {
+        const int b = g / nblk, blk = g - b * nblk;
+        const int n = blk * 32 + l31, nc = min(n, N - 1);
+        using Epi0 = EpiPointwiseT<G33 ? 3 : -1, G33 ? 3 : -1>;
+        Epi0 ep0{e0, nullptr, b, M, N};
+        typename Epi0::Gathered G;
+        if (G33) ep0.gather_setup(nc, G);
+        f32x16 acc[TM];
+        auto zero = [&]() {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+        };
+        // K-steps k0 .. k0 + STEPS - 1 of a layer on the operands fs[0 .. STEPS): one scheduling region with an explicit software pipeline, the
+        // weight-fragment reads of K-step s + 3 in front of the matrix instructions of K-step s (12 LDS reads in flight: the wait counter
+        // holds 15).  Left alone, hipcc hoists every read of a layer to its top (1.2 KB of scratch per lane).
+        auto steps = [&](const float* w, int k0, const float* fs, auto n_tag) {
+            constexpr int STEPS = decltype(n_tag)::value;
+            const float* wl = w + half * M + l31;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                float a[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = wl[2 * (k0 + s) * M + i * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], fs[s], acc[i], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 3 * TM, 0);
+#pragma unroll
+            for (int s = 0; s < STEPS - 3; ++s) {
+                __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * TM, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        zero();
+#pragma unroll
+        for (int s0 = 0; s0 < KS0; s0 += CH) steps(w0, s0, &f0[s0], std::integral_constant<int, CH>{});
+        float f1[KS];                       // layer 1's operands: layer 0's output, one register per K-step
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float v[16], t16[16];
+            if (G33) ep0.gather_sum(G, i * 32 + 4 * half, t16);
+            ep0.apply_pre(i * 32 + 4 * half, nc, acc[i], G33 ? t16 : nullptr, v);
+            chain_rows_to_ksteps(v, &f1[i * 16]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        request(min(g + stride, total - 1));
+        zero();
+        steps(w1, 0, f1, std::integral_constant<int, KS>{});
+        float h[TM][16];                    // layer 1's output: rows i * 32 + 8q + j + 4 * half of this lane's column (r = 4q + j)
+        {
+            EpiPointwise ep1{e1, nullptr, b, M, N};
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ep1.apply(i * 32 + 4 * half, nc, acc[i], h[i]);
+        }
+        // output layer: k ascending, the order of the MFMA accumulation.  Rows 8q' .. 8q' + 3 of a column live in lane l, rows 8q' + 4 .. + 7
+        // in lane l + 32: the running sum visits the low half-wave, is handed over (permlane32_swap of a register with itself broadcasts one
+        // half-wave's value to both), visits the high half-wave, and is handed back.
+        for (int p = 0; p < tl.P; ++p) {
+            const float* wp = w2 + 16 * half + p;
+            float a = 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float w[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = wp[(i * 32 + 8 * q + j) * 4];
+                    float t = a;            // low half-wave: rows 8q' + 0..3
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t = fmaf(w[j], h[i][4 * q + j], t);
+                    const float lo = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false)[0]);
+                    float u = lo;           // high half-wave: rows 8q' + 4..7
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) u = fmaf(w[j], h[i][4 * q + j], u);
+                    a = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(u), false, false)[1]);
+                }
+            if (tl.sc2) a *= tl.sc2[p];
+            if (tl.sh2) a += tl.sh2[p];
+            if (tl.relu2) a = fmaxf(a, 0.0f);
+            if (n < N && half == 0) out[((long long)b * tl.P + p) * N + n] = a;
         }
     }
 }
@@ -1034,6 +1237,26 @@ extern "C" int di2p_point_head(const di2p_src_t* srcs, int n_src, const float* W
         DI2P_CHECK_ARG(!e.g_table[t] || (e.g_idx[t] && e.g_k[t] >= 1 && e.g_nodes[t] >= 1), "gathered table without index / k / nodes");
     }
     HeadTail tl{W1t, scale1, shift1, W2t, scale2, shift2, relu1, relu2, P};
+    bool reg_ok = K0 <= 96 && n_src <= 2 && di2p_opt(DI2P_OPT_HEAD_REG) != 0;
+    if (n_src == 2) reg_ok = reg_ok && srcs[0].channels % 2 == 0;            // both half-waves of a K-step read the same source
+    for (int i = 0; i < n_src; ++i) reg_ok = reg_ok && (long long)srcs[i].channels * srcs[i].row_stride * 4 < (1ll << 31);   // buffer-descriptor range
+    if (reg_ok) {
+        // wave-autonomous kernel: one 8-wave workgroup per compute unit (118 KB of weights in LDS), equal trips per wave where the sizes allow
+        constexpr int KS0 = 48;
+        const int nblk = di2p_cdiv(N, 32);
+        const long long total = (long long)B * nblk;
+        DI2P_CHECK_ARG(total < (1ll << 30), "too many column blocks");
+        const int wgs = (int)std::min<long long>(di2p_cu_count(), (total + 7) / 8);
+        const size_t lds_reg = (size_t)(2 * KS0 * HEAD_M + HEAD_M * HEAD_M + HEAD_M * 4 + 4 * HEAD_M) * sizeof(float);
+        if (e.g_table[0] && e.g_table[1] && e.g_k[0] == 3 && e.g_k[1] == 3) {
+            (void)hipFuncSetAttribute((const void*)point_head_reg_kernel<true, KS0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
+            hipLaunchKernelGGL((point_head_reg_kernel<true, KS0>), dim3(wgs), dim3(512), lds_reg, (hipStream_t)stream, s, W0t, K0, e, tl, out, N, nblk, (int)total);
+        } else {
+            (void)hipFuncSetAttribute((const void*)point_head_reg_kernel<false, KS0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
+            hipLaunchKernelGGL((point_head_reg_kernel<false, KS0>), dim3(wgs), dim3(512), lds_reg, (hipStream_t)stream, s, W0t, K0, e, tl, out, N, nblk, (int)total);
+        }
+        DI2P_RETURN_LAUNCH();
+    }
     const size_t lds = (HeadCfg::LDS_FLOATS + HEAD_M * HEAD_BN) * sizeof(float);
     // > 64 KB of dynamic LDS needs the opt-in (per device; the call is cheap, so it is simply made every time)
     if (e.g_table[0] && e.g_table[1] && e.g_k[0] == 3 && e.g_k[1] == 3) {      // the reference's configuration (k_interp_point_a = k_interp_point_b = 3)

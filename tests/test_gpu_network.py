@@ -139,6 +139,10 @@ def test_fused_point_head_is_bit_identical(dev, N):
         del det.fuse_head
     assert fused.shape == chain.shape == (2, 2, N)
     assert torch.equal(fused, chain)
+    from deepi2p_amd import _lib
+    with _lib.option("head_reg", 1):         # the wave-autonomous kernel (activations in registers; the LDS-tile kernel is the default)
+        reg = det(*x)
+    assert torch.equal(fused, reg)
 
 
 @pytest.mark.parametrize("N", [2048, 1000])

@@ -22,3 +22,12 @@ print("fused head with gathered add : %.0f us" % t(lambda: ops.point_head(S, l0,
 print("fused head without gathers   : %.0f us" % t(lambda: ops.point_head(S, l0, l1, l2, N)))
 print("layer 0 alone with gathers   : %.0f us" % t(lambda: ops.pointwise_gemm(S, W0, 128, N, scale=sc, shift=sh, relu=True, gathered=[(Ga, ia, wa), (Gb, ib, wb)])))
 print("layer 0 alone without gathers: %.0f us" % t(lambda: ops.pointwise_gemm(S, W0, 128, N, scale=sc, shift=sh, relu=True)))
+from deepi2p_amd import _lib
+new = ops.point_head(S, l0, l1, l2, N, gathered=[(Ga, ia, wa), (Gb, ib, wb)])
+new_ng = ops.point_head(S, l0, l1, l2, N)
+with _lib.option("head_reg", 1):
+    print("wave-autonomous head with gathered add : %.0f us" % t(lambda: ops.point_head(S, l0, l1, l2, N, gathered=[(Ga, ia, wa), (Gb, ib, wb)])))
+    print("wave-autonomous head without gathers   : %.0f us" % t(lambda: ops.point_head(S, l0, l1, l2, N)))
+    old = ops.point_head(S, l0, l1, l2, N, gathered=[(Ga, ia, wa), (Gb, ib, wb)])
+    old_ng = ops.point_head(S, l0, l1, l2, N)
+print("bit-identical:", torch.equal(new, old), torch.equal(new_ng, old_ng), float((new - old).abs().max()))
