@@ -177,7 +177,7 @@ def test_point_chain_argument_checks(dev):
     from deepi2p_amd._lib import DeepI2PHipError
     g = torch.Generator(device="cpu").manual_seed(1)
     mk = lambda k, m: (torch.randn(k, m, generator=g).to(dev), torch.rand(m, generator=g).to(dev) + 0.5, torch.randn(m, generator=g).to(dev), True)
-    for M, K0, N in ((32, 8, 256), (32, 7, 250), (32, 32, 1000), (64, 32, 256), (64, 40, 330), (64, 7, 64)):
+    for M, K0, N in ((32, 8, 256), (32, 7, 250), (32, 32, 1000), (64, 32, 256), (64, 40, 330), (64, 7, 64), (32, 7, 1), (64, 33, 31)):
         x = torch.randn(3, K0, N, generator=g).to(dev)
         layers = [mk(K0, M), mk(M, M), (mk(M, M)[0], None, mk(M, M)[2], False)]
         for nl in (3, 2):
@@ -189,6 +189,7 @@ def test_point_chain_argument_checks(dev):
             assert torch.equal(y, ref), (M, K0, N, nl)
     x = torch.randn(2, 8, 256, generator=g).to(dev)
     layers = [mk(8, 32), mk(32, 32), mk(32, 32)]
+    assert ops.point_chain([ops.Src(x[:0])], layers, 256).shape == (0, 32, 256)       # empty batch
     assert not ops.point_chain_ok([ops.Src(x)], [mk(8, 48), mk(48, 48)], 256)        # width not 32 / 64
     assert not ops.point_chain_ok([ops.Src(x)], [mk(8, 32), mk(32, 64)], 256)        # widths differ
     assert not ops.point_chain_ok([ops.Src(x), ops.Src(x)], layers, 256)             # two sources
