@@ -59,6 +59,7 @@ enum Di2pOption {
     DI2P_OPT_PW_X3,                 // 1 (default): the host layer runs the GEMM-shaped pointwise layers (K >= 128, M % 128 == 0) on the bf16x3 kernel (read by ops.py)
     DI2P_OPT_PW_NOCHAIN,            // 1: the host layer runs the narrow PointNet chains as separate launches instead of di2p_point_chain (bit-identical; read by ops.py)
     DI2P_OPT_HEAD_REG,              // 1: di2p_point_head runs the wave-autonomous kernel (one persistent 8-wave workgroup per compute unit: faster alone, slower beside other streams' kernels) instead of the LDS-tile kernel (bit-identical)
+    DI2P_OPT_CONV_S2SCALAR,         // 1: stride-2 convolutions stage their operand with four dword loads per row (rounds 1-3) instead of aligned 8-float windows (bit-identical)
     DI2P_OPT_COUNT
 };
 long long di2p_opt(int id);

@@ -183,6 +183,80 @@ struct LoaderIm2colTap4 {
     }
 };
 
+// Stride 2, WINDOW form (round 4).  The four output pixels ow .. ow + 3 (ow % 4 == 0) of a lane read the input columns 2 ow - pad + kw + {0, 2, 4, 6}:
+// with W == 2 OW and (pad, KW) = (1, 3) or (0, 1) they lie in the 8-float window [2 ow, 2 ow + 8) of the input row plus, for the leftmost tap of a
+// padded 3x3, the one element to its left.  Two aligned 16-byte loads and one dword per staged row -- whole cache lines across the wave -- instead of
+// four dword loads with a 32-byte lane pitch (half of every line fetched and dropped, twice the address work in the texture path); finish() picks the
+// four values by the tap's offset o = kw - pad in {-1, 0, +1}.  Same values into LDS as LoaderIm2colTap4<2>: results are bit-identical.
+struct LoaderIm2colTap4W2 {
+    struct Raw { float4 a, b, c; };          // c.x: the element left of the window (three float4s: no padding bytes for the register promotion to trip over)
+    const float* x;
+    int Cin, H, W, OH, OW, KH, KW, pad, Ntot;
+    const float* xb;
+    const float* tile_ptr;   // channel ci0 of the (clamped) input row, at column 2 ow
+    int ih0, iw0, HW;
+    int ci0, kh, kw, bk;
+    int eoff;                // -1: the element left of the window exists, 0: the window starts at column 0
+    int off;                 // kw - pad
+    unsigned okmask;
+    int pending_seek = 0;
+    __device__ __forceinline__ void column4(int j) {
+        const int jj = j < Ntot ? j : 0;
+        const int opix = OH * OW;
+        const int b = jj / opix, pix = jj - b * opix;
+        const int oh = pix / OW, ow = pix - oh * OW;
+        HW = H * W;
+        xb = x + (long long)b * Cin * HW;
+        ih0 = oh * 2 - pad;
+        iw0 = ow * 2;
+        eoff = iw0 > 0 ? -1 : 0;
+        ci0 = -bk; kh = 0; kw = 0;
+        if (pending_seek > 0) seek(pending_seek);
+        tile_ptr = xb + iw0; off = 0; okmask = 0;
+    }
+    __device__ __forceinline__ void seek(int t0) {
+        const int k0 = t0 * bk, tap = k0 / Cin;
+        ci0 = k0 - tap * Cin - bk;
+        kh = tap / KW; kw = tap - kh * KW;
+    }
+    __device__ __forceinline__ void begin_tile(int) {
+        ci0 += bk;
+        if (ci0 >= Cin) { ci0 = 0; if (++kw == KW) { kw = 0; ++kh; } }
+        const int ih = ih0 + kh;
+        const bool row_ok = (unsigned)ih < (unsigned)H;
+        const int ihc = min(max(ih, 0), H - 1);
+        tile_ptr = xb + (ci0 * H + ihc) * W + iw0;
+        off = kw - pad;
+        okmask = !row_ok ? 0u : ((off < 0 && iw0 == 0) ? 0xeu : 0xfu);
+    }
+    __device__ __forceinline__ Raw load4(int k) const {
+        const float* r = tile_ptr + (k & (bk - 1)) * HW;
+        Raw q;
+        q.a = *reinterpret_cast<const float4*>(r);
+        q.b = *reinterpret_cast<const float4*>(r + 4);
+        q.c = make_float4(r[eoff], 0.0f, 0.0f, 0.0f);
+        return q;
+    }
+    struct Info { int off; unsigned okmask; };
+    __device__ __forceinline__ Info info() const { return Info{off, okmask}; }
+    __device__ __forceinline__ float4 pick(const Raw& q, int o, unsigned ok) const {
+        // The nine staged values as opaque REGISTER values before the selects: hipcc otherwise rewrites "select of two fields" as "load from a
+        // selected address", which keeps the staged rows in scratch instead of registers (560 B per lane, the kernel twice as slow).
+        float e = q.c.x, a0 = q.a.x, a1 = q.a.y, a2 = q.a.z, a3 = q.a.w, b0 = q.b.x, b1 = q.b.y, b2 = q.b.z, b3 = q.b.w;
+        asm volatile("" : "+v"(e), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+        float4 v;
+        v.x = o < 0 ? e : (o > 0 ? a1 : a0);
+        v.y = o < 0 ? a1 : (o > 0 ? a3 : a2);
+        v.z = o < 0 ? a3 : (o > 0 ? b1 : b0);
+        v.w = o < 0 ? b1 : (o > 0 ? b3 : b2);
+        v.x = (ok & 1u) ? v.x : 0.0f; v.y = (ok & 2u) ? v.y : 0.0f;
+        v.z = (ok & 4u) ? v.z : 0.0f; v.w = (ok & 8u) ? v.w : 0.0f;
+        return v;
+    }
+    __device__ __forceinline__ float4 finish(const Raw& q, int, const Info& in) const { return pick(q, in.off, in.okmask); }
+    __device__ __forceinline__ float4 finish(const Raw& q, int) const { return pick(q, off, okmask); }
+};
+
 // Vector stager for weights in their own (ci,kh,kw) order -- the 7x7/2 stem (Cin = 3: no tap holds a whole K-step).  Each
 // staged row decodes its own (ci,kh,kw) (divisions by compile-time constants), loads 4 output pixels of one output row as
 // four clamped scalars (unconditional), and remembers the in-image mask of the pass for fix().
@@ -353,7 +427,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv2d_vec_kernel(const float* _
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int K = Cin * KH * KW;
     LoaderWt4 la{Wt, K, Cout};
-    LoaderIm2colTap4<STRIDE> lb;
+    std::conditional_t<STRIDE == 22, LoaderIm2colTap4W2, LoaderIm2colTap4<STRIDE == 22 ? 2 : STRIDE>> lb;      // 22: stride 2, window loads
     lb.x = x; lb.Cin = Cin; lb.H = H; lb.W = W; lb.OH = OH; lb.OW = OW; lb.KH = KH; lb.KW = KW;
     lb.pad = pad; lb.Ntot = Ntot; lb.bk = Cfg::BK;
     int tx, ty;
@@ -399,7 +473,11 @@ void launch_conv_vec(const float* x, const float* Wt, const float* scale, const 
     // the depth-1 engine (tests compare the two)
     const bool depth1 = di2p_opt(DI2P_OPT_CONV_DEPTH1) != 0;
 #define DI2P_CONV_VEC_LAUNCH(S, D) hipLaunchKernelGGL((conv2d_vec_kernel<Cfg, S, D>), grid, block, lds, st, x, Wt, scale, shift, residual, y, Cin, H, W, Cout, OH, OW, KH, KW, pad, Ntot, relu, part, splits)
+    // stride 2: aligned 8-float windows where the shape allows (W == 2 OW, whole 8-column groups, padded 3x3 or plain 1x1); conv_s2scalar = 1: never
+    const bool window = stride == 2 && W == 2 * OW && W % 8 == 0 && ((pad == 1 && KW == 3) || (pad == 0 && KW == 1)) &&
+                        ((uintptr_t)x & 15) == 0 && !di2p_opt(DI2P_OPT_CONV_S2SCALAR);
     if (stride == 1) { if (depth1) DI2P_CONV_VEC_LAUNCH(1, 1); else DI2P_CONV_VEC_LAUNCH(1, 2); }
+    else if (window) { if (depth1) DI2P_CONV_VEC_LAUNCH(22, 1); else DI2P_CONV_VEC_LAUNCH(22, 2); }
     else { if (depth1) DI2P_CONV_VEC_LAUNCH(2, 1); else DI2P_CONV_VEC_LAUNCH(2, 2); }
 #undef DI2P_CONV_VEC_LAUNCH
     if (splits > 1) {

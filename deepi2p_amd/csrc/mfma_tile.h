@@ -13,6 +13,7 @@
 //   * accumulators: TM x TN tiles of 16 VGPRs per wave; C/D layout col = lane&31,
 //     row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 // Priority of a wave while it issues an MFMA cluster.  Two waves of a SIMD that contend for the matrix pipe at equal priority drift into
@@ -151,6 +152,23 @@ struct LoaderWt4 {
     }
 };
 
+// What a B loader keeps in registers per staged row between the request and the LDS store: a float4 that fix() patches in place (the
+// default), or its own `Raw` type (more loads per row than the four values that go to LDS: the stride-2 window loader of conv.hip) that
+// finish() turns into the float4.
+template <class L, class = void>
+struct StagedOf { using type = float4; };
+template <class L>
+struct StagedOf<L, std::void_t<typename L::Raw>> { using type = typename L::Raw; };
+template <class L, class... Extra>
+__device__ __forceinline__ float4 staged_finish(L& lb, float4& v, int pass, const Extra&... extra) {
+    lb.fix(v, pass, extra...);
+    return v;
+}
+template <class L, class R, class... Extra>
+__device__ __forceinline__ float4 staged_finish(L& lb, R& raw, int pass, const Extra&... extra) {
+    return lb.finish(raw, pass, extra...);
+}
+
 template <class Cfg, class LoaderA, class LoaderB, class Epi>
 __device__ __forceinline__ void mfma_gemm_block_vec(float* lds, LoaderA& la, LoaderB& lb, Epi& epi, int K, int m_blk, int j_blk,
                                                     int t_begin = 0, int t_end = -1) {   // K-steps [t_begin, t_end) (split-K); default: all
@@ -180,7 +198,8 @@ __device__ __forceinline__ void mfma_gemm_block_vec(float* lds, LoaderA& la, Loa
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    float4 ra[A_PASSES], rb[B_PASSES];
+    float4 ra[A_PASSES];
+    typename StagedOf<LoaderB>::type rb[B_PASSES];
     const int T = (t_end < 0 ? (K + BK - 1) / BK : t_end) - t_begin;      // number of K-steps of this block (>= 1)
     int k_loaded = 0;
     auto gload = [&](int t) {
@@ -200,8 +219,8 @@ __device__ __forceinline__ void mfma_gemm_block_vec(float* lds, LoaderA& la, Loa
         }
 #pragma unroll
         for (int p = 0; p < B_PASSES; ++p) {
-            lb.fix(rb[p], p);
-            if (b_on) *reinterpret_cast<float4*>(&Bs[(buf * BK + b_row0 + p * B_RPP) * BN + b_col]) = rb[p];
+            const float4 v = staged_finish(lb, rb[p], p);
+            if (b_on) *reinterpret_cast<float4*>(&Bs[(buf * BK + b_row0 + p * B_RPP) * BN + b_col]) = v;
         }
     };
     gload(0);
@@ -291,7 +310,7 @@ __device__ __forceinline__ void mfma_gemm_block_vec2(float* lds, LoaderA& la, Lo
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    struct Stage { float4 ra[A_PASSES], rb[B_PASSES]; int k0; typename LoaderB::Info info; };
+    struct Stage { float4 ra[A_PASSES]; typename StagedOf<LoaderB>::type rb[B_PASSES]; int k0; typename LoaderB::Info info; };
     Stage s0, s1;
     const int T = (t_end < 0 ? (K + BK - 1) / BK : t_end) - t_begin;
     auto gload = [&](int t, Stage& s) {
@@ -311,8 +330,8 @@ __device__ __forceinline__ void mfma_gemm_block_vec2(float* lds, LoaderA& la, Lo
         }
 #pragma unroll
         for (int p = 0; p < B_PASSES; ++p) {
-            lb.fix(s.rb[p], p, s.info);
-            if (b_on) *reinterpret_cast<float4*>(&Bs[(buf * BK + b_row0 + p * B_RPP) * BN + b_col]) = s.rb[p];
+            const float4 v = staged_finish(lb, s.rb[p], p, s.info);
+            if (b_on) *reinterpret_cast<float4*>(&Bs[(buf * BK + b_row0 + p * B_RPP) * BN + b_col]) = v;
         }
     };
     auto compute = [&](int buf) {

@@ -137,7 +137,7 @@ def test_attention_pool(dev):
                                                   (3, 256, 5, 16, 512, 3, 2, 1), (1, 512, 5, 16, 512, 3, 1, 1),
                                                   (1, 5, 9, 11, 7, 3, 1, 1), (2, 32, 3, 4, 32, 3, 1, 1),
                                                   (1, 64, 1, 8, 64, 3, 1, 1), (3, 32, 7, 12, 36, 1, 1, 0),
-                                                  (2, 32, 6, 8, 64, 3, 2, 1)])
+                                                  (2, 32, 6, 8, 64, 3, 2, 1), (2, 64, 40, 128, 128, 3, 2, 1), (2, 128, 20, 64, 256, 1, 2, 0)])
 def test_conv2d(dev, B, Cin, H, W, Cout, k, s, p):
     from deepi2p_amd import ops
     g = torch.Generator().manual_seed(Cin + Cout)
@@ -160,6 +160,10 @@ def test_conv2d(dev, B, Cin, H, W, Cout, k, s, p):
         with _lib.option("conv_depth1", 1):          # depth-1 vs depth-2 register prefetch: same K order, same MFMA sequence
             y6 = ops.conv2d(x.to(dev), Wtap, scale.to(dev), shift.to(dev), k, k, s, p, True, residual=res.to(dev), tap_major=True).cpu()
         assert torch.equal(y6, y3)
+        if s == 2:      # aligned 8-float window loads (default where the shape allows) vs four dword loads per staged row: the same values reach LDS
+            with _lib.option("conv_s2scalar", 1):
+                y7 = ops.conv2d(x.to(dev), Wtap, scale.to(dev), shift.to(dev), k, k, s, p, True, residual=res.to(dev), tap_major=True).cpu()
+            assert torch.equal(y7, y3)
         with _lib.option("conv_nosplit", 1):
             y4 = ops.conv2d(x.to(dev), Wtap, scale.to(dev), shift.to(dev), k, k, s, p, True, residual=res.to(dev), tap_major=True).cpu()
         assert (y4 - y3).abs().max() <= _tol(ref0, Cin * k * k)
