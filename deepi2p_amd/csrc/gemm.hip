@@ -1272,13 +1272,13 @@ extern "C" int di2p_point_head(const di2p_src_t* srcs, int n_src, const float* W
 extern "C" int di2p_point_chain(const di2p_src_t* srcs, int n_src, const float* W0t, int K0, const di2p_epilogue_t* epi0,
                                 const float* W1t, const float* scale1, const float* shift1, int relu1, const float* W2t,
                                 const float* scale2, const float* shift2, int relu2, float* Y, int B, int M, int N, void* stream) {
-    DI2P_CHECK_ARG(srcs && n_src == 1 && W0t && W1t && Y && epi0, "fused chain: one dense source");
+    DI2P_CHECK_ARG(srcs && n_src == 1 && W0t && W1t && epi0, "fused chain: one dense source");
     DI2P_CHECK_ARG(M == 32 || M == 64, "fused chain: width 32 or 64 (use the separate layers otherwise)");
     DI2P_CHECK_ARG(K0 <= M, "fused chain: at most M input channels");
     DI2P_CHECK_ARG(B >= 0 && N >= 1 && K0 >= 1, "bad size");
     DI2P_CHECK_ARG(epi0->group_max <= 1 && !epi0->transpose_out, "fused chain: layer 0 takes scale/shift/relu/bias/gathered only");
-    if (B == 0) return 0;
-    DI2P_CHECK_ARG(srcs[0].ptr && srcs[0].channels == K0 && srcs[0].mode == DI2P_SRC_DENSE, "fused chain: one dense source of K0 channels");
+    if (B == 0) return 0;          // an empty batch has no output buffer to check
+    DI2P_CHECK_ARG(Y && srcs[0].ptr && srcs[0].channels == K0 && srcs[0].mode == DI2P_SRC_DENSE, "fused chain: one dense source of K0 channels");
     DI2P_CHECK_ARG((long long)srcs[0].channels * srcs[0].row_stride < (1ll << 31), "per-frame source extent must fit 31 bits");
     EpiDev e{};
     e.group_max = 1;
