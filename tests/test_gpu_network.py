@@ -157,7 +157,8 @@ def test_fused_pointnet_chains_are_bit_identical(dev, N):
     x = [torch.from_numpy(batch[k]).to(dev) for k in ("pc", "intensity", "sn", "node_a", "node_b")]
     _lib.WORK = {}
     try:
-        fused = det.pc_encoder(*x)
+        with _lib.option("pw_nochain", 0):
+            fused = det.pc_encoder(*x)
         assert "di2p_point_chain" in _lib.WORK
         _lib.WORK = {}
         with _lib.option("pw_nochain", 1):
