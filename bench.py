@@ -100,6 +100,7 @@ def parse_args(argv=None):
                          "set below unless the environment already has it), 3 otherwise")
     ap.add_argument("--no-h2d-pass", action="store_true", help="skip the second timed loop with the H2D copy inside the step")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per stream")
+    ap.add_argument("--split-solver", action="store_true", help="experiment: classifier and pose solve of a step as two graphs on a high- and a normal-priority stream")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="only launch the ranks, rendezvous, run one barrier + all_reduce and print n_gpus (no GPU work)")
     return ap.parse_args(argv)
@@ -272,7 +273,7 @@ def main():
             _, P, _ = ops.select_best(bp.view(B, 1, -1).contiguous(), bc.view(B, 1).contiguous(), True, has_inside=o["has_inside"])
             return dict(o, P=P, cost=bc, best=best.int(), costs=allc)
     ex = RegistrationExecutor(mm, pipe, K64, host, n_streams=n_streams, use_graph=not args.no_graph, restarts=restarts,
-                              labels_override=solver_labels, step_fn=step_fn, post_fn=post_fn, h2d_mode=os.environ.get("DI2P_H2D_MODE", "copy_stream"))
+                              labels_override=solver_labels, step_fn=step_fn, post_fn=post_fn, h2d_mode=os.environ.get("DI2P_H2D_MODE", "copy_stream"), split_solver=args.split_solver)
 
     def barrier():
         if world > 1:

@@ -60,7 +60,7 @@ class RegistrationExecutor:
     SURVEY.md 8d: random-init weights predict nothing); default None = the network's own prediction, as the reference does."""
 
     def __init__(self, mm, pipe, K, example_batch, n_streams=8, use_graph=True, restarts=None, labels_override=None, step_fn=None,
-                 post_fn=None, h2d_mode="copy_stream"):
+                 post_fn=None, h2d_mode="copy_stream", split_solver=False):
         self.mm, self.pipe = mm, pipe
         self.device = mm.device
         self.n_streams = max(1, int(n_streams))
@@ -82,13 +82,19 @@ class RegistrationExecutor:
         # "eager" = hipMemcpyAsync on the slot's stream ahead of the replay (0.95-0.96); "graph" = memcpy nodes of the step's graph, which
         # the runtime executes as blit KERNELS on the CUs (0.91-0.95; tools/sweep_h2d_mode.sh, tools/probe_h2d.sh)
         self.h2d_mode = h2d_mode
+        # split_solver (experiment, graphs only): the classifier and the pose solve of a step as TWO graphs on two streams of different
+        # priority -- the classifier's ~90 short kernels on a high-priority queue, the solver's long-lived workgroups on a normal one, so
+        # that a freed compute unit goes to a waiting classifier kernel first (tools/r04_split.sh)
+        self.split_solver = bool(split_solver) and self.use_graph and step_fn is None
         mm.detector.prepack()                 # derive the kernel operands now, on the current stream, before other streams use them
         self._weights_version = mm.detector.weights_version
         self._packed_refs = mm.detector.packed_operands()     # the graphs hold raw pointers into these: keep them alive
         torch.cuda.synchronize(self.device)
         self.slots = []
         for i in range(self.n_streams):
-            s = Slot(i, torch.cuda.Stream(device=self.device))
+            s = Slot(i, torch.cuda.Stream(device=self.device, priority=-1 if self.split_solver else 0))
+            s.solver_stream = torch.cuda.Stream(device=self.device) if self.split_solver else None
+            s.net_done = torch.cuda.Event()
             s.copy_stream = torch.cuda.Stream(device=self.device) if h2d_mode == "copy_stream" else None
             s.copied = torch.cuda.Event()
             for k in INPUT_NAMES:
@@ -115,14 +121,22 @@ class RegistrationExecutor:
         d = slot.dev
         if self.step_fn is not None:
             return self.step_fn(slot, d)
+        return self._solve_part(slot, self._net_part(slot))
+
+    def _net_part(self, slot):
+        d = slot.dev
         logits = self.mm.detector(d["pc"], d["intensity"], d["sn"], d["node_a"], d["node_b"], d["img"])
         coarse = logits[0] if isinstance(logits, tuple) else logits
-        pred = ops.argmax_channels(coarse)                                   # inference_pass (:100-117): i32 [B,N]
-        labels = self.labels_override if self.labels_override is not None else pred
-        out = self.pipe(d["pc"], labels, d[K_NAME], self.restarts)           # same stream: the pose solve follows its classification
-        out["pred"] = pred
+        net = {"pred": ops.argmax_channels(coarse)}                          # inference_pass (:100-117): i32 [B,N]
         if isinstance(logits, tuple):
-            out["fine_pred"] = ops.argmax_channels(logits[1])
+            net["fine_pred"] = ops.argmax_channels(logits[1])
+        return net
+
+    def _solve_part(self, slot, net):
+        d = slot.dev
+        labels = self.labels_override if self.labels_override is not None else net["pred"]
+        out = self.pipe(d["pc"], labels, d[K_NAME], self.restarts)           # same stream: the pose solve follows its classification
+        out.update(net)
         return out
 
     def _capture(self, slot, with_h2d):
@@ -130,10 +144,34 @@ class RegistrationExecutor:
             self._step(slot, with_h2d)                                       # eager once: lazily created constants, allocator warm-up
         slot.stream.synchronize()
         self._x3_refs = [e[1] for e in ops._X3_CACHE.values()]               # the graph will hold raw pointers to these split weights too
+        if self.split_solver:
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga, stream=slot.stream):
+                if with_h2d:
+                    for k in INPUT_NAMES + (K_NAME,):
+                        slot.dev[k].copy_(slot.host[k], non_blocking=True)
+                net = self._net_part(slot)
+            torch.cuda.synchronize(self.device)
+            with torch.cuda.graph(gb, stream=slot.solver_stream):
+                out = self._solve_part(slot, net)
+            slot.graphs[with_h2d] = ((ga, gb), out)
+            return
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=slot.stream):
             out = self._step(slot, with_h2d)
         slot.graphs[with_h2d] = (g, out)
+
+    def _replay(self, slot, g):
+        """Replay a slot's step on the CURRENT stream (= slot.stream); with split_solver the pose solve follows on the solver stream."""
+        if not isinstance(g, tuple):
+            g.replay()
+            return
+        slot.stream.wait_event(slot.done)             # the slot's previous solve still reads the labels this classifier pass overwrites
+        g[0].replay()
+        slot.net_done.record()
+        with torch.cuda.stream(slot.solver_stream):
+            slot.solver_stream.wait_event(slot.net_done)
+            g[1].replay()
 
     def warm_up(self, with_h2d=True):
         """Capture (or run once) every slot's step so that the first timed submit pays nothing extra.  A failed capture switches the
@@ -158,7 +196,7 @@ class RegistrationExecutor:
             for slot in self.slots:
                 if with_h2d in slot.graphs and (slot.index, with_h2d) not in self._replayed:
                     with torch.cuda.stream(slot.stream):
-                        slot.graphs[with_h2d][0].replay()
+                        self._replay(slot, slot.graphs[with_h2d][0])
                     self._replayed.add((slot.index, with_h2d))
         if want_h2d and not self._h2d_warm:
             # the first copy on a stream pays one-time costs (DMA queue set-up, first touch of the pinned buffers by the engine): once per
@@ -226,13 +264,17 @@ class RegistrationExecutor:
                 if in_step not in slot.graphs:
                     self._capture(slot, in_step)
                 g, out = slot.graphs[in_step]
-                g.replay()
+                self._replay(slot, g)
                 slot.outputs = out
             else:
                 slot.outputs = self._step(slot, in_step)
             if self.post_fn is not None:
                 slot.outputs = self.post_fn(slot, slot.outputs)
-            slot.done.record()
+            if self.split_solver and self.use_graph:
+                with torch.cuda.stream(slot.solver_stream):
+                    slot.done.record()
+            else:
+                slot.done.record()
         slot.busy = True
         return slot.index
 
