@@ -66,6 +66,28 @@ def test_graph_replay_equals_eager_and_operator_calls(dev, override, h2d_mode):
         assert int((outs[True][0]["best"] >= 0).sum()) == int(((outs[True][0]["pred"] == 1).sum(dim=1) > 0).sum())
 
 
+def test_split_solver_graphs_equal_single_graph(dev):
+    """split_solver=True (experiment): classifier and pose solve as two graphs on two streams joined by events -- the same bits as the
+    one-graph step, with slots reused with new host data while their previous solve may still be running."""
+    from deepi2p_amd.pipeline import RegistrationExecutor
+    mm, pipe, K, restarts, batches, host = _setup(dev)
+    outs = {}
+    for split in (False, True):
+        ex = RegistrationExecutor(mm, pipe, K, host[0], n_streams=2, restarts=restarts, split_solver=split)
+        ex.warm_up(with_h2d=True)
+        assert ex.use_graph and ex.split_solver == split, ex.graph_error
+        tickets = [ex.submit(host[i]) for i in (0, 1)]
+        got = [{k: ex.result(t)[k].clone() for k in KEYS} for t in tickets]
+        for i in (2, 1, 0):
+            t = ex.submit(host[i])
+            got.append({k: ex.result(t)[k].clone() for k in KEYS})
+            assert ex.latency_ms(t) > 0.0
+        outs[split] = got
+    for a, b in zip(outs[True], outs[False]):
+        for k in KEYS:
+            assert torch.equal(a[k], b[k]), k
+
+
 def test_run_iterator_and_backpressure(dev):
     from deepi2p_amd.pipeline import RegistrationExecutor
     mm, pipe, K, restarts, batches, host = _setup(dev)
