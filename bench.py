@@ -273,7 +273,7 @@ def main():
             _, P, _ = ops.select_best(bp.view(B, 1, -1).contiguous(), bc.view(B, 1).contiguous(), True, has_inside=o["has_inside"])
             return dict(o, P=P, cost=bc, best=best.int(), costs=allc)
     ex = RegistrationExecutor(mm, pipe, K64, host, n_streams=n_streams, use_graph=not args.no_graph, restarts=restarts,
-                              labels_override=solver_labels, step_fn=step_fn, post_fn=post_fn, h2d_mode=os.environ.get("DI2P_H2D_MODE", "copy_stream"), split_solver=args.split_solver)
+                              labels_override=solver_labels, step_fn=step_fn, post_fn=post_fn, h2d_mode=os.environ.get("DI2P_H2D_MODE", "copy_stream"), split_solver=args.split_solver, double_buffer=bool(os.environ.get("DI2P_DOUBLE_BUFFER")))
 
     def barrier():
         if world > 1:

@@ -34,12 +34,17 @@ class Slot:
 
     def __init__(self, index, stream):
         self.index, self.stream = index, stream
-        self.dev, self.host = {}, {}
-        self.graphs = {}          # with_h2d (bool) -> (hipGraph, outputs dict)
+        self.devs, self.cur, self.host = [{}], 0, {}      # device input sets (two with double_buffer) and the one holding the newest batch
+        self.graphs = {}          # (with_h2d, input set) -> (hipGraph, outputs dict)
+        self.set_done = [torch.cuda.Event(), torch.cuda.Event()]      # last step that read input set j
         self.done = torch.cuda.Event(enable_timing=True)
         self.start = torch.cuda.Event(enable_timing=True)
         self.outputs = None
         self.busy = False
+
+    @property
+    def dev(self):
+        return self.devs[self.cur]
 
 
 class RegistrationExecutor:
@@ -60,7 +65,7 @@ class RegistrationExecutor:
     SURVEY.md 8d: random-init weights predict nothing); default None = the network's own prediction, as the reference does."""
 
     def __init__(self, mm, pipe, K, example_batch, n_streams=8, use_graph=True, restarts=None, labels_override=None, step_fn=None,
-                 post_fn=None, h2d_mode="copy_stream", split_solver=False):
+                 post_fn=None, h2d_mode="copy_stream", split_solver=False, double_buffer=False):
         self.mm, self.pipe = mm, pipe
         self.device = mm.device
         self.n_streams = max(1, int(n_streams))
@@ -82,6 +87,11 @@ class RegistrationExecutor:
         # "eager" = hipMemcpyAsync on the slot's stream ahead of the replay (0.95-0.96); "graph" = memcpy nodes of the step's graph, which
         # the runtime executes as blit KERNELS on the CUs (0.91-0.95; tools/sweep_h2d_mode.sh, tools/probe_h2d.sh)
         self.h2d_mode = h2d_mode
+        # double_buffer (option; h2d_mode "copy_stream" with graphs): TWO sets of device inputs per slot and one graph per set (sharing one
+        # memory pool), so the copies of a slot's NEXT batch do not wait for its running step to stop reading the inputs.  Measured
+        # (tools/r04_dbuf.sh): the H2D-inclusive latency of a batch drops 51.5 -> 48.5 ms at 8 batches in flight, the H2D-inclusive RATE
+        # does not move (0.95 of the resident rate either way: the copies do not cost the step its inputs' wait) -- off by default
+        self.double_buffer = bool(double_buffer) and h2d_mode == "copy_stream" and self.use_graph
         # split_solver (experiment, graphs only): the classifier and the pose solve of a step as TWO graphs on two streams of different
         # priority -- the classifier's ~90 short kernels on a high-priority queue, the solver's long-lived workgroups on a normal one, so
         # that a freed compute unit goes to a waiting classifier kernel first (tools/r04_split.sh)
@@ -101,10 +111,12 @@ class RegistrationExecutor:
                 t = example_batch[k]
                 s.host[k] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
                 s.host[k].copy_(t)
-                s.dev[k] = t.to(self.device, non_blocking=False).contiguous()
+                s.devs[0][k] = t.to(self.device, non_blocking=False).contiguous()
             s.host[K_NAME] = torch.empty((B, 3, 3), dtype=torch.float64).pin_memory()
             s.host[K_NAME].copy_(self.K64.cpu())
-            s.dev[K_NAME] = self.K64.clone()
+            s.devs[0][K_NAME] = self.K64.clone()
+            if self.double_buffer:
+                s.devs.append({k: v.clone() for k, v in s.devs[0].items()})
             self.slots.append(s)
         self._next = 0
         self._h2d_warm = False
@@ -140,26 +152,38 @@ class RegistrationExecutor:
         return out
 
     def _capture(self, slot, with_h2d):
+        """Capture the step once per input set of the slot (the sets' graphs share one memory pool: they never run at the same time)."""
+        keep = slot.cur
+        pool = None
+        for j in range(len(slot.devs)):
+            slot.cur = j
+            self._capture_set(slot, with_h2d, j, pool)
+            g = slot.graphs[(with_h2d, j)][0]
+            pool = (g[0] if isinstance(g, tuple) else g).pool()
+        slot.cur = keep
+
+    def _capture_set(self, slot, with_h2d, j, pool):
+        kw = {} if pool is None else {"pool": pool}
         with torch.cuda.stream(slot.stream):
             self._step(slot, with_h2d)                                       # eager once: lazily created constants, allocator warm-up
         slot.stream.synchronize()
         self._x3_refs = [e[1] for e in ops._X3_CACHE.values()]               # the graph will hold raw pointers to these split weights too
         if self.split_solver:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, stream=slot.stream):
+            with torch.cuda.graph(ga, stream=slot.stream, **kw):
                 if with_h2d:
                     for k in INPUT_NAMES + (K_NAME,):
                         slot.dev[k].copy_(slot.host[k], non_blocking=True)
                 net = self._net_part(slot)
             torch.cuda.synchronize(self.device)
-            with torch.cuda.graph(gb, stream=slot.solver_stream):
+            with torch.cuda.graph(gb, stream=slot.solver_stream, pool=ga.pool()):
                 out = self._solve_part(slot, net)
-            slot.graphs[with_h2d] = ((ga, gb), out)
+            slot.graphs[(with_h2d, j)] = ((ga, gb), out)
             return
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=slot.stream):
+        with torch.cuda.graph(g, stream=slot.stream, **kw):
             out = self._step(slot, with_h2d)
-        slot.graphs[with_h2d] = (g, out)
+        slot.graphs[(with_h2d, j)] = (g, out)
 
     def _replay(self, slot, g):
         """Replay a slot's step on the CURRENT stream (= slot.stream); with split_solver the pose solve follows on the solver stream."""
@@ -180,7 +204,7 @@ class RegistrationExecutor:
         want_h2d = bool(with_h2d)
         with_h2d = with_h2d and self.h2d_mode == "graph"
         for slot in self.slots:
-            if self.use_graph and with_h2d not in slot.graphs:
+            if self.use_graph and (with_h2d, 0) not in slot.graphs:
                 try:
                     self._capture(slot, with_h2d)
                 except Exception as exc:          # noqa: BLE001 -- any capture problem: run eagerly, keep the reason
@@ -194,17 +218,19 @@ class RegistrationExecutor:
         if self.use_graph:
             # likewise the first replay of a captured graph (the runtime uploads it then): once per slot and graph here
             for slot in self.slots:
-                if with_h2d in slot.graphs and (slot.index, with_h2d) not in self._replayed:
+                if (with_h2d, 0) in slot.graphs and (slot.index, with_h2d) not in self._replayed:
                     with torch.cuda.stream(slot.stream):
-                        self._replay(slot, slot.graphs[with_h2d][0])
+                        for j in range(len(slot.devs)):
+                            self._replay(slot, slot.graphs[(with_h2d, j)][0])
                     self._replayed.add((slot.index, with_h2d))
         if want_h2d and not self._h2d_warm:
             # the first copy on a stream pays one-time costs (DMA queue set-up, first touch of the pinned buffers by the engine): once per
             # slot here, like the graph capture above, not inside somebody's first timed steps
             for slot in self.slots:
                 with torch.cuda.stream(slot.copy_stream if slot.copy_stream is not None else slot.stream):
-                    for k in INPUT_NAMES + (K_NAME,):
-                        slot.dev[k].copy_(slot.host[k], non_blocking=True)
+                    for d in slot.devs:
+                        for k in INPUT_NAMES + (K_NAME,):
+                            d[k].copy_(slot.host[k], non_blocking=True)
             self._h2d_warm = True
         self._warmed.add(want_h2d)
         torch.cuda.synchronize(self.device)
@@ -238,7 +264,9 @@ class RegistrationExecutor:
             if not with_h2d:
                 raise ValueError("a host batch needs with_h2d=True (its copies are part of the step)")
         if slot.busy and host_batch is not None:
-            slot.done.synchronize()               # new host data: the slot's previous H2D copies must have read the pinned buffers
+            # new host data: the slot's previous H2D copies must have read the pinned buffers (their own event when they run on the copy
+            # stream; otherwise they are part of the step)
+            (slot.copied if self.h2d_mode == "copy_stream" and self.double_buffer else slot.done).synchronize()
         if host_batch is not None:
             for k in INPUT_NAMES:
                 slot.host[k].copy_(host_batch[k])
@@ -247,9 +275,10 @@ class RegistrationExecutor:
         names = INPUT_NAMES + (K_NAME,)
         in_step = with_h2d and self.h2d_mode == "graph"
         if with_h2d and self.h2d_mode == "copy_stream":
+            if self.double_buffer:
+                slot.cur ^= 1                                     # the set the slot's step BEFORE the previous one read
             with torch.cuda.stream(slot.copy_stream):
-                if slot.busy:
-                    slot.copy_stream.wait_event(slot.done)        # the previous step of this slot still reads the device inputs
+                slot.copy_stream.wait_event(slot.set_done[slot.cur])      # the last step that read this input set
                 for k in names:
                     slot.dev[k].copy_(slot.host[k], non_blocking=True)
                 slot.copied.record()
@@ -261,9 +290,9 @@ class RegistrationExecutor:
             elif with_h2d and self.h2d_mode == "copy_stream":
                 slot.stream.wait_event(slot.copied)
             if self.use_graph:
-                if in_step not in slot.graphs:
+                if (in_step, slot.cur) not in slot.graphs:
                     self._capture(slot, in_step)
-                g, out = slot.graphs[in_step]
+                g, out = slot.graphs[(in_step, slot.cur)]
                 self._replay(slot, g)
                 slot.outputs = out
             else:
@@ -273,8 +302,10 @@ class RegistrationExecutor:
             if self.split_solver and self.use_graph:
                 with torch.cuda.stream(slot.solver_stream):
                     slot.done.record()
+                    slot.set_done[slot.cur].record()
             else:
                 slot.done.record()
+                slot.set_done[slot.cur].record()
         slot.busy = True
         return slot.index
 

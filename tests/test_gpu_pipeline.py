@@ -66,6 +66,30 @@ def test_graph_replay_equals_eager_and_operator_calls(dev, override, h2d_mode):
         assert int((outs[True][0]["best"] >= 0).sum()) == int(((outs[True][0]["pred"] == 1).sum(dim=1) > 0).sum())
 
 
+def test_double_buffered_inputs_equal_single_set(dev):
+    """double_buffer=True: two device input sets per slot, one graph per set, copies of the next batch issued while the slot's step runs --
+    the same bits as the single-set executor, including the resident replay of the newest data and tickets kept across a re-submit."""
+    from deepi2p_amd.pipeline import RegistrationExecutor
+    mm, pipe, K, restarts, batches, host = _setup(dev)
+    outs = {}
+    for dbuf in (False, True):
+        ex = RegistrationExecutor(mm, pipe, K, host[0], n_streams=2, restarts=restarts, double_buffer=dbuf)
+        ex.warm_up(with_h2d=True)
+        assert ex.use_graph and ex.double_buffer == dbuf, ex.graph_error
+        got = []
+        for i in (0, 1, 2, 1, 0):                   # slot 0: batches 0, 2, 0; slot 1: batches 1, 1 -- submitted without waiting
+            got.append(ex.submit(host[i]))
+        res = []
+        for i, t in enumerate(got[-2:]):             # the last step of each slot
+            res.append({k: ex.result(t)[k].clone() for k in KEYS})
+        t = ex.submit(None, with_h2d=False)          # resident replay of what the next slot (slot 1) holds: batch 1
+        res.append({k: ex.result(t)[k].clone() for k in KEYS})
+        outs[dbuf] = res
+    for a, b in zip(outs[True], outs[False]):
+        for k in KEYS:
+            assert torch.equal(a[k], b[k]), k
+
+
 def test_split_solver_graphs_equal_single_graph(dev):
     """split_solver=True (experiment): classifier and pose solve as two graphs on two streams joined by events -- the same bits as the
     one-graph step, with slots reused with new host data while their previous solve may still be running."""
