@@ -26,23 +26,30 @@ __global__ __launch_bounds__(256) void knn_nodes_kernel(const float* __restrict_
     const int nc = min(n, Nq - 1);
     const float* q = query + (long long)b * 3 * Nq;
     const float qx = q[nc], qy = q[Nq + nc], qz = q[2 * Nq + nc];
-    // The k best candidates as SORTED 64-bit keys (bits of d^2 << 32 | node id): d^2 >= +0 is never negative, so the unsigned order of
-    // the keys is exactly the (d^2, id) order the insertion needs -- "closer, then lower id" is ONE compare, and inserting is a
-    // branch-free chain of selects (a NaN distance has the largest key and is never inserted, like `d < best` before).  The
-    // branchy insertion this replaces compiled to ~72 instructions per node, half of them exec-mask bookkeeping.
-    unsigned long long bk[KN];
+    // The k best candidates, sorted by (d^2, node id), as separate distance and id registers.  Candidates arrive in ascending id, so
+    // "closer, then lower id" is the STRICT 32-bit compare d^2 < best d^2 (an equal distance goes behind the one already there, which has
+    // the lower id; a NaN distance compares false and is never inserted) and inserting is a branch-free chain of selects.  (Round 3 kept
+    // 64-bit keys d^2 << 32 | id: the same selects, but three 64-bit compares per node instead of three 32-bit ones.  The branchy insertion
+    // before that compiled to ~72 instructions per node, half of them exec-mask bookkeeping.)
+    // The distances are compared as their BIT patterns (unsigned order = float order for d^2 >= +0); the empty-slot pattern 0x7f800001 lies
+    // above +inf (an overflowed distance is still inserted, as with the 64-bit keys) and below every quiet NaN (never inserted).
+    unsigned kd[KN];
+    int ki[KN];
 #pragma unroll
-    for (int j = 0; j < KN; ++j) bk[j] = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;       // (+inf, no node)
+    for (int j = 0; j < KN; ++j) { kd[j] = 0x7f800001u; ki[j] = 0x7fffffff; }       // (above +inf, no node)
     auto consider = [&](float nx, float ny, float nz, int m) __attribute__((always_inline)) {
         const float dx = __fsub_rn(qx, nx), dy = __fsub_rn(qy, ny), dz = __fsub_rn(qz, nz);
-        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)m;
+        const unsigned d = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
         bool lt[KN];
 #pragma unroll
-        for (int j = 0; j < KN; ++j) lt[j] = key < bk[j];
+        for (int j = 0; j < KN; ++j) lt[j] = d < kd[j];
 #pragma unroll
-        for (int j = KN - 1; j >= 1; --j) bk[j] = lt[j - 1] ? bk[j - 1] : (lt[j] ? key : bk[j]);      // shift down / insert / keep
-        bk[0] = lt[0] ? key : bk[0];
+        for (int j = KN - 1; j >= 1; --j) {                                             // shift down / insert / keep
+            kd[j] = lt[j - 1] ? kd[j - 1] : (lt[j] ? d : kd[j]);
+            ki[j] = lt[j - 1] ? ki[j - 1] : (lt[j] ? m : ki[j]);
+        }
+        kd[0] = lt[0] ? d : kd[0];
+        ki[0] = lt[0] ? m : ki[0];
     };
     int m = 0;
     for (; m + 4 <= M; m += 4) {          // uniform addresses: the compiler turns these into s_load_dwordx4
@@ -56,7 +63,7 @@ __global__ __launch_bounds__(256) void knn_nodes_kernel(const float* __restrict_
     float bd[KN];
     int bi[KN];
 #pragma unroll
-    for (int j = 0; j < KN; ++j) { bd[j] = __fsqrt_rn(__uint_as_float((unsigned)(bk[j] >> 32))); bi[j] = (int)(unsigned)(bk[j] & 0xffffffffu); }
+    for (int j = 0; j < KN; ++j) { bd[j] = __fsqrt_rn(__uint_as_float(kd[j])); bi[j] = ki[j]; }
     // equal rounded distances: lowest node id first (insertion sort on (d, id); the squared order is already almost that)
 #pragma unroll
     for (int a = 1; a < KN; ++a)
