@@ -311,7 +311,7 @@ def main():
 
     # per-kernel-family durations: HIP events on the launch stream, in a SERIAL pass right after the timed region
     # (with several batches in flight, events inside the timed region would measure contention, not the kernels)
-    timed_names = ("di2p_conv2d", "di2p_conv2d_ws", "di2p_conv3x3_winograd", "di2p_conv7x7s2_stem", "di2p_pointwise_gemm", "di2p_pointwise_gemm_x3", "di2p_point_head", "di2p_point_chain", "di2p_index_max_values",
+    timed_names = ("di2p_conv2d", "di2p_conv2d_ws", "di2p_conv3x3_winograd", "di2p_conv3x3_x3", "di2p_conv7x7s2_stem", "di2p_pointwise_gemm", "di2p_pointwise_gemm_x3", "di2p_point_head", "di2p_point_chain", "di2p_index_max_values",
                    "di2p_solve_batched_f32", "di2p_knn_nodes")
     prof_steps = 2
     _lib.TIMED = {n: [] for n in timed_names}
@@ -332,8 +332,10 @@ def main():
     # and the fused Winograd kernel that runs the 3x3 stride-1 layers
     direct_ms, wino_ms, wino_calls = fam_ms["di2p_conv2d"] + fam_ms["di2p_conv2d_ws"], fam_ms["di2p_conv3x3_winograd"], launches["di2p_conv3x3_winograd"]
     stem_ms = fam_ms["di2p_conv7x7s2_stem"]
-    fam_ms["di2p_conv2d"] += fam_ms.pop("di2p_conv2d_ws") + fam_ms.pop("di2p_conv3x3_winograd") + fam_ms.pop("di2p_conv7x7s2_stem")
-    launches["di2p_conv2d"] += launches.pop("di2p_conv2d_ws") + launches.pop("di2p_conv3x3_winograd") + launches.pop("di2p_conv7x7s2_stem")
+    # ... and the 3x3 layers that run as direct convolutions on the bf16 matrix instructions with exact three-way fp32 splits (conv_x3.hip)
+    cx_ms, cx_calls, cx_mac = fam_ms["di2p_conv3x3_x3"], launches["di2p_conv3x3_x3"], work.get("di2p_conv3x3_x3", 0) / prof_steps
+    fam_ms["di2p_conv2d"] += fam_ms.pop("di2p_conv2d_ws") + fam_ms.pop("di2p_conv3x3_winograd") + fam_ms.pop("di2p_conv7x7s2_stem") + fam_ms.pop("di2p_conv3x3_x3")
+    launches["di2p_conv2d"] += launches.pop("di2p_conv2d_ws") + launches.pop("di2p_conv3x3_winograd") + launches.pop("di2p_conv7x7s2_stem") + launches.pop("di2p_conv3x3_x3")
     wino_exec_flops = 2.0 * work.get("di2p_conv3x3_winograd", 0) / prof_steps
     # pointwise family = the single-layer launches + the fused three-layer point head
     # ... and the GEMM-shaped layers that run on the bf16 matrix instructions with exact three-way fp32 splits (priced separately below)
@@ -367,6 +369,13 @@ def main():
             "compulsory_bytes_per_launch": (conv_bytes_per_frame(H, W) * B + 85.1e6) / 36.0,
             "winograd": {"calls_per_step": wino_calls, "ms_per_step": wino_ms, "executed_mfma_tflops": wino_exec_flops / max(wino_ms, 1e-9) / 1e9,
                          "direct_kernel_ms_per_step": direct_ms, "stem_kernel_ms_per_step": stem_ms},
+            "bf16x3": {"calls_per_step": cx_calls, "ms_per_step": cx_ms, "fp32_equivalent_tflops": 2.0 * cx_mac / max(cx_ms, 1e-9) / 1e9,
+                       "frac_of_fp32_mfma_peak": 2.0 * cx_mac / max(cx_ms, 1e-9) / 1e9 / MFMA_F32_PEAK_TFLOPS,
+                       "executed_bf16_tflops": 12.0 * cx_mac / max(cx_ms, 1e-9) / 1e9, "bf16_mfma_peak_tflops": MFMA_BF16_PEAK_TFLOPS,
+                       "frac_of_bf16_mfma_peak": 12.0 * cx_mac / max(cx_ms, 1e-9) / 1e9 / MFMA_BF16_PEAK_TFLOPS,
+                       "note": "3x3 layers (and the 1x1 / stride-2 branches fused into the stride-2 ones) as direct implicit GEMMs on the bf16 matrix "
+                               "instructions, both fp32 operands split EXACTLY into three bf16 terms (six products per fp32 product, fp32 accumulation): "
+                               "fp32_equivalent = 2*MAC / time, executed = 6 x that, priced against the 2.5 PFLOP/s dense bf16 peak"},
             "note": "achieved = reference-algorithmic 2*MAC of the 36 convolutions (SURVEY 8d) / time of the whole family; the 3x3 "
                     "stride-1 layers run as Winograd F(2x2,3x3) (16 instead of 36 multiplications per tile and channel pair, exact "
                     "arithmetic in fp32): `winograd.executed_mfma_tflops` is what the MFMA units actually issue for them"},
@@ -475,7 +484,7 @@ def main():
             "metric": "frames/sec (img+pc infer + 60-restart GN pose) KITTI 20k-pt, 1/2/4/8 GPU",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if hyp else "weak", "vs_baseline": None,
-            "dtype": "f32 network (fp32-input MFMA; GEMM-shaped point layers: bf16 MFMA on exact three-way fp32 splits, fp32 accumulation) + f64 solver",
+            "dtype": "f32 network (fp32-input MFMA; 3x3 convolutions and GEMM-shaped point layers: bf16 MFMA on exact three-way fp32 splits, fp32 accumulation) + f64 solver",
             "data": "synthetic frames, random-init closed-form weights; solver labels = GT frustum labels with 5% flips (SURVEY 8d)",
             "config": {"workload": ("BASELINE configs[4]: Oxford-shaped %d-pt / %dx%d, %d frames per step on every rank, coarse classification "
                                     "+ %d 2D GN/LM hypotheses per frame sharded over the ranks, all_gather + argmin" % (N, H, W, B, R)) if hyp else

@@ -36,6 +36,7 @@ const OptDef kOpts[DI2P_OPT_COUNT] = {
     {"solver_prep_bitonic", "DI2P_SOLVER_PREP_BITONIC", 0},
     {"pw_x3", "DI2P_PW_X3", 1},                     {"pw_nochain", "DI2P_PW_NOCHAIN", 0},
     {"head_reg", "DI2P_HEAD_REG", 0},               {"conv_s2scalar", "DI2P_CONV_S2SCALAR", 0},
+    {"conv_x3", "DI2P_CONV_X3", 31},                 {"conv_x3_cfg", "DI2P_CONV_X3_CFG", -1},
 };
 long long g_opt[DI2P_OPT_COUNT];
 std::once_flag g_opt_once;

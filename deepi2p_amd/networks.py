@@ -104,7 +104,8 @@ class _PackedModule(nn.Module):
             if isinstance(m, _PackedModule):
                 m._packed = None
                 m._weights_version += 1
-        ops.x3_invalidate()          # the split (bf16x3) copies are keyed by the addresses of the operands just dropped
+        # the split (bf16x3) copies of these operands expire with them (ops._X3_CACHE entries are weakly tied to the operand they were
+        # made from): nothing global is cleared here -- another model's splits, which its captured graphs point to, stay where they are
 
     @property
     def weights_version(self):
@@ -320,6 +321,12 @@ class ImageEncoder(_PackedModule):
                         w = sd[q + "." + name + ".weight"]
                         if w.is_cuda and (name == "conv2" or blk["stride"] == 1):
                             blk["U" + name[-1]] = ops.winograd_weights(w)
+                        # every 3x3 layer: the split (bf16x3) copy of the tap-major matrix for di2p_conv3x3_x3; owned by this container,
+                        # so it is dropped and re-derived with the weights it was made from
+                        if w.is_cuda and w.shape[1] % 16 == 0:
+                            blk["X" + name[-1]] = ops.bf16x3_pack(blk["c" + name[-1]][0])
+                    if "ds" in blk and blk["ds"][0].is_cuda and blk["ds"][0].shape[0] % 16 == 0:
+                        blk["Xd"] = ops.bf16x3_pack(blk["ds"][0])
                     p["blocks"].append(blk)
             self._packed = p
         return self._packed
@@ -335,19 +342,34 @@ class ImageEncoder(_PackedModule):
         x = ops.maxpool3x3s2(x)
         stage_out = {}
         wino = not _lib.get_option("conv_nowinograd")
+        # bit s-1: the stride-1 layers of stage s, bit 4: the stride-2 layers (+ their 1x1 downsample branch) on di2p_conv3x3_x3
+        x3_mask = _lib.get_option("conv_x3")
         for blk in p["blocks"]:
             identity = x
             Wt, sc, sh, _ = blk["c1"]
-            wino_ok = wino and x.shape[3] % 2 == 0 and x.shape[3] >= 4       # the kernel wants an even width (else: direct kernel)
-            if wino_ok and "U1" in blk:
-                y = ops.conv3x3_winograd(x, blk["U1"], sc, sh, True)
-            else:
-                y = ops.conv2d(x, Wt, sc, sh, 3, 3, blk["stride"], 1, True, tap_major=True)
-            if "ds" in blk:
-                Wd, sd_, shd, _ = blk["ds"]
-                identity = ops.conv2d(x, Wd, sd_, shd, 1, 1, blk["stride"], 0, False, tap_major=True)
+            Cout, stride = Wt.shape[1], blk["stride"]
+            x3_bit = 16 if stride == 2 else 1 << (blk["stage"] - 1)
+            y = None
+            if (x3_mask & x3_bit) and "X1" in blk and (stride == 1 or "Xd" in blk) and ops.conv3x3_x3_supported(x.shape, Cout, stride):
+                if stride == 2:
+                    Wd, sd_, shd, _ = blk["ds"]
+                    y, identity = ops.conv3x3_x3(x, blk["X1"], Cout, sc, sh, 2, True, downsample=(blk["Xd"], sd_, shd))
+                else:
+                    y = ops.conv3x3_x3(x, blk["X1"], Cout, sc, sh, 1, True)
+            if y is None:
+                wino_ok = wino and x.shape[3] % 2 == 0 and x.shape[3] >= 4       # the kernel wants an even width (else: direct kernel)
+                if wino_ok and "U1" in blk:
+                    y = ops.conv3x3_winograd(x, blk["U1"], sc, sh, True)
+                else:
+                    y = ops.conv2d(x, Wt, sc, sh, 3, 3, stride, 1, True, tap_major=True)
+                if "ds" in blk:
+                    Wd, sd_, shd, _ = blk["ds"]
+                    identity = ops.conv2d(x, Wd, sd_, shd, 1, 1, stride, 0, False, tap_major=True)
             Wt, sc, sh, _ = blk["c2"]
-            if wino and "U2" in blk and y.shape[3] % 2 == 0 and y.shape[3] >= 4:
+            x3_bit = 1 << (blk["stage"] - 1)
+            if (x3_mask & x3_bit) and "X2" in blk and ops.conv3x3_x3_supported(y.shape, Cout, 1):
+                x = ops.conv3x3_x3(y, blk["X2"], Cout, sc, sh, 1, True, residual=identity)
+            elif wino and "U2" in blk and y.shape[3] % 2 == 0 and y.shape[3] >= 4:
                 x = ops.conv3x3_winograd(y, blk["U2"], sc, sh, True, residual=identity)
             else:
                 x = ops.conv2d(y, Wt, sc, sh, 3, 3, 1, 1, True, residual=identity, tap_major=True)

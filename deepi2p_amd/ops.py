@@ -173,17 +173,26 @@ def _fill_gathered(e, gathered, B, M, N):
         e.g_k[t] = k
 
 
-# bf16x3 operand cache: packed (split) weights of the GEMM-shaped layers, keyed by the fp32 operand they were made from.  The fp32 operands
-# are themselves derived tensors that networks._PackedModule frees and re-derives when the weights change -- it calls x3_invalidate() then,
-# so a recycled address can never return a stale split.  Filled by the first eager call of a layer (the executor runs one eager step before
-# it captures a graph); a call under stream capture with a cold cache packs on the capturing stream, which is valid too (the pack kernel
-# becomes a graph node), only slower.
+# bf16x3 operand cache: packed (split) weights of the GEMM-shaped layers, keyed by the fp32 operand they were made from.  An entry lives exactly
+# as long as the fp32 operand's BASE tensor (a derived tensor owned by one networks._PackedModule's `_packed` container): a weak-reference
+# finaliser drops it when that tensor is freed, so (i) a recycled address can never return a stale split, (ii) invalidating ONE module (its
+# .to(), load_state_dict, an optimiser step) never touches another module's splits -- a holder of raw pointers (a captured hipGraph) keeps the
+# module's packed operands referenced and thereby their splits (pipeline.RegistrationExecutor._packed_refs / _x3_refs).
+# An entry is published only when it is COMPLETE: the packing stream is synchronised before the entry becomes visible, so another stream
+# that finds it needs no ordering; under stream capture nothing can be waited for -- the pack becomes a node of THAT graph and is not
+# cached (the executor runs one eager step before it captures, so this is the cold path only).
 _X3_CACHE = {}            # (address, K, M, device) -> (weak reference to the fp32 operand's base tensor, split operand)
 X3_MIN_K = 128
 
 
 def x3_invalidate():
+    """Drop every cached split (tests; never needed for correctness: entries die with the operand they were made from)."""
     _X3_CACHE.clear()
+
+
+def x3_live_operands():
+    """The split operands currently cached (a holder of raw pointers to them keeps this list)."""
+    return [e[1] for e in _X3_CACHE.values()]
 
 
 def bf16x3_pack(Wt):
@@ -217,7 +226,16 @@ def _x3_operand(Wt, B, M, N, x3):
     if ent is not None and ent[0]() is base:
         return ent[1]
     Wp = bf16x3_pack(Wt)
-    _X3_CACHE[key] = (weakref.ref(base), Wp)
+    if torch.cuda.is_current_stream_capturing():
+        return Wp                                    # a node of this graph only: never visible to another stream or graph
+    torch.cuda.current_stream(Wt.device).synchronize()   # complete before it is published (once per layer and weights version)
+
+    def _expired(ref, key=key):
+        ent = _X3_CACHE.get(key)
+        if ent is not None and ent[0] is ref:
+            del _X3_CACHE[key]
+
+    _X3_CACHE[key] = (weakref.ref(base, _expired), Wp)
     return Wp
 
 
@@ -357,6 +375,33 @@ def conv2d(x, Wt, scale, shift, KH, KW, stride, pad, relu, residual=None, tap_ma
     else:
         call("di2p_conv2d", *args, stream())
     return y
+
+
+def conv3x3_x3_supported(x_shape, Cout, stride):
+    """True if di2p_conv3x3_x3 has a kernel instance for this layer shape (x_shape = (B, Cin, H, W))."""
+    B, Cin, H, W = (int(v) for v in x_shape)
+    return bool(_lib.load().di2p_conv3x3_x3_supported(B, Cin, H, W, int(Cout), int(stride)))
+
+
+def conv3x3_x3(x, Wp, Cout, scale, shift, stride, relu, residual=None, downsample=None):
+    """3x3 / pad 1 convolution on the bf16 matrix instructions with exact three-way fp32 splits (di2p_conv3x3_x3):
+    y = relu?(scale * conv(x) + shift + residual).  Wp = bf16x3_pack(tap-major Wt[9 Cin, Cout]).  stride 2 takes
+    downsample = (Wp_ds, scale_ds, shift_ds) -- the BasicBlock's 1x1 / stride-2 branch of the same input (resnet.py:160-164) -- and
+    returns (y, y_ds)."""
+    require_cuda(x, Wp, scale, shift, residual)
+    B, Cin, H, W = x.shape
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((B, Cout, OH, OW), dtype=_f32, device=x.device)
+    Wd = sd = hd = yd = None
+    if downsample is not None:
+        Wd, sd, hd = downsample
+        require_cuda(Wd, sd, hd)
+        yd = torch.empty((B, Cout, OH, OW), dtype=_f32, device=x.device)
+    if _lib.WORK is not None:
+        _lib.WORK["di2p_conv3x3_x3"] = _lib.WORK.get("di2p_conv3x3_x3", 0) + B * Cout * Cin * (9 + (1 if downsample is not None else 0)) * OH * OW
+    call("di2p_conv3x3_x3", ptr(x), ptr(Wp), ptr(scale), ptr(shift), ptr(residual), ptr(y), B, Cin, H, W, Cout, int(stride), int(bool(relu)),
+         ptr(Wd), ptr(sd), ptr(hd), ptr(yd), stream())
+    return (y, yd) if downsample is not None else y
 
 
 def stem_weights(weight):

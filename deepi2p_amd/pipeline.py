@@ -99,6 +99,8 @@ class RegistrationExecutor:
         mm.detector.prepack()                 # derive the kernel operands now, on the current stream, before other streams use them
         self._weights_version = mm.detector.weights_version
         self._packed_refs = mm.detector.packed_operands()     # the graphs hold raw pointers into these: keep them alive
+        self._x3_refs = []                                    # ... and into their split (bf16x3) copies: accumulated at every capture
+        self._K64_host = self.K64.cpu()
         torch.cuda.synchronize(self.device)
         self.slots = []
         for i in range(self.n_streams):
@@ -113,7 +115,7 @@ class RegistrationExecutor:
                 s.host[k].copy_(t)
                 s.devs[0][k] = t.to(self.device, non_blocking=False).contiguous()
             s.host[K_NAME] = torch.empty((B, 3, 3), dtype=torch.float64).pin_memory()
-            s.host[K_NAME].copy_(self.K64.cpu())
+            s.host[K_NAME].copy_(self._K64_host)
             s.devs[0][K_NAME] = self.K64.clone()
             if self.double_buffer:
                 s.devs.append({k: v.clone() for k, v in s.devs[0].items()})
@@ -167,7 +169,10 @@ class RegistrationExecutor:
         with torch.cuda.stream(slot.stream):
             self._step(slot, with_h2d)                                       # eager once: lazily created constants, allocator warm-up
         slot.stream.synchronize()
-        self._x3_refs = [e[1] for e in ops._X3_CACHE.values()]               # the graph will hold raw pointers to these split weights too
+        # the graph will hold raw pointers to the split (bf16x3) weights too: ACCUMULATE them (a later capture must not drop what an
+        # earlier graph points to); the list is emptied only when every graph is (_follow_weights)
+        have = {id(t) for t in self._x3_refs}
+        self._x3_refs += [t for t in ops.x3_live_operands() if id(t) not in have]
         if self.split_solver:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, stream=slot.stream, **kw):
@@ -255,14 +260,14 @@ class RegistrationExecutor:
         if bool(with_h2d) not in self._warmed:
             self.warm_up(with_h2d)                # first use: captures, first replays, first copies (synchronises the device once)
         slot = self.slots[self._next]
-        self._next = (self._next + 1) % self.n_streams
-        if host_batch is not None:
+        if host_batch is not None:                # validate BEFORE the slot position advances: a rejected submit consumes nothing
             for k in INPUT_NAMES + ((K_NAME,) if K_NAME in host_batch else ()):
                 if tuple(host_batch[k].shape) != tuple(slot.host[k].shape):
                     raise ValueError("host batch %r has shape %s, this executor was built (and its graphs captured) for %s -- pad the batch "
                                      "or build an executor for that shape" % (k, tuple(host_batch[k].shape), tuple(slot.host[k].shape)))
             if not with_h2d:
                 raise ValueError("a host batch needs with_h2d=True (its copies are part of the step)")
+        self._next = (self._next + 1) % self.n_streams
         if slot.busy and host_batch is not None:
             # new host data: the slot's previous H2D copies must have read the pinned buffers (their own event when they run on the copy
             # stream; otherwise they are part of the step)
@@ -272,6 +277,8 @@ class RegistrationExecutor:
                 slot.host[k].copy_(host_batch[k])
             if K_NAME in host_batch:
                 slot.host[K_NAME].copy_(host_batch[K_NAME])       # f32 -> f64 on the way into the pinned buffer
+            else:
+                slot.host[K_NAME].copy_(self._K64_host)           # no K in this batch: the constructor's, not what the slot last held
         names = INPUT_NAMES + (K_NAME,)
         in_step = with_h2d and self.h2d_mode == "graph"
         if with_h2d and self.h2d_mode == "copy_stream":
@@ -322,6 +329,7 @@ class RegistrationExecutor:
             s.busy = False
         self._replayed.clear()
         self._warmed.clear()
+        self._x3_refs = []
         self.mm.detector.prepack()
         self._packed_refs = self.mm.detector.packed_operands()
         self._weights_version = self.mm.detector.weights_version

@@ -24,7 +24,7 @@ extern "C" {
 const char* di2p_last_error(void);
 int di2p_version(void);
 /* Tuning / test knobs, cached in the library (initialised once from the environment variable DI2P_<NAME>): "conv_nosplit",
- * "conv_split_blocks", "conv_novec", "conv_cfg", "conv_depth1", "pw_novec", "solver_cfg", "solver_nocull", "solver_noprefilter", "solver_tier_sweeps".
+ * "conv_split_blocks", "conv_novec", "conv_cfg", "conv_depth1", "conv_x3", "conv_x3_cfg", "pw_novec", "solver_cfg", "solver_nocull", "solver_noprefilter", "solver_tier_sweeps".
  * set: 0, or -1 for an unknown name; get: the value, or -1 for an unknown name. */
 int di2p_set_option(const char* name, long long value);
 long long di2p_get_option(const char* name);
@@ -203,6 +203,19 @@ long long di2p_conv2d_workspace_bytes(int B, int Cin, int H, int W, int Cout, in
 int di2p_winograd_weight_transform(const float* weight, float* U, int Cin, int Cout, void* stream);
 int di2p_conv3x3_winograd(const float* x, const float* U, const float* scale, const float* shift, const float* residual, float* y, int B,
                           int Cin, int H, int W, int Cout, int relu, void* stream);
+/* 3x3 convolutions (pad 1, stride 1 or 2) on the bf16 matrix instructions with the EXACT three-way fp32 split of both operands ("bf16x3",
+ * see di2p_pointwise_gemm_x3): a direct implicit GEMM whose input patch is split once while it is staged into LDS and then serves all nine
+ * taps.  Replaces cuDNN's conv+BN+ReLU(+residual) of models/resnet.py:56-72 (BasicBlock.forward) for the layers it supports; with stride 2
+ * the BasicBlock's 1x1 / stride-2 downsample branch (models/resnet.py:160-164, applied at :62-63) is computed from the same staged patch.
+ *   Wp    = di2p_bf16x3_pack of the tap-major matrix Wt[(kh*3+kw)*Cin + ci][Cout] (K = 9 Cin, M = Cout);
+ *   Wp_ds = di2p_bf16x3_pack of Wt_ds[Cin][Cout] (stride 2: required; stride 1: must be NULL);
+ *   y     f32[B,Cout,OH,OW] = relu?(scale * conv3x3(x f32[B,Cin,H,W]) + shift + residual);  y_ds = scale_ds * conv1x1/s2(x) + shift_ds.
+ * di2p_conv3x3_x3_supported: 1 if a kernel instance exists for the shape (OW % 32 == 0 and Cin % 16 == 0, or OW % 16 == 0 and
+ * Cin % 32 == 0; the input patch of a tile must fit the LDS), else 0 -- the caller then uses di2p_conv3x3_winograd / di2p_conv2d. */
+int di2p_conv3x3_x3_supported(int B, int Cin, int H, int W, int Cout, int stride);
+int di2p_conv3x3_x3(const float* x, const void* Wp, const float* scale, const float* shift, const float* residual, float* y, int B,
+                    int Cin, int H, int W, int Cout, int stride, int relu, const void* Wp_ds, const float* scale_ds,
+                    const float* shift_ds, float* y_ds, void* stream);
 /* The ResNet stem (7x7 / stride 2 / pad 3, 3 -> 64 channels, models/resnet.py:137-139,197-199) as a direct kernel: the filter bank and
  * the input row segments of a workgroup are staged once (columns de-interleaved by parity), then 168 MFMAs per wave without a barrier.
  *   di2p_stem_pack: weight f32[64,3,7,7] -> Wp f32[168,64] (taps padded 7 -> 8 per row), once per checkpoint load.

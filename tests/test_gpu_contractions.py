@@ -315,3 +315,29 @@ def test_bf16x3_split_cache_follows_the_operand_not_the_address(dev):
     assert len(seen) < 4              # the allocator did recycle an address: the case the weak reference exists for
     ops.x3_invalidate()
     assert not ops._X3_CACHE
+
+
+@pytest.mark.gpu
+def test_bf16x3_cache_entries_live_and_die_with_their_operand(dev):
+    """Round-4 advisor finding: the split weights were dropped by ANY module's invalidation while captured graphs of another model still
+    pointed to them.  An entry now lives exactly as long as the fp32 operand it was made from: a foreign module's .to() / load_state_dict
+    leaves it alone, deleting the operand removes it."""
+    import gc
+    from deepi2p_amd import ops, networks
+    ops.x3_invalidate()
+    g = torch.Generator().manual_seed(5)
+    B, K, M, N = 1, 256, 256, 2048
+    x = torch.randn(B, K, N, generator=g).to(dev)
+    Wt = (torch.randn(K, M, generator=g) / K ** 0.5).to(dev)
+    ops.pointwise_gemm([ops.Src(x)], Wt, M, N, x3=True)
+    assert len(ops._X3_CACHE) == 1
+    Wp = ops.x3_live_operands()[0]
+    other = networks._PackedModule()
+    other._invalidate()                                   # another model changing must not clear this operand's split
+    other.to(dev)
+    assert ops.x3_live_operands() and ops.x3_live_operands()[0] is Wp
+    y = ops.pointwise_gemm([ops.Src(x)], Wt, M, N, x3=True)
+    assert ops.x3_live_operands()[0] is Wp                # found again, not re-packed
+    del Wt, y
+    gc.collect()
+    assert not ops._X3_CACHE                              # expired with the operand

@@ -1,0 +1,138 @@
+"""GPU parity of di2p_conv3x3_x3 (3x3 convolutions on the bf16 matrix instructions with exact three-way fp32 splits, conv_x3.hip)
+against an fp64 convolution of the same fp32 operands, and against the fp32-MFMA kernels it replaces: the bar the round-3 review set for
+bf16x3 -- max error <= 1.25 x and rms error <= 1.1 x the fp32-MFMA kernel's, inside the 3e-6 sqrt(K) max|y| tolerance of the other
+contraction tests.  Reference layers: models/resnet.py:56-72 (BasicBlock), :160-164 (downsample)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from deepi2p_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+# (Cin, H, W, Cout, stride): the seven 3x3 layer shapes of ResNet-34 at 160 x 512 (compile-time patch rows), then shapes that run on the
+# run-time-row-length instances: ragged last tiles, several Cout tiles with a partial one, widths that are multiples of 16 only
+RESNET_SHAPES = [(64, 40, 128, 64, 1), (128, 20, 64, 128, 1), (256, 10, 32, 256, 1), (512, 5, 16, 512, 1),
+                 (64, 40, 128, 128, 2), (128, 20, 64, 256, 2), (256, 10, 32, 512, 2)]
+OTHER_SHAPES = [(32, 12, 64, 48, 1), (32, 9, 96, 40, 1), (64, 6, 48, 80, 1), (96, 7, 16, 200, 1), (16, 3, 32, 32, 1),
+                (32, 12, 64, 72, 2), (64, 8, 32, 48, 2)]
+
+
+def _ref64(x, w, stride):
+    return F.conv2d(x.double(), w.double(), stride=stride, padding=1)
+
+
+def _err(y, ref):
+    d = (y.double() - ref).abs()
+    return float(d.max()), float((d ** 2).mean().sqrt())
+
+
+def _operands(Cin, H, W, Cout, stride, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = torch.randn(B, Cout, OH, OW, generator=g)
+    wd = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    sd, hd = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    return x, w, scale, shift, res, wd, sd, hd
+
+
+@pytest.mark.parametrize("Cin,H,W,Cout,stride", RESNET_SHAPES + OTHER_SHAPES)
+def test_conv3x3_x3_matches_fp64_and_is_as_accurate_as_fp32_mfma(dev, Cin, H, W, Cout, stride):
+    from deepi2p_amd import ops
+    B = 3
+    assert ops.conv3x3_x3_supported((B, Cin, H, W), Cout, stride), "no kernel instance for a shape this test lists"
+    x, w, scale, shift, res, wd, sd, hd = _operands(Cin, H, W, Cout, stride, B, 7 + Cin + W)
+    Wt = w.permute(2, 3, 1, 0).reshape(-1, Cout).contiguous().to(dev)             # tap-major [9 Cin][Cout]
+    Wp = ops.bf16x3_pack(Wt)
+    xd, sc, sh = x.to(dev), scale.to(dev), shift.to(dev)
+    K = 9 * Cin
+    if stride == 1:
+        # raw contraction (scale 1, shift 0): the accuracy comparison proper
+        one, zero = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+        y3 = ops.conv3x3_x3(xd, Wp, Cout, one, zero, 1, False).cpu()
+        y1 = ops.conv2d(xd, Wt, one, zero, 3, 3, 1, 1, False, tap_major=True).cpu()
+        ref = _ref64(x, w, 1)
+        (m3, r3), (m1, r1) = _err(y3, ref), _err(y1, ref)
+        tol = 3e-6 * K ** 0.5 * float(ref.abs().max()) + 1e-6
+        assert m3 <= tol and m3 <= 1.25 * m1 + 1e-7 and r3 <= 1.1 * r1 + 1e-8, (m3, m1, r3, r1, tol)
+        # the full epilogue: folded BatchNorm, residual, ReLU
+        y = ops.conv3x3_x3(xd, Wp, Cout, sc, sh, 1, True, residual=res.to(dev)).cpu()
+        full = torch.relu(ref * scale.view(1, -1, 1, 1).double() + shift.view(1, -1, 1, 1).double() + res.double())
+        assert _err(y, full)[0] <= 2 * tol * 1.5 + 1e-5
+        y = ops.conv3x3_x3(xd, Wp, Cout, sc, sh, 1, False).cpu()
+        full = ref * scale.view(1, -1, 1, 1).double() + shift.view(1, -1, 1, 1).double()
+        assert _err(y, full)[0] <= 2 * tol * 1.5 + 1e-5
+    else:
+        Wtd = wd.reshape(Cout, Cin).t().contiguous().to(dev)
+        Wpd = ops.bf16x3_pack(Wtd)
+        one, zero = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+        y3, yd3 = ops.conv3x3_x3(xd, Wp, Cout, one, zero, 2, False, downsample=(Wpd, one, zero))
+        y1 = ops.conv2d(xd, Wt, one, zero, 3, 3, 2, 1, False, tap_major=True).cpu()
+        yd1 = ops.conv2d(xd, Wtd, one, zero, 1, 1, 2, 0, False, tap_major=True).cpu()
+        ref, refd = _ref64(x, w, 2), F.conv2d(x.double(), wd.double(), stride=2)
+        for got, base, r, k in ((y3.cpu(), y1, ref, K), (yd3.cpu(), yd1, refd, Cin)):
+            (m3, r3), (m1, r1) = _err(got, r), _err(base, r)
+            tol = 3e-6 * k ** 0.5 * float(r.abs().max()) + 1e-6
+            assert m3 <= tol and m3 <= 1.25 * m1 + 1e-7 and r3 <= 1.1 * r1 + 1e-8, (k, m3, m1, r3, r1, tol)
+        y, yd = ops.conv3x3_x3(xd, Wp, Cout, sc, sh, 2, True, downsample=(Wpd, sd.to(dev), hd.to(dev)))
+        full = torch.relu(ref * scale.view(1, -1, 1, 1).double() + shift.view(1, -1, 1, 1).double())
+        fulld = refd * sd.view(1, -1, 1, 1).double() + hd.view(1, -1, 1, 1).double()
+        assert _err(y.cpu(), full)[0] <= 1e-4 and _err(yd.cpu(), fulld)[0] <= 1e-4
+
+
+def test_conv3x3_x3_every_configuration_agrees(dev):
+    """The four tile configurations (knob conv_x3_cfg) are four blockings of the same sums: equal up to the order of fp32 additions."""
+    from deepi2p_amd import ops
+    B, Cin, H, W, Cout = 2, 64, 8, 64, 128
+    x, w, scale, shift, res, *_ = _operands(Cin, H, W, Cout, 1, B, 3)
+    Wt = w.permute(2, 3, 1, 0).reshape(-1, Cout).contiguous().to(dev)
+    Wp = ops.bf16x3_pack(Wt)
+    ref = _ref64(x, w, 1)
+    tol = 3e-6 * (9 * Cin) ** 0.5 * float(ref.abs().max()) + 1e-6
+    one, zero = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+    ran = 0
+    for cfg in range(4):
+        with _lib.option("conv_x3_cfg", cfg):
+            if not ops.conv3x3_x3_supported((B, Cin, H, W), Cout, 1):
+                continue
+            y = ops.conv3x3_x3(x.to(dev), Wp, Cout, one, zero, 1, False).cpu()
+        assert _err(y, ref)[0] <= tol, cfg
+        ran += 1
+    assert ran >= 3
+
+
+def test_conv3x3_x3_argument_checks(dev):
+    from deepi2p_amd import ops
+    assert not ops.conv3x3_x3_supported((1, 64, 8, 24, 64), 64, 1)          # width not a multiple of 16
+    assert not ops.conv3x3_x3_supported((1, 8, 8, 32, 64), 64, 1)           # fewer than 16 input channels
+    assert not ops.conv3x3_x3_supported((1, 64, 7, 32, 64), 64, 2)          # odd height with stride 2
+    x = torch.zeros(1, 64, 8, 24, device=dev)
+    Wp = ops.bf16x3_pack(torch.zeros(576, 64, device=dev))
+    one = torch.ones(64, device=dev)
+    with pytest.raises(_lib.DeepI2PHipError):
+        ops.conv3x3_x3(x, Wp, 64, one, one, 1, False)
+    x = torch.zeros(1, 64, 8, 32, device=dev)
+    with pytest.raises(_lib.DeepI2PHipError):                               # stride 2 comes with its downsample branch
+        ops.conv3x3_x3(x, Wp, 64, one, one, 2, False)
+
+
+def test_image_encoder_same_features_with_and_without_conv_x3(dev):
+    """The whole ResNet-34 with every supported 3x3 layer on the bf16x3 kernel against the fp32-MFMA kernels (Winograd / direct): the stage-3,
+    stage-4 and pooled features agree to fp32 round-off of a 34-layer network."""
+    from deepi2p_amd import synthetic as nt
+    from deepi2p_amd.networks import ImageEncoder
+    opt = nt.OptLike(20480, 160, 512, False)
+    sd = {k[len("img_encoder."):]: v for k, v in nt.synthetic_state_dict(opt).items() if k.startswith("img_encoder.")}
+    enc = ImageEncoder(opt)
+    enc.load_state_dict(sd)
+    enc = enc.to(dev)
+    img = torch.rand(2, 3, 160, 512, generator=torch.Generator().manual_seed(1)).to(dev) * 255
+    with _lib.option("conv_x3", 31):
+        a = [t.clone() for t in enc(img)]
+    with _lib.option("conv_x3", 0):
+        b = [t.clone() for t in enc(img)]
+    for u, v in zip(a, b):
+        assert float((u - v).abs().max()) <= 2e-4 * float(v.abs().max()) + 1e-6
