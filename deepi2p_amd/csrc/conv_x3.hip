@@ -72,7 +72,7 @@ struct CxArgs {
     const u32x4_t* Wp_ds; const float* scale_ds; const float* shift_ds; float* y_ds;      // fused 1x1 / stride-2 branch (DS instances)
     int Cin, H, W, Cout, OH, OW, Mp, Mp_ds;
     int spr, nseg, tiles_per_frame, n_mt;     // segments per output row, per frame; workgroup tiles per frame; Cout tiles
-    int PW, PWH, PP;                          // patch row length, its even-column half (stride 2), entries per channel group (= PRmax * PW)
+    int PW, PWH, PP, PPU;                     // patch row length, its even-column half (stride 2), entries per channel group (PRmax * PW = PPU, rounded up to 16)
     int relu;
 };
 
@@ -80,7 +80,12 @@ struct CxArgs {
 // WM x WN waves; STRIDE 1 / 2; DS: also the 1x1 / stride-2 convolution of the same input (centre tap, own weights and accumulators);
 // DBUF: two patch buffers.  ITEMS: (patch position, channel group) pairs a thread stages per chunk.  PWT: the patch row length W + 2 as a
 // compile-time constant (the nine tap offsets are then immediates of the LDS reads), 0: run-time (one address add per read).
-template <int MF, int TM, int TN, int WM, int WN, int STRIDE, bool DS, bool DBUF, int ITEMS, int PWT>
+// SA: the five small products of a K-step go to a SECOND accumulator set.  The bf16 matrix instructions align every product to the largest
+// addend (normally the accumulator) and TRUNCATE what falls below its last bit (tools/probe_mfma_rounding.hip: 1 + 0.75 ulp -> 1 when the
+// 0.75 ulp is a product of the same instruction): small products added to a large accumulator lose their low bits, with a bias.  Kept apart,
+// they meet an accumulator 2^-8 times smaller.  Measured against fp64 on the four stride-1 shapes: rms error 3.6e-7 -> 1.5e-7 (K = 576) ...
+// 9.1e-7 -> 3.6e-7 (K = 4608), below both fp32-MFMA kernels (4.2e-7 ... 6.3e-7); same speed.  Every shipped instance has it on.
+template <int MF, int TM, int TN, int WM, int WN, int STRIDE, bool DS, bool DBUF, int ITEMS, int PWT, bool SA>
 __global__ __launch_bounds__(256, 1) void conv3x3_x3_kernel(const CxArgs a) {
     typedef Mma<MF> M;
     typedef typename M::acc_t acc_t;
@@ -122,7 +127,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3_kernel(const CxArgs a) {
         const int q = tid + 256 * it;
         const int cig = q / a.PP, pos = q - cig * a.PP, prow = pos / PW, pcol = pos - prow * PW;
         const int irow = irow0 + prow, icol = pcol - 1;
-        const bool in_patch = cig < CIGS;
+        const bool in_patch = cig < CIGS && pos < a.PPU;      // the padding entries behind a channel group's rows are nobody's (with the
+                                                              // parity split of stride 2 their image would land in the NEXT group's first row)
         g_ok[it] = in_patch && prow < PR && irow >= 0 && irow < a.H && icol >= 0 && icol < a.W;
         g_off[it] = g_ok[it] ? (cig * 8 * HW + irow * a.W + icol) * 4 : 0;
         const int pc = STRIDE == 2 ? (pcol & 1) * PWH + (pcol >> 1) : pcol;
@@ -159,13 +165,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3_kernel(const CxArgs a) {
 #pragma unroll
             for (int p = 0; p < 3; ++p) af[slot][i][p] = __builtin_amdgcn_raw_buffer_load_b128(wr, a_off[i], so + p * 16, 0);
     };
-    acc_t acc[TM][TN];
+    acc_t acc[TM][TN], accs[SA ? TM : 1][SA ? TN : 1];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < M::NACC; ++r) acc[i][j][r] = 0.0f;
+            for (int r = 0; r < M::NACC; ++r) {
+                acc[i][j][r] = 0.0f;
+                if constexpr (SA) accs[i][j][r] = 0.0f;
+            }
     // fused downsample branch: own descriptor, offsets, accumulators
     acc_t acc_ds[DS ? TM : 1][DS ? TN : 1];
     u32x4_t af_ds[DS ? TM : 1][3];
@@ -206,10 +215,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3_kernel(const CxArgs a) {
     };
     // one tap of one chunk: six products per tile, smallest terms first; consecutive matrix instructions write different accumulators
     auto tap_mma = [&](int slot, int set, int tap) __attribute__((always_inline)) {
-#define DI2P_CX_PROD(QA, QB)                                                                                                            \
+#define DI2P_CX_PROD(ACC, QA, QB)                                                                                                       \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                                       \
-        acc[i][j] = M::mma(af[slot][i][QA], bf[set][j][QB], acc[i][j]);
-        DI2P_CX_PROD(2, 0) DI2P_CX_PROD(1, 1) DI2P_CX_PROD(0, 2) DI2P_CX_PROD(1, 0) DI2P_CX_PROD(0, 1) DI2P_CX_PROD(0, 0)
+        ACC[i][j] = M::mma(af[slot][i][QA], bf[set][j][QB], ACC[i][j]);
+        if constexpr (SA) {
+            DI2P_CX_PROD(accs, 2, 0) DI2P_CX_PROD(accs, 1, 1) DI2P_CX_PROD(accs, 0, 2) DI2P_CX_PROD(accs, 1, 0) DI2P_CX_PROD(accs, 0, 1)
+        } else {
+            DI2P_CX_PROD(acc, 2, 0) DI2P_CX_PROD(acc, 1, 1) DI2P_CX_PROD(acc, 0, 2) DI2P_CX_PROD(acc, 1, 0) DI2P_CX_PROD(acc, 0, 1)
+        }
+        DI2P_CX_PROD(acc, 0, 0)
 #undef DI2P_CX_PROD
         if constexpr (DS) {
             if (tap == 4) {
@@ -238,9 +252,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3_kernel(const CxArgs a) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             constexpr int NM = TM * TN * 6, NB = 3 * TN, NA = 3 * TM;
-            // the operands of the next K-step (next tap, or the weights of tap 0 of the next chunk; past the end: a valid, unused address)
-            if (tap < 8) { a_load((tap + 1) % 3, tap + 1, c); b_read((tap + 1) & 1, tap + 1); }
-            else a_load(0, 0, min(c + 1, NC - 1));
+            // the B fragments of the next K-step and the A fragments of the one after it (ring of three slots, 9 % 3 == 0: slot = tap % 3 in
+            // every chunk; past the end: a valid, unused address).  Two K-steps ahead because memory returns a wave's loads IN ORDER: the wait
+            // for these weights also waits for every staged-patch load issued before them, which comes from HBM
+            if (tap < 8) b_read((tap + 1) & 1, tap + 1);
+            if (tap < 7) a_load((tap + 2) % 3, tap + 2, c);
+            else a_load((tap + 2) % 3, tap - 7, min(c + 1, NC - 1));
             tap_mma(tap % 3, tap & 1, tap);
             const bool stores = STAGE && DBUF && tap >= 3 && tap - 3 < ITEMS, loads = STAGE && tap < ITEMS;
             if (stores) stage_store(tap - 3, buf ^ 1);
@@ -250,8 +267,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3_kernel(const CxArgs a) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    // one matrix instruction
                 if (i < NA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                        // one A request
                 else if (i < NA + NB && tap < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one B request
+                if (loads && i >= NA && i < NA + 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // one load of the item fetched in this tap
                 if (stores) __builtin_amdgcn_sched_group_barrier(0x002, (56 + NM - 1) / NM, 0);       // the split: ~56 vector instructions
-                if (loads && i >= NM - 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // one load of the item fetched in this tap
             }
             if (stores) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -268,34 +285,61 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3_kernel(const CxArgs a) {
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) stage_store(it, 0);
     a_load(0, 0, 0);
+    a_load(1, 1, 0);
     __syncthreads();
     for (int c = 0; c + 1 < NC; ++c) chunk(c, std::true_type{});
     chunk(NC - 1, std::false_type{});
 
     // ---- epilogue
-    auto store = [&](const acc_t (&ac)[TM][TN], const float* scale, const float* shift, const float* res, float* y, bool relu) {
+    if constexpr (SA) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int co0 = mt * MT + (wm * TM + i) * MF;
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] += accs[i][j];
+    }
+    // Every load of the epilogue (folded BatchNorm rows, residual) is requested before the first result is formed, and nothing in it
+    // branches: hipcc otherwise waits for each residual value (and the store before it) in turn -- eighty memory round trips per wave.
+    // Buffer addressing drops what must not be written (segments past the frame, channels past Cout): their offset is out of range.
+    auto store = [&](const acc_t (&ac)[TM][TN], const float* scale, const float* shift, const float* res, float* y, bool relu,
+                     auto res_tag) __attribute__((always_inline)) {
+        constexpr bool RES = decltype(res_tag)::value;
+        constexpr int OOB = 0x40000000;
+        const int bytes = a.Cout * OHW * 4;
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (long long)b * a.Cout * OHW), 0, bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)((RES ? res : y) + (long long)b * a.Cout * OHW), 0, bytes, 0x00020000);
+        int so[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) so[j] = sval[j] ? ooff[j] * 4 : OOB;
+        float sc[TM][M::NACC], sh[TM][M::NACC], rv[TM][TN][RES ? M::NACC : 1];
+        int co_off[TM][M::NACC];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < M::NACC; ++r) {
-                const int co = co0 + M::row(r, cl);
-                if (co >= a.Cout) continue;
-                const float sc = scale[co], sh = shift[co];
-                const long long ch = ((long long)b * a.Cout + co) * OHW;
+                const int co = mt * MT + (wm * TM + i) * MF + M::row(r, cl), cc = min(co, a.Cout - 1);
+                sc[i][r] = scale[cc]; sh[i][r] = shift[cc];
+                co_off[i][r] = co < a.Cout ? co * OHW * 4 : OOB;
+                if constexpr (RES) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (!sval[j]) continue;
-                    float v = ac[i][j][r] * sc + sh;
-                    if (res) v += res[ch + ooff[j]];
-                    if (relu) v = fmaxf(v, 0.0f);
-                    y[ch + ooff[j]] = v;
+                    for (int j = 0; j < TN; ++j)
+                        rv[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, co_off[i][r] + so[j], 0, 0));
                 }
             }
-        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < M::NACC; ++r)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float v = ac[i][j][r] * sc[i][r] + sh[i][r];
+                    if constexpr (RES) v += rv[i][j][r];
+                    v = relu ? fmaxf(v, 0.0f) : v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, co_off[i][r] + so[j], 0, 0);
+                }
     };
-    store(acc, a.scale, a.shift, a.residual, a.y, a.relu != 0);
-    if constexpr (DS) store(acc_ds, a.scale_ds, a.shift_ds, nullptr, a.y_ds, false);
+    if (a.residual) store(acc, a.scale, a.shift, a.residual, a.y, a.relu != 0, std::true_type{});
+    else store(acc, a.scale, a.shift, a.residual, a.y, a.relu != 0, std::false_type{});
+    if constexpr (DS) store(acc_ds, a.scale_ds, a.shift_ds, nullptr, a.y_ds, false, std::false_type{});
 }
 
 struct CxCfg { int MF, TM, TN, WM, WN; };
@@ -303,7 +347,7 @@ constexpr CxCfg kCfgs[4] = {{32, 1, 5, 2, 2}, {32, 1, 5, 4, 1}, {16, 2, 5, 4, 1}
 constexpr int CX_LDS_MAX = 160 * 1024;
 
 struct CxPlan {
-    int cfg = -1, items = 0, dbuf = 0, tiles_per_frame = 0, n_mt = 0, PW = 0, PWH = 0, PP = 0, spr = 0, nseg = 0;
+    int cfg = -1, items = 0, dbuf = 0, tiles_per_frame = 0, n_mt = 0, PW = 0, PWH = 0, PP = 0, PPU = 0, spr = 0, nseg = 0;
     long long lds = 0, cost = 0;
 };
 
@@ -324,23 +368,28 @@ CxPlan cx_plan(int ci, int B, int Cin, int H, int W, int Cout, int stride) {
         rows = r > rows ? r : rows;
     }
     const int PRmax = stride * (rows - 1) + 3;
-    p.PW = W + 2; p.PWH = (p.PW + 1) / 2; p.PP = PRmax * p.PW;
+    // entries per channel group, a multiple of 16: with 16-pixel segments the four channel groups of a wave's ds_read_b128 then fall on
+    // disjoint bank sets (48-byte entries: 16 of them are 3 x 256 bytes)
+    p.PW = W + 2; p.PWH = (p.PW + 1) / 2; p.PPU = PRmax * p.PW; p.PP = (p.PPU + 15) / 16 * 16;
     const long long buf = (long long)CIGS * p.PP * 48 + 48;
     if (2 * buf <= CX_LDS_MAX - 1024) { p.dbuf = 1; p.lds = 2 * buf; }
     else if (buf <= CX_LDS_MAX - 1024) { p.dbuf = 0; p.lds = buf; }
     else return p;
     p.items = di2p_cdiv((long long)CIGS * p.PP, 256);
     if (p.items > 8) return p;
-    const long long wgs = (long long)B * p.tiles_per_frame * p.n_mt;
+    // the choice must not depend on the batch a frame is in (different blockings add in different orders: a frame's result would change
+    // with the batch size): priced for the nominal 32-frame step whatever B is
+    (void)B;
+    const long long wgs = 32ll * p.tiles_per_frame * p.n_mt;
     const long long per_wg = (long long)(Cin / KS) * 9 * c.TM * c.TN * 6 * (c.MF == 32 ? 32 : 16) + (long long)(Cin / KS) * p.items * 400 * (p.dbuf ? 1 : 4);
     p.cost = di2p_cdiv(wgs, di2p_cu_count()) * per_wg;
     p.cfg = ci;
     return p;
 }
 
-template <int MF, int TM, int TN, int WM, int WN, int STRIDE, bool DS, bool DBUF, int ITEMS, int PWT>
+template <int MF, int TM, int TN, int WM, int WN, int STRIDE, bool DS, bool DBUF, int ITEMS, int PWT, bool SA>
 void cx_launch_one(const CxArgs& a, int grid, size_t lds, hipStream_t st) {
-    auto k = conv3x3_x3_kernel<MF, TM, TN, WM, WN, STRIDE, DS, DBUF, ITEMS, PWT>;
+    auto k = conv3x3_x3_kernel<MF, TM, TN, WM, WN, STRIDE, DS, DBUF, ITEMS, PWT, SA>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
 }
@@ -374,7 +423,10 @@ int cx_find_instance(int cfg, int stride, int dbuf, int need, int pw) {
 bool cx_launch(int inst, const CxPlan& p, const CxArgs& a, int grid, hipStream_t st) {
     int i = 0;
 #define DI2P_CX_CASE(CFG, MF, TM, TN, WM, WN, STRIDE, DBUF, ITEMS, PWT)                                                                \
-    if (inst == i++) { cx_launch_one<MF, TM, TN, WM, WN, STRIDE, STRIDE == 2, DBUF != 0, ITEMS, PWT>(a, grid, (size_t)p.lds, st); return true; }
+    if (inst == i++) {                                                                                                                 \
+        cx_launch_one<MF, TM, TN, WM, WN, STRIDE, STRIDE == 2, DBUF != 0, ITEMS, PWT, true>(a, grid, (size_t)p.lds, st);              \
+        return true;                                                                                                                    \
+    }
     DI2P_CX_INSTANCES(DI2P_CX_CASE)
 #undef DI2P_CX_CASE
     return false;
@@ -422,6 +474,7 @@ extern "C" int di2p_conv3x3_x3(const float* x, const void* Wp, const float* scal
     const bool ds = Wp_ds != nullptr;
     DI2P_CHECK_ARG(ds == (stride == 2), "stride 2 runs WITH the fused 1x1 / stride-2 branch of the same input (and only stride 2 has one)");
     DI2P_CHECK_ARG(!ds || (scale_ds && shift_ds && y_ds), "the fused 1x1 branch needs its scale / shift / output");
+    DI2P_CHECK_ARG((long long)Cout * H * W * 4 < (1ll << 30), "per-frame output must stay below 2^30 bytes");
     DI2P_CHECK_ARG((long long)Cin * H * W * 4 < (1ll << 31) && (long long)9 * (Cin / 8) * (di2p_cdiv(Cout, 128) * 128) * 48 < (1ll << 31),
                    "per-frame input and the packed weights must fit 31-bit byte offsets");
     if (B == 0) return 0;
@@ -434,7 +487,7 @@ extern "C" int di2p_conv3x3_x3(const float* x, const void* Wp, const float* scal
     a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.OH = (H - 1) / stride + 1; a.OW = (W - 1) / stride + 1;
     a.Mp = di2p_cdiv(Cout, 128) * 128; a.Mp_ds = a.Mp;
     a.spr = best.spr; a.nseg = best.nseg; a.tiles_per_frame = best.tiles_per_frame; a.n_mt = best.n_mt;
-    a.PW = best.PW; a.PWH = best.PWH; a.PP = best.PP; a.relu = relu;
+    a.PW = best.PW; a.PWH = best.PWH; a.PP = best.PP; a.PPU = best.PPU; a.relu = relu;
     const long long grid = (long long)B * best.tiles_per_frame * best.n_mt;
     DI2P_CHECK_ARG(grid < (1ll << 31), "too many workgroups");
     hipStream_t st = (hipStream_t)stream;
