@@ -10,7 +10,7 @@ sweeps with a heavy tail, several classifier kernels have fewer workgroups than 
   * the ~150 launches of a step are captured ONCE per slot into a hipGraph (every entry point of the C-ABI library is
     capture-safe: no allocation, no synchronisation) and replayed; the H2D copies read the slot's pinned buffers on a second stream
     per slot (SDMA engines; as memcpy nodes of the graph they would run as blit kernels on the CUs), so `submit(host_batch)` is:
-    memcpy into pinned memory + six async copies + one graph launch;
+    memcpy into pinned memory + ONE async copy of the slot's flat staging buffer (all seven inputs) + one graph launch;
   * results stay on the device until `result()` is asked for them (one event per slot).
 
 `bench.py` is a thin caller of this class.  Environment: more than 3 streams need GPU_MAX_HW_QUEUES >= S (set before the HIP
@@ -41,10 +41,27 @@ class Slot:
         self.start = torch.cuda.Event(enable_timing=True)
         self.outputs = None
         self.busy = False
+        self.host_flat, self.dev_flats = None, []         # ONE pinned staging buffer / ONE device buffer per input set: host[k] / devs[j][k] are views
 
     @property
     def dev(self):
         return self.devs[self.cur]
+
+    def copy_in(self, j=None):
+        """The step's host->device transfer of ALL inputs of the slot: one asynchronous copy of the flat staging buffer (seven tensors, one
+        DMA command) on the current stream."""
+        self.dev_flats[self.cur if j is None else j].copy_(self.host_flat, non_blocking=True)
+
+
+def _flat_views(flat, layout):
+    """Typed views into a flat uint8 buffer: layout = [(name, offset, shape, dtype)]."""
+    out = {}
+    for name, off, shape, dtype in layout:
+        n = 1
+        for v in shape:
+            n *= int(v)
+        out[name] = flat[off:off + n * torch.empty((), dtype=dtype).element_size()].view(dtype).view(shape)
+    return out
 
 
 class RegistrationExecutor:
@@ -109,16 +126,26 @@ class RegistrationExecutor:
             s.net_done = torch.cuda.Event()
             s.copy_stream = torch.cuda.Stream(device=self.device) if h2d_mode == "copy_stream" else None
             s.copied = torch.cuda.Event()
+            # one flat pinned buffer and one flat device buffer hold all seven inputs (256-byte aligned pieces): a step's transfer is ONE copy
+            layout, off = [], 0
+            for k in INPUT_NAMES + (K_NAME,):
+                shape, dtype = ((B, 3, 3), torch.float64) if k == K_NAME else (tuple(example_batch[k].shape), example_batch[k].dtype)
+                n = 1
+                for v in shape:
+                    n *= int(v)
+                layout.append((k, off, shape, dtype))
+                off = (off + n * torch.empty((), dtype=dtype).element_size() + 255) // 256 * 256
+            s.host_flat = torch.empty((off,), dtype=torch.uint8).pin_memory()
+            s.host = _flat_views(s.host_flat, layout)
             for k in INPUT_NAMES:
-                t = example_batch[k]
-                s.host[k] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
-                s.host[k].copy_(t)
-                s.devs[0][k] = t.to(self.device, non_blocking=False).contiguous()
-            s.host[K_NAME] = torch.empty((B, 3, 3), dtype=torch.float64).pin_memory()
+                s.host[k].copy_(example_batch[k])
             s.host[K_NAME].copy_(self._K64_host)
-            s.devs[0][K_NAME] = self.K64.clone()
-            if self.double_buffer:
-                s.devs.append({k: v.clone() for k, v in s.devs[0].items()})
+            n_sets = 2 if self.double_buffer else 1
+            s.devs = []
+            for _ in range(n_sets):
+                flat = s.host_flat.to(self.device, non_blocking=False)
+                s.dev_flats.append(flat)
+                s.devs.append(_flat_views(flat, layout))
             self.slots.append(s)
         self._next = 0
         self._h2d_warm = False
@@ -130,8 +157,7 @@ class RegistrationExecutor:
     def _step(self, slot, with_h2d):
         """Enqueue one step on the CURRENT stream (the slot's stream, or the capturing stream)."""
         if with_h2d:        # a1: MMClassifer.set_input's copies (multimodal_classifier.py:82-93), from the slot's pinned buffers
-            for k in INPUT_NAMES + (K_NAME,):
-                slot.dev[k].copy_(slot.host[k], non_blocking=True)
+            slot.copy_in()
         d = slot.dev
         if self.step_fn is not None:
             return self.step_fn(slot, d)
@@ -177,8 +203,7 @@ class RegistrationExecutor:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, stream=slot.stream, **kw):
                 if with_h2d:
-                    for k in INPUT_NAMES + (K_NAME,):
-                        slot.dev[k].copy_(slot.host[k], non_blocking=True)
+                    slot.copy_in()
                 net = self._net_part(slot)
             torch.cuda.synchronize(self.device)
             with torch.cuda.graph(gb, stream=slot.solver_stream, pool=ga.pool()):
@@ -233,9 +258,8 @@ class RegistrationExecutor:
             # slot here, like the graph capture above, not inside somebody's first timed steps
             for slot in self.slots:
                 with torch.cuda.stream(slot.copy_stream if slot.copy_stream is not None else slot.stream):
-                    for d in slot.devs:
-                        for k in INPUT_NAMES + (K_NAME,):
-                            d[k].copy_(slot.host[k], non_blocking=True)
+                    for j in range(len(slot.devs)):
+                        slot.copy_in(j)
             self._h2d_warm = True
         self._warmed.add(want_h2d)
         torch.cuda.synchronize(self.device)
@@ -286,14 +310,12 @@ class RegistrationExecutor:
                 slot.cur ^= 1                                     # the set the slot's step BEFORE the previous one read
             with torch.cuda.stream(slot.copy_stream):
                 slot.copy_stream.wait_event(slot.set_done[slot.cur])      # the last step that read this input set
-                for k in names:
-                    slot.dev[k].copy_(slot.host[k], non_blocking=True)
+                slot.copy_in()
                 slot.copied.record()
         with torch.cuda.stream(slot.stream):
             slot.start.record()
             if with_h2d and self.h2d_mode == "eager":
-                for k in names:
-                    slot.dev[k].copy_(slot.host[k], non_blocking=True)
+                slot.copy_in()
             elif with_h2d and self.h2d_mode == "copy_stream":
                 slot.stream.wait_event(slot.copied)
             if self.use_graph:

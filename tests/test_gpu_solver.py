@@ -180,9 +180,55 @@ def test_two_tier_launch_agrees_with_single_launch(dev):
         with _lib.option("solver_tier_sweeps", tier):
             b = run()
         ok = _agreement(a[0], b[0], True)
-        assert ok.mean() >= 0.9, (tier, ok)     # a parked hypothesis may end in a neighbouring minimum (other summation order); most must not
+        # a parked hypothesis may end in a neighbouring minimum (the wide tier adds its wave partials in another order): the ones that do
+        # are ENUMERATED in KNOWN_FORKS; one more is a failure
+        _check_forks(("two_tier", tier), ok)
         np.testing.assert_allclose(b[1][ok], a[1][ok], rtol=1e-6)
         assert abs(b[1].min() - a[1].min()) <= 1e-6 * a[1].min()
+
+
+@pytest.mark.parametrize("seed,is_2d,N", [(101, True, 4096), (102, True, 20480), (103, False, 3000), (104, False, 9000)])
+def test_classification_cache_is_bit_identical_in_both_tiers(dev, seed, is_2d, N):
+    """Round-4 advisor finding: the classification cache (recorded masks re-used while the iterate's motion stays below the recorded slack;
+    constants 1.0001 mu + 1e-6, the 0.99999 re-record factor, RING / 2 refresh) was compared with `solver_nocache` on a few fixed seeds of the
+    2-D path in the narrow tier only.  Here: random scenes, the 2-D and the 3-D path, and BOTH tiers (the wide tier resumes parked hypotheses
+    from an empty cache) -- each tier with the cache on against the SAME tier with it off, bit for bit, and the cache must actually have been
+    hit (profile counters of the PROFILE instantiation)."""
+    from deepi2p_amd import ops, _lib
+    rng = np.random.default_rng(seed)
+    f = synthetic.make_frame(rng, N=N, H=H, W=W, flip=0.05, with_image=False)
+    _, y0, pcf, labf = flm.get_initial_guess(f["pc"].astype(np.float64), f["labels"])
+    R = 16
+    ys, Ts = flm.draw_restarts(rng, R, y0, 10 * math.pi / 180, 10)
+    pts = torch.from_numpy(np.ascontiguousarray(pcf.astype(np.float32))).to(dev).unsqueeze(0)
+    args = (pts, torch.from_numpy(np.ascontiguousarray(labf.astype(np.int32))).to(dev).unsqueeze(0),
+            torch.from_numpy(np.ascontiguousarray(f["K"])).to(dev).view(1, 3, 3), torch.from_numpy(np.ascontiguousarray(ys)).to(dev).view(1, R),
+            torch.from_numpy(np.ascontiguousarray(Ts)).to(dev).view(1, R, 3), H, W, LB, UB, 500, is_2d)
+
+    def run(profile=False):
+        sweeps = torch.zeros((1, R), dtype=torch.int32, device=dev)
+        prof = torch.zeros((R, 20), dtype=torch.int64, device=dev) if profile else None
+        if profile:
+            _lib.load().di2p_solver_set_profile_buffer(prof.data_ptr())
+        try:
+            params, cost, iters = ops.solve_batched(*args, sweeps=sweeps)
+            torch.cuda.synchronize()
+        finally:
+            if profile:
+                _lib.load().di2p_solver_set_profile_buffer(None)
+        out = (params.cpu().numpy(), cost.cpu().numpy(), iters.cpu().numpy(), sweeps.cpu().numpy())
+        return out + ((prof.cpu().numpy(),) if profile else ())
+    for tier in (0, 8):
+        with _lib.option("solver_tier_sweeps", tier):
+            on = run()
+            with _lib.option("solver_nocache", 1):
+                off = run()
+            for u, v in zip(on, off):
+                assert u.tobytes() == v.tobytes(), (tier, is_2d)
+            prof = run(profile=True)[4]
+        # columns 16 / 17: clusters whose recorded mask was re-used / whose guard walk was skipped (wave 0, summed over the sweeps)
+        assert prof[:, 16].sum() > 0 and prof[:, 17].sum() > 0, (tier, prof[:, 16].sum(), prof[:, 17].sum())
+        assert on[3].max() > 8                      # tier 8 did park hypotheses
 
 
 def test_solvePGivenK_drop_in(dev):
@@ -269,7 +315,8 @@ def test_small_and_ragged_frames(dev, N):
                                                   (33, True, 20480, (160, 512), 0.05)])
 def test_solver_matches_oracle_other_cameras(dev, seed, is_2d, N, HW, flip):
     """Same parity statement as above on other image sizes / intrinsics / label noise (the cluster shortcut and the
-    cost-only line-search sweeps must not move any iterate: >= 90 % of hypotheses agree, best cost to 1e-6)."""
+    cost-only line-search sweeps must not move any iterate: EVERY hypothesis agrees -- KNOWN_FORKS is empty --, costs and the best cost
+    to 1e-6, equal iteration counts)."""
     from deepi2p_amd import registration
     h, w = HW
     rng = np.random.default_rng(seed)

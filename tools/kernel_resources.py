@@ -35,8 +35,8 @@ def main():
         n = re.sub(r"\(.*", "", n)
         if filt and filt not in n:
             continue
-        print("%-90s %5s %5s %5s %6s %6s %7s %4s %7s" % (n[:90], r.get("VGPRs"), r.get("AGPRs"), r.get("TotalSGPRs"), r.get("VGPR Spill"),
-                                                      r.get("SGPR Spill"), r.get("ScratchSize [bytes/lane]"), r.get("Occupancy [waves/SIMD]"), r.get("LDS Size [bytes/block]")))
+        print("%-90s %5s %5s %5s %6s %6s %7s %4s %7s" % (n[:90], r.get("VGPRs"), r.get("AGPRs"), r.get("TotalSGPRs"), r.get("VGPRs Spill", r.get("VGPR Spill")),
+                                                      r.get("SGPRs Spill", r.get("SGPR Spill")), r.get("ScratchSize [bytes/lane]"), r.get("Occupancy [waves/SIMD]"), r.get("LDS Size [bytes/block]")))
 
 
 main()
