@@ -31,6 +31,13 @@ class EpilogueT(ctypes.Structure):
                 ("g_nodes", c_int * 2), ("g_k", c_int * 2), ("transpose_out", c_int), ("group_max_out", c_void_p)]
 
 
+class HeadX3T(ctypes.Structure):      # di2p_head_x3_t
+    _fields_ = [("src", c_void_p * 2), ("batch_stride", c_ll * 2), ("row_stride", c_int * 2), ("channels", c_int * 2),
+                ("W0p", c_void_p), ("W1p", c_void_p), ("scale_shift", c_void_p), ("relu0", c_int), ("relu1", c_int),
+                ("tab", c_void_p * 2), ("idx", c_void_p * 2), ("w", c_void_p * 2), ("nodes", c_int * 2),
+                ("W2t", c_void_p), ("scale2", c_void_p), ("shift2", c_void_p), ("relu2", c_int), ("P", c_int)]
+
+
 SRC_DENSE, SRC_GATHER, SRC_GROUP = 0, 1, 2
 
 # name -> argtypes (all return int)
@@ -87,6 +94,8 @@ _SIGS = {
     "di2p_conv3x3_winograd": [c_void_p] * 6 + [c_int] * 6 + [c_void_p],
     "di2p_conv3x3_x3": [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 5,
     "di2p_conv3x3_x3_supported": [c_int] * 6,
+    "di2p_head_x3_pack": [c_void_p, c_int, c_void_p, c_void_p],
+    "di2p_point_head_x3": [ctypes.POINTER(HeadX3T), c_void_p, c_int, c_int, c_void_p],
     "di2p_bn_train_forward": [c_void_p] * 9 + [c_float, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "di2p_bn_train_backward": [c_void_p] * 6 + [c_int] + [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p, c_void_p],
     "di2p_channel_sum": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
@@ -108,6 +117,7 @@ _WS_SIGS = {        # <name>_workspace_bytes helpers returning long long
     "di2p_gather_backward_workspace_bytes": [c_int] * 4,
     "di2p_conv2d_wgrad_workspace_bytes": [c_int] * 9,
     "di2p_bf16x3_packed_bytes": [c_int] * 2,
+    "di2p_head_x3_packed_bytes": [c_int],
 }
 EXPORTS = sorted(list(_SIGS) + ["di2p_last_error", "di2p_version", "di2p_solve_workspace_bytes", "di2p_solver_set_profile_buffer", "di2p_pnp_workspace_bytes",
                  "di2p_conv2d_workspace_bytes", "di2p_set_option", "di2p_get_option", "di2p_random_choice_workspace_bytes", "di2p_classifier_loss_workspace_bytes"] + list(_WS_SIGS))

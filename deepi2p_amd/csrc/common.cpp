@@ -17,7 +17,7 @@ void di2p_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* di2p_last_error(void) { return g_err; }
-extern "C" int di2p_version(void) { return 4; }
+extern "C" int di2p_version(void) { return 5; }
 
 namespace {
 struct OptDef { const char* name; const char* env; long long def; };
@@ -37,6 +37,7 @@ const OptDef kOpts[DI2P_OPT_COUNT] = {
     {"pw_x3", "DI2P_PW_X3", 1},                     {"pw_nochain", "DI2P_PW_NOCHAIN", 0},
     {"head_reg", "DI2P_HEAD_REG", 0},               {"conv_s2scalar", "DI2P_CONV_S2SCALAR", 0},
     {"conv_x3", "DI2P_CONV_X3", 31},                 {"conv_x3_cfg", "DI2P_CONV_X3_CFG", -1},
+    {"head_x3", "DI2P_HEAD_X3", 1},                 {"head_x3_tab", "DI2P_HEAD_X3_TAB", 1},
 };
 long long g_opt[DI2P_OPT_COUNT];
 std::once_flag g_opt_once;

@@ -436,7 +436,8 @@ bool cx_launch(int inst, const CxPlan& p, const CxArgs& a, int grid, hipStream_t
 CxPlan cx_best(int B, int Cin, int H, int W, int Cout, int stride, long long force, int* inst_out) {
     CxPlan best;
     for (int ci = 0; ci < 4; ++ci) {
-        if (force >= 0 && force != ci) continue;
+        if (force >= 0 && force < 4 && force != ci) continue;
+        if (force >= 4 && ((force >> 2) & (1 << ci)) == 0) continue;      // force = 4 * (bit mask of admitted configurations): experiments
         CxPlan p = cx_plan(ci, B, Cin, H, W, Cout, stride);
         if (p.cfg < 0) continue;
         int inst = cx_find_instance(ci, stride, p.dbuf, p.items, p.PW);

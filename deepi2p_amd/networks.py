@@ -407,6 +407,15 @@ class KeypointDetector(_PackedModule):
             # node_b_pn layer 0: channel order [node_b_feat 256 | global 512 (bcast) | w_s32 512 | img_global 512 (bcast)]
             Wt = p["node_b_pn"][0][0]
             p["node_b_pn_dense_Wt"] = torch.cat((Wt[0:256], Wt[768:1280]), dim=0).contiguous()
+            # the coarse head on the bf16 matrix instructions (di2p_point_head_x3): the dense rows of layer 0 and layer 1, split once into
+            # fragment order; the folded scale / shift rows as one [4,128] block.  Owned by this container like every derived operand.
+            l0, l1, l2 = p["per_point_pn"]
+            if (l0[0].is_cuda and tuple(l0[0].shape) == (736, 128) and tuple(l1[0].shape) == (128, 128) and l2[0].shape[0] == 128
+                    and l2[0].shape[1] <= 4 and not l0[0].requires_grad):
+                ones = torch.ones(128, device=l0[0].device)
+                p["head_x3"] = {"W0p": ops.head_x3_pack(l0[0][640:736].contiguous()), "W1p": ops.head_x3_pack(l1[0]),
+                                "ss": torch.stack((l0[1] if l0[1] is not None else ones, l0[2], l1[1] if l1[1] is not None else ones, l1[2])).contiguous(),
+                                "relu0": l0[3], "relu1": l1[3], "W2t": l2[0], "sc2": l2[1], "sh2": l2[2], "relu2": l2[3]}
             self._packed = p
         return self._packed
 
@@ -454,7 +463,12 @@ class KeypointDetector(_PackedModule):
         G_b = ops.pointwise_gemm([Src(up_b)], Wt[128:640], M0, Mb, transpose_out=True)
         gathered = [(G_a, idx_a, ex["w_a"]), (G_b, idx_pb, w_pb)]
         l1, l2 = p["per_point_pn"][1], p["per_point_pn"][2]
-        if M0 == 128 and l1[0].shape[1] == 128 and l2[0].shape[1] <= 4 and N % 4 == 0 and self.fuse_head:
+        if ("head_x3" in p and self.fuse_head and _lib.get_option("head_x3") and first.shape[1] == 32 and second.shape[1] == 64
+                and idx_a.shape[-1] == 3 and idx_pb.shape[-1] == 3):
+            # coarse head, round 5: one wave-autonomous launch on the bf16 matrix instructions (exact three-way splits), node tables in LDS
+            scores = ops.point_head_x3(first, second, p["head_x3"],
+                                       [(G_a, idx_a.reshape(B, N, 3), ex["w_a"]), (G_b, idx_pb.reshape(B, N, 3), w_pb)], N)
+        elif M0 == 128 and l1[0].shape[1] == 128 and l2[0].shape[1] <= 4 and N % 4 == 0 and self.fuse_head:
             # coarse head: the three layers in one launch, hidden activations stay in LDS (bit-identical to the chain below)
             scores = ops.point_head([Src(first), Src(second)], (Wt[640:736], sc, sh, act), l1, l2, N, gathered=gathered)
         else:

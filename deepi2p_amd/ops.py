@@ -295,6 +295,47 @@ def point_head(srcs, layer0, layer1, layer2, N, batch_bias=None, gathered=None):
     return out
 
 
+def head_x3_pack(Wt):
+    """Wt f32[K,128] (contiguous, K % 16 == 0) -> the fragment-ordered split operand of di2p_point_head_x3 (uint8 storage)."""
+    require_cuda(Wt)
+    K, M = Wt.shape
+    if M != 128 or K % 16 or not Wt.is_contiguous():
+        raise RuntimeError("head_x3_pack needs a contiguous f32[K,128] with K % 16 == 0")
+    Wp = torch.empty((_lib.load().di2p_head_x3_packed_bytes(K),), dtype=torch.uint8, device=Wt.device)
+    call("di2p_head_x3_pack", ptr(Wt), K, ptr(Wp), stream())
+    return Wp
+
+
+def point_head_x3(src0, src1, packed, gathered, N):
+    """The coarse per-point head in one launch on the bf16 matrix instructions (di2p_point_head_x3).  src0 / src1: dense f32[B,ch,N];
+    packed: dict W0p, W1p (head_x3_pack), ss f32[4,128] (scale0, shift0, scale1, shift1), relu0, relu1, W2t f32[128,P], sc2, sh2, relu2;
+    gathered: [(table f32[B,nodes,128], idx i32[B,N,3], w f32[B,N,3] | None)] x 2.  -> f32[B,P,N]."""
+    require_cuda(src0, src1, packed["W0p"], packed["W1p"], packed["ss"], packed["W2t"], packed["sc2"], packed["sh2"])
+    B = src0.shape[0]
+    P = packed["W2t"].shape[1]
+    h = _lib.HeadX3T()
+    for t, x in enumerate((src0, src1)):
+        _chk(x, _f32, "head source")
+        if x.dim() != 3 or x.shape[2] != N or x.stride(2) != 1:
+            raise RuntimeError("head sources must be [B, ch, N] with unit column stride")
+        h.src[t], h.batch_stride[t], h.row_stride[t], h.channels[t] = ptr(x), x.stride(0), x.stride(1), x.shape[1]
+    for t, (tab, gi, gw) in enumerate(gathered):
+        require_cuda(tab, gi, gw)
+        _chk(tab, _f32, "gathered table")
+        _chk(gi, _i32, "gathered index")
+        if tuple(tab.shape[0::2]) != (B, 128) or tuple(gi.shape) != (B, N, 3) or (gw is not None and tuple(gw.shape) != (B, N, 3)):
+            raise RuntimeError("the head takes node tables [B,nodes,128] with three neighbours per point")
+        h.tab[t], h.idx[t], h.w[t], h.nodes[t] = ptr(tab), ptr(gi), ptr(gw), tab.shape[1]
+    h.W0p, h.W1p, h.scale_shift = ptr(packed["W0p"]), ptr(packed["W1p"]), ptr(packed["ss"])
+    h.relu0, h.relu1, h.relu2, h.P = int(bool(packed["relu0"])), int(bool(packed["relu1"])), int(bool(packed["relu2"])), P
+    h.W2t, h.scale2, h.shift2 = ptr(packed["W2t"]), ptr(packed["sc2"]), ptr(packed["sh2"])
+    out = torch.empty((B, P, N), dtype=_f32, device=src0.device)
+    if _lib.WORK is not None:
+        _lib.WORK["di2p_point_head_x3"] = _lib.WORK.get("di2p_point_head_x3", 0) + B * N * ((src0.shape[1] + src1.shape[1]) * 128 + 128 * 128 + 128 * P)
+    call("di2p_point_head_x3", ctypes.byref(h), ptr(out), B, N, stream())
+    return out
+
+
 def point_chain_ok(srcs, layers, N):
     """Can di2p_point_chain run these layers ((Wt, scale, shift, relu) tuples; layers[0].Wt holds the rows of the dense `srcs`)?"""
     if len(layers) not in (2, 3) or len(srcs) != 1 or _lib.get_option("pw_nochain"):

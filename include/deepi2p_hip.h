@@ -203,6 +203,22 @@ long long di2p_conv2d_workspace_bytes(int B, int Cin, int H, int W, int Cout, in
 int di2p_winograd_weight_transform(const float* weight, float* U, int Cin, int Cout, void* stream);
 int di2p_conv3x3_winograd(const float* x, const float* U, const float* scale, const float* shift, const float* residual, float* y, int B,
                           int Cin, int H, int W, int Cout, int relu, void* stream);
+/* The coarse per-point head (per_point_pn, models/networks_united.py:57-74 applied at :188-197: 736 -> 128 -> 128 -> P) in ONE launch on the bf16
+ * matrix instructions with exact three-way fp32 splits, wave-autonomous (a wave keeps all 128 channels of 32 points in registers through the three
+ * layers).  Layer 0 = the dense channels of the point (two sources f32[B, ch, N], channels multiples of 16) through W0 PLUS the per-node products
+ * of its interpolated inputs, gathered from two node-major tables f32[B, nodes, 128] (3 neighbours each, idx i32[B,N,3], weights f32[B,N,3] or NULL
+ * = 1) -- the same decomposition as di2p_point_head.  Weights: di2p_head_x3_pack of the [K][128] k-major matrices of layer 0 (rows of the dense
+ * sources only) and layer 1; scale_shift = f32[4][128] (scale0, shift0, scale1, shift1); W2t f32[128][P], scale2 / shift2 f32[P] or NULL.
+ * out f32[B,P,N].  This build runs 32 + 64 dense channels (K0 = 96), P <= 4; anything else: di2p_point_head / di2p_pointwise_gemm. */
+typedef struct {
+    const float* src[2]; long long batch_stride[2]; int row_stride[2]; int channels[2];
+    const void* W0p; const void* W1p; const float* scale_shift; int relu0, relu1;
+    const float* tab[2]; const int32_t* idx[2]; const float* w[2]; int nodes[2];
+    const float* W2t; const float* scale2; const float* shift2; int relu2, P;
+} di2p_head_x3_t;
+long long di2p_head_x3_packed_bytes(int K);
+int di2p_head_x3_pack(const float* Wt, int K, void* Wp, void* stream);
+int di2p_point_head_x3(const di2p_head_x3_t* h, float* out, int B, int N, void* stream);
 /* 3x3 convolutions (pad 1, stride 1 or 2) on the bf16 matrix instructions with the EXACT three-way fp32 split of both operands ("bf16x3",
  * see di2p_pointwise_gemm_x3): a direct implicit GEMM whose input patch is split once while it is staged into LDS and then serves all nine
  * taps.  Replaces cuDNN's conv+BN+ReLU(+residual) of models/resnet.py:56-72 (BasicBlock.forward) for the layers it supports; with stride 2

@@ -1,0 +1,33 @@
+"""The coarse per-point head at the benchmark shape (32 frames x 20480 points, 128 + 128 nodes): di2p_point_head_x3 (tables in LDS / from
+memory) against di2p_point_head (fp32 MFMA, LDS tile).  REPS=20 python tools/bench_head_x3.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+from deepi2p_amd import _lib
+import test_gpu_head_x3 as T
+dev = torch.device("cuda", 0)
+B, N, REPS = int(os.environ.get("B", 32)), 20480, int(os.environ.get("REPS", 20))
+d = T._case(dev, B, N, (128, 128), 2, 1)
+
+
+def timed(f):
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(REPS):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / REPS * 1e3
+
+
+flop = 2.0 * B * N * (96 * 128 + 128 * 128 + 128 * 2)
+t = timed(lambda: T._run_fp32(d, N))
+print("fp32-MFMA fused head (LDS tile)        %7.1f us  %6.1f TFLOP/s" % (t, flop / t / 1e6))
+for tab in (1, 3, 0):
+    with _lib.option("head_x3_tab", tab):
+        t = timed(lambda: T._run_x3(d, N))
+    print("bf16x3 head, tables %-18s %7.1f us  %6.1f TFLOP/s fp32-equivalent (%.0f of executed bf16 products)" % ({1: "in LDS, 4 waves", 3: "in LDS, 8 waves", 0: "from memory"}[tab], t, flop / t / 1e6, 6 * flop / t / 1e6))

@@ -6,7 +6,7 @@
 #                                         kernel-trace statistics;   then:  python tools/make_profiles.py <tag>
 # The bench line is produced AFTER the counter files it quotes.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 STAGE=${2:-bench}
 OUT=gpurun_out
 mkdir -p $OUT
@@ -14,6 +14,9 @@ if [ "$STAGE" = "counters" ]; then
   bash tools/profile_round.sh $TAG pmc > $OUT/${TAG}_profile_round_pmc.log 2>&1
   bash tools/prof_solver_counters.sh $TAG > $OUT/${TAG}_solver_counters.log 2>&1
   bash tools/prof_step_instructions.sh $TAG > $OUT/${TAG}_step_instructions.log 2>&1
+  # the bf16x3 convolution kernels, one instance per ResNet layer shape: matrix-pipe busy cycles, waits, LDS conflicts, instruction mix
+  PASSES="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU;SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU;FETCH_SIZE;WRITE_SIZE" \
+    timeout 600 bash tools/prof_kernel_counters.sh ${TAG}_convx3 conv3x3_x3 python tools/run_conv_x3_only.py > $OUT/${TAG}_convx3_counters.log 2>&1
   ls $OUT | grep "^${TAG}_" | tr '\n' ' '
   exit 0
 fi
@@ -21,7 +24,9 @@ timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -3 > $OUT/${TAG}_gputes
 timeout 400 python bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench.err
 timeout 200 python bench.py --mode train --steps 6 --warmup 2 > $OUT/${TAG}_train_line.json 2>> $OUT/${TAG}_bench.err
 timeout 100 python tools/bench_index_max.py > $OUT/${TAG}_index_max_cold.txt 2>&1
-LAYERS=1 timeout 150 python tools/bench_conv.py > $OUT/${TAG}_conv_layers.txt 2>&1
+timeout 300 python tools/bench_conv_x3.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_conv_layers.txt
+timeout 100 python tools/diag_conv_x3_accuracy.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_conv_x3_accuracy.txt
+tools/bin/probe_mfma_rounding > $OUT/${TAG}_mfma_rounding.txt 2>&1
 timeout 150 python tools/bench_winograd.py > $OUT/${TAG}_winograd_layers.txt 2>&1
 PROF=1 timeout 150 python tools/bench_solver.py > $OUT/${TAG}_solver_phases.txt 2>&1
 bash tools/profile_round.sh $TAG stats > $OUT/${TAG}_profile_round.log 2>&1

@@ -4,7 +4,7 @@ copies the evidence files, derives <tag>_pmc_traffic.json from the counter passe
     python tools/make_profiles.py r04               after `tools/final_round.sh r04 bench`"""
 import csv, json, os, shutil, sys
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out") + "/", os.path.join(ROOT, "profiles") + "/"
 KEEP_OLD = ("%s_sweep_solver_cfg.txt" % TAG, "%s_winograd_counters.txt" % TAG)
@@ -20,7 +20,7 @@ for f in os.listdir(G):
 
 # ---- counter-derived HBM traffic
 passes = 13            # tools/bench_conv.py: 3 warm-up + 10 timed encoder passes
-conv_kernels = ("wino_conv_kernel", "wino_reg_kernel", "conv2d_vec_kernel", "conv2d_kernel", "conv2d_stem_kernel", "stem_conv_kernel", "conv_splitk_reduce_kernel")
+conv_kernels = ("conv3x3_x3_kernel", "wino_conv_kernel", "wino_reg_kernel", "conv2d_vec_kernel", "conv2d_kernel", "conv2d_stem_kernel", "stem_conv_kernel", "conv_splitk_reduce_kernel")
 fetch16 = ("wino_conv_kernel", "wino_reg_kernel", "conv2d_vec_kernel", "conv_splitk_reduce_kernel")
 F = {r["kernel"]: r for r in rows(TAG + "_pmc_conv_FETCH_SIZE.csv")}
 Wr = {r["kernel"]: r for r in rows(TAG + "_pmc_conv_WRITE_SIZE.csv")}
@@ -37,9 +37,10 @@ for k, r in Wr.items():
         s = float(r["sum"]) / passes; wr += s
         per_kernel.setdefault(short(k), {})["WRITE_KiB_per_pass"] = round(s, 1)
 r1 = json.load(open(P + "r01_pmc_traffic.json"))
-sol_f = [r for r in rows(TAG + "_pmc_solver_FETCH_SIZE.csv") if "solve_kernel" in r["kernel"]][0]
-sol_w = [r for r in rows(TAG + "_pmc_solver_WRITE_SIZE.csv") if "solve_kernel" in r["kernel"]][0]
-fk, wk = float(sol_f["mean_per_launch"]), float(sol_w["mean_per_launch"])
+# the solver's traffic: ONE source, the counter file bench.py's `counters_file` names (tools/prof_solver_counters.sh)
+_sc = json.load(open(G + TAG + "_solver_counters.json")) if os.path.exists(G + TAG + "_solver_counters.json") else json.load(open(P + TAG + "_solver_counters.json"))
+fk, wk = float(_sc["FETCH_SIZE"]), float(_sc["WRITE_SIZE"])
+sol_f = {"launches": 6}
 def index_max_entry(C, fallback):
     try:
         f = [r for r in rows("%s_pmc_index_max_C%d_FETCH_SIZE.csv" % (TAG, C)) if "index_max" in r["kernel"]][0]
@@ -55,16 +56,16 @@ def index_max_entry(C, fallback):
 im64, old64 = index_max_entry(64, r1["index_max_C64_B32_N20480_K128"])
 im32, old32 = index_max_entry(32, r1["index_max_C32_B32_N20480_K128"])
 out = {"units": r1["units"] + "; solver records and the 16-byte staged convolution kernels corrected x2; WRITE_SIZE raw",
-       "commands": ["tools/profile_round.sh %s: rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python tools/bench_solver.py | tools/bench_conv.py (13 encoder passes)" % TAG],
+       "commands": ["tools/profile_round.sh %s pmc: rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python tools/bench_conv.py (13 encoder passes) | tools/bench_index_max.py; solve_kernel: copied from %s_solver_counters.json (tools/prof_solver_counters.sh, the same passes as its instruction counters)" % (TAG, TAG)],
        "carried_over_from_r01": [n for n, o in (("index_max_C64_B32_N20480_K128", old64), ("index_max_C32_B32_N20480_K128", old32)) if o],
        "index_max_C64_B32_N20480_K128": im64, "index_max_C32_B32_N20480_K128": im32,
        "solve_kernel_F32_R60_N20480": {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "fetch_bytes_corrected": fk * 2048, "hbm_bytes_corrected": fk * 2048 + wk * 1024,
                                        "compulsory_bytes": 32 * 20480 * 16 + 32 * 320 * 32, "launches": int(sol_f["launches"]),
-                                       "note": "one launch = 32 frames x 60 hypotheses; a frame's records + boxes (338 KB) are read ~64 sweeps x 60 hypotheses times but stay cache resident; WRITE_SIZE = the outputs + the classification cache entries that leave L2 + the write-back of the kernel's private segment (a few dozen bytes per lane of per-sweep straight-line spill code: tools/kernel_resources.py prints the exact size)"},
+                                       "note": "one launch = 32 frames x 60 hypotheses; a frame's records + boxes (338 KB) are read ~64 sweeps x 60 hypotheses times but stay cache resident; WRITE_SIZE = the outputs + the classification-cache entries (16 B per missed cluster and sweep; the L2 is write-through: every store leaves it) + the kernel's private segment (tools/kernel_resources.py prints its size).  Same numbers as %s_solver_counters.json: they ARE that file's" % TAG},
        "conv2d_resnet34_B32_160x512": {"FETCH_SIZE_KiB_per_encoder_pass_raw": fr, "FETCH_SIZE_KiB_per_encoder_pass_corrected": fc, "WRITE_SIZE_KiB_per_encoder_pass_raw": wr,
                                        "kernel_launches_per_pass": launches, "conv_calls_per_pass": 36, "hbm_bytes_per_call_corrected": (fc + wr) * 1024 / 36,
                                        "hbm_bytes_per_call_raw": (fr + wr) * 1024 / 36, "per_kernel": per_kernel,
-                                       "note": "sum over the convolution kernels of one image-encoder pass (Winograd launches, implicit-GEMM launches + split-K reduce, the direct stem); FETCH x2 for the kernels that load 16 B per lane, stem raw (dword loads: uncalibrated)"}}
+                                       "note": "sum over the convolution kernels of one image-encoder pass (bf16x3 direct convolutions, any Winograd / implicit-GEMM launches left, the direct stem); FETCH x2 for the kernels that load 16 B per lane, the bf16x3 kernels (dword loads of the activations, 16-byte loads of the split weights from L2) and the stem raw: uncalibrated"}}
 json.dump(out, open(P + TAG + "_pmc_traffic.json", "w"), indent=1)
 if len(sys.argv) > 2 and sys.argv[2] == "counters":       # stage 1: the counter files only (commit them, THEN run the bench stage)
     print("profiles/%s_pmc_traffic.json, %s_solver_counters.json, %s_step_instructions.txt rebuilt" % (TAG, TAG, TAG))
@@ -120,26 +121,38 @@ files listed in KEEP_OLD (if present) come from earlier calls of the round.
   host->device copy of every batch inside the step; device time of one batch {line['latency_ms_per_batch']['streams_%d' % line['config']['streams']]:.1f} ms with all streams busy,
   {line['latency_ms_per_batch']['one_step_in_flight']:.1f} ms with a single step in flight.  Roofline object = time-dominant family = `solve_kernel`:
   {k['solve_kernel']['ms_per_step']:.2f} ms per step, {k['solve_kernel']['achieved']:.1f} TFLOP/s by SURVEY 8(d)'s unit = {k['solve_kernel']['frac']:.2f} of the 78.6 TFLOP/s fp64 vector peak.
-  Per family (`kernels`): convolution {cv['ms_per_step']:.2f} ms = {cv['achieved']:.1f} TFLOP/s algorithmic = **{cv['frac']:.2f}** of the fp32-MFMA peak (26 Winograd
-  launches {cv['winograd']['ms_per_step']:.2f} ms, whose MFMA units issue {cv['winograd']['executed_mfma_tflops']:.0f} TFLOP/s; 9 implicit-GEMM launches {cv['winograd']['direct_kernel_ms_per_step']:.2f} ms; stem
-  {cv['winograd']['stem_kernel_ms_per_step']:.2f} ms); pointwise {pw['ms_per_step']:.2f} ms ({pw['achieved']:.0f} TFLOP/s reference-algorithmic, {pw['achieved_executed']:.0f} executed); index_max
+  Per family (`kernels`): convolution {cv['ms_per_step']:.2f} ms = {cv['achieved']:.1f} TFLOP/s algorithmic = **{cv['frac']:.2f}** of the fp32-MFMA peak ({cv['bf16x3']['calls_per_step']} bf16x3
+  launches {cv['bf16x3']['ms_per_step']:.2f} ms = {cv['bf16x3']['fp32_equivalent_tflops']:.0f} TFLOP/s fp32-equivalent = {cv['bf16x3']['executed_bf16_tflops']:.0f} TFLOP/s of executed bf16 products = {cv['bf16x3']['frac_of_bf16_mfma_peak']:.2f} of the 2.5 PFLOP/s bf16 peak;
+  {cv['winograd']['calls_per_step']} Winograd launches {cv['winograd']['ms_per_step']:.2f} ms; other implicit-GEMM launches {cv['winograd']['direct_kernel_ms_per_step']:.2f} ms; stem
+  {cv['winograd']['stem_kernel_ms_per_step']:.2f} ms); pointwise {pw['ms_per_step']:.2f} ms ({pw['achieved_executed']:.0f} TFLOP/s executed = {pw['frac']:.2f} of the fp32-MFMA peak; {pw['achieved']:.0f} TFLOP/s by the reference's layer sizes); index_max
   {k['index_max_kernel']['ms_per_step']*1e3:.0f} us in-pipeline ({k['index_max_kernel']['achieved']:.0f} GB/s).  CPU baseline: {line['cpu_baseline']['value']:.3f} frames/s on {line['cpu_baseline']['cores']} threads.
 * `{TAG}_bench_kernel_stats_pipelined.csv` / `{TAG}_bench_line_pipelined.json` -- `rocprofv3 --kernel-trace --stats --output-format csv --
   python bench.py --no-cpu-baseline --no-h2d-pass` ({s3['value']:.0f} frames/s under the profiler); several batches in flight: durations include
   contention.
 * `{TAG}_bench_kernel_stats_serial.csv` / `{TAG}_bench_line_serial.json` -- the same with `--streams 1` ({ser['value']:.0f} frames/s): durations without
   contention.  `solve_kernel` averages {avg('solve_kernel')/1e3:.2f} ms (rocprof) against {ser['kernels']['solve_kernel']['ms_per_step']:.2f} ms from the HIP events of the same run's JSON
-  line; `wino_conv_kernel<32, true, 8>` {avg('wino_conv_kernel<32, true, 8>'):.1f} us, `wino_reg_kernel<4>` {avg('wino_reg_kernel<4>'):.1f} us per call; `knn_nodes_kernel<3>` {avg('knn_nodes_kernel<3>'):.1f} us, `index_max` {avg('index_max'):.1f} us.
-* `{TAG}_pmc_{{solver,conv}}_{{FETCH,WRITE}}_SIZE.csv`, `{TAG}_pmc_traffic.json` -- separate `--pmc` passes (kernel-trace only) on
-  `tools/bench_solver.py` and `tools/bench_conv.py`.  solve_kernel: {sp['FETCH_SIZE_KiB']/1024:.1f} MiB fetched raw (x2 = {sp['fetch_bytes_corrected']/1e6:.1f} MB) per launch against 10.8 MB
-  of once-through records + boxes (the working set is cache resident), {sp['WRITE_SIZE_KiB']/1024:.1f} MiB written (round 3: 34 MiB; the classification-cache entries -- 16 B per missed cluster and sweep --
-  are written back several times: 20 GB/s over the launch, DESIGN.md section 4 "Round 4 on the solver").  Convolution family of one
+  line; `conv3x3_x3_kernel` (all instances) {avg('conv3x3_x3_kernel'):.1f} us per call; `point_head_kernel` {avg('point_head_kernel'):.1f} us; `knn_nodes_kernel<3>` {avg('knn_nodes_kernel<3>'):.1f} us, `index_max` {avg('index_max'):.1f} us.
+* `{TAG}_pmc_conv_{{FETCH,WRITE}}_SIZE.csv`, `{TAG}_pmc_traffic.json` -- separate `--pmc` passes (kernel-trace only) on `tools/bench_conv.py`; the
+  solver's entry is COPIED from `{TAG}_solver_counters.json` (one source for its traffic: the file the bench line's `counters_file` names).
+  solve_kernel: {sp['FETCH_SIZE_KiB']/1024:.1f} MiB fetched raw (x2 = {sp['fetch_bytes_corrected']/1e6:.1f} MB) per launch against 10.8 MB
+  of once-through records + boxes (the working set is cache resident), {sp['WRITE_SIZE_KiB']/1024:.1f} MiB written (the classification-cache entries, 16 B per missed
+  cluster and sweep: the L2 is write-through, every store leaves it).  Convolution family of one
   encoder pass: FETCH {cvp['FETCH_SIZE_KiB_per_encoder_pass_raw']/1024:.0f} MiB raw / {cvp['FETCH_SIZE_KiB_per_encoder_pass_corrected']/1024:.0f} MiB corrected, WRITE {cvp['WRITE_SIZE_KiB_per_encoder_pass_raw']/1024:.0f} MiB = {cvp['hbm_bytes_per_call_corrected']/1e6:.0f} MB per convolution call against
-  52 MB compulsory (the Winograd workgroups re-stream their slice of the transformed filters: under 1 TB/s over the family's time
-  -- not a limiter).  index_max (fresh passes on cold inputs): C = 64 {pm['index_max_C64_B32_N20480_K128']['hbm_bytes_corrected']/1e6:.0f} MB against {pm['index_max_C64_B32_N20480_K128']['algorithmic_bytes']/1e6:.0f} MB algorithmic, C = 32 {pm['index_max_C32_B32_N20480_K128']['hbm_bytes_corrected']/1e6:.0f} / {pm['index_max_C32_B32_N20480_K128']['algorithmic_bytes']/1e6:.0f} MB.  (`{TAG}_bench_line.json` was produced AFTER
+  52 MB compulsory.  index_max (fresh passes on cold inputs): C = 64 {pm['index_max_C64_B32_N20480_K128']['hbm_bytes_corrected']/1e6:.0f} MB against {pm['index_max_C64_B32_N20480_K128']['algorithmic_bytes']/1e6:.0f} MB algorithmic, C = 32 {pm['index_max_C32_B32_N20480_K128']['hbm_bytes_corrected']/1e6:.0f} / {pm['index_max_C32_B32_N20480_K128']['algorithmic_bytes']/1e6:.0f} MB.  (`{TAG}_bench_line.json` was produced AFTER
   these counter files were committed: its `traffic` / `frac_executed` fields are computed from them -- `counters_file` in the line names the file.)
-* `{TAG}_conv_layers.txt`, `{TAG}_winograd_layers.txt` -- per-layer timings: the remaining implicit-GEMM layers (stride-2 3x3, 1x1
-  downsample) and, for the four 3x3 stride-1 shapes at B = 32, direct vs the Winograd variants:
+* `{TAG}_conv_layers.txt` -- `tools/bench_conv_x3.py`: per 3x3 layer shape at B = 32, the bf16x3 direct convolution (every tile configuration that
+  runs the shape) against the fp32-MFMA kernels it replaces (Winograd; for stride 2 the direct kernel + the 1x1 branch), then the whole image
+  encoder under the `conv_x3` masks:
+```
+{chr(10).join(open(P + TAG + "_conv_layers.txt").read().strip().splitlines())}
+```
+* `{TAG}_convx3_counters.json` -- `tools/prof_kernel_counters.sh` on `tools/run_conv_x3_only.py`: per kernel instance (= layer shape) the matrix-pipe busy
+  cycles (`SQ_VALU_MFMA_BUSY_CYCLES`, cycles summed over the SIMDs) against the waves' lifetime (`SQ_WAVE_CYCLES`, quad-cycles x 4), waits, LDS bank
+  conflicts, VALU / LDS instructions per matrix instruction, FETCH / WRITE.
+* `{TAG}_conv_x3_accuracy.txt` -- `tools/diag_conv_x3_accuracy.py`: error against an fp64 convolution, bf16x3 per configuration next to the fp32-MFMA kernels.
+* `{TAG}_mfma_rounding.txt` -- `tools/probe_mfma_rounding.hip`: how the bf16 matrix instructions round (products of one instruction are aligned to the
+  largest addend and truncated below its last bit; the fp32-input instruction is an exact fma chain) -- why the bf16x3 kernels keep the small products apart.
+* `{TAG}_winograd_layers.txt` -- the fp32 kernels alone (direct vs the Winograd variants on the four stride-1 shapes):
 ```
 {chr(10).join(wl[-7:])}
 ```

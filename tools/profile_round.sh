@@ -4,7 +4,7 @@
 # Writes gpurun_out/<tag>_*.csv (kernel-trace statistics of the bench command, default streams ("pipelined") and serial; separate --pmc passes
 # for the solver and index_max -- counters are never combined with other trace domains).  Copy what should be judged into profiles/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 WHAT=${2:-all}          # stats | pmc | all
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
@@ -43,7 +43,8 @@ with open(sys.argv[2], "w") as fh:
         fh.write('"%s",%s,%d,%.6g,%.6g\n' % (k, c, n, s, s / n))
 PY
 }
-for c in FETCH_SIZE WRITE_SIZE; do pmc $c bench_solver.py solver; done
+# (the solver's FETCH_SIZE / WRITE_SIZE are taken by tools/prof_solver_counters.sh together with its other counters: ONE source, the file
+#  bench.py's `counters_file` names)
 for c in FETCH_SIZE WRITE_SIZE; do pmc $c bench_conv.py conv; done
 for c in FETCH_SIZE WRITE_SIZE; do pmc $c bench_index_max.py index_max_C64 CS=64; pmc $c bench_index_max.py index_max_C32 CS=32; done
 ls -la $OUT | grep ${TAG}_
