@@ -311,7 +311,7 @@ def main():
 
     # per-kernel-family durations: HIP events on the launch stream, in a SERIAL pass right after the timed region
     # (with several batches in flight, events inside the timed region would measure contention, not the kernels)
-    timed_names = ("di2p_conv2d", "di2p_conv2d_ws", "di2p_conv3x3_winograd", "di2p_conv3x3_x3", "di2p_conv7x7s2_stem", "di2p_pointwise_gemm", "di2p_pointwise_gemm_x3", "di2p_point_head", "di2p_point_chain", "di2p_index_max_values",
+    timed_names = ("di2p_conv2d", "di2p_conv2d_ws", "di2p_conv3x3_winograd", "di2p_conv3x3_x3", "di2p_conv7x7s2_stem", "di2p_pointwise_gemm", "di2p_pointwise_gemm_x3", "di2p_point_head", "di2p_point_head_x3", "di2p_point_chain", "di2p_index_max_values",
                    "di2p_solve_batched_f32", "di2p_knn_nodes")
     prof_steps = 2
     _lib.TIMED = {n: [] for n in timed_names}
@@ -342,9 +342,10 @@ def main():
     x3_ms, x3_calls = fam_ms.pop("di2p_pointwise_gemm_x3"), launches.pop("di2p_pointwise_gemm_x3")
     x3_mac = work.get("di2p_pointwise_gemm_x3", 0) / prof_steps
     chain_ms, chain_calls = fam_ms.pop("di2p_point_chain"), launches.pop("di2p_point_chain")     # fused narrow PointNet chains (HBM-bound)
-    fam_ms["di2p_pointwise_gemm"] += fam_ms.pop("di2p_point_head") + x3_ms + chain_ms
-    launches["di2p_pointwise_gemm"] += launches.pop("di2p_point_head") + x3_calls + chain_calls
-    pw_exec_flops = 2.0 * (work.get("di2p_pointwise_gemm", 0) + work.get("di2p_point_head", 0) + work.get("di2p_point_chain", 0)) / prof_steps + 2.0 * x3_mac
+    hx_ms, hx_calls, hx_mac = fam_ms.pop("di2p_point_head_x3"), launches.pop("di2p_point_head_x3"), work.get("di2p_point_head_x3", 0) / prof_steps
+    fam_ms["di2p_pointwise_gemm"] += fam_ms.pop("di2p_point_head") + x3_ms + chain_ms + hx_ms
+    launches["di2p_pointwise_gemm"] += launches.pop("di2p_point_head") + x3_calls + chain_calls + hx_calls
+    pw_exec_flops = 2.0 * (work.get("di2p_pointwise_gemm", 0) + work.get("di2p_point_head", 0) + work.get("di2p_point_chain", 0)) / prof_steps + 2.0 * x3_mac + 2.0 * hx_mac
     conv_flops = conv_flops_per_frame(H, W) * B
     knn_bytes = 2 * B * (12 * N + 24 * N + 3 * 4 * 128)          # the two point-level calls (pc -> node_a, pc -> node_b); node-level calls are negligible
     idx_bytes = B * (4 * 32 * N + 4 * N + 2 * 4 * 32 * 128) + B * (4 * 64 * N + 4 * N + 2 * 4 * 64 * 128)
@@ -388,6 +389,10 @@ def main():
                              "hbm_tb_per_s": B * N * 4.0 * ((7 + 32) + (32 + 64)) / max(chain_ms, 1e-9) / 1e9,
                              "note": "first_pointnet (7->32->32->32) and second_pointnet (32+32->64->64) as one launch each: compulsory "
                                      "traffic = inputs once + outputs once, hidden activations in LDS"},
+            "head_bf16x3": {"calls_per_step": hx_calls, "ms_per_step": hx_ms, "fp32_equivalent_tflops": 2.0 * hx_mac / max(hx_ms, 1e-9) / 1e9,
+                            "executed_bf16_tflops": 12.0 * hx_mac / max(hx_ms, 1e-9) / 1e9, "frac_of_bf16_mfma_peak": 12.0 * hx_mac / max(hx_ms, 1e-9) / 1e9 / MFMA_BF16_PEAK_TFLOPS,
+                            "note": "the coarse per-point head (three layers, gathered node products) as ONE wave-autonomous launch on the bf16 matrix instructions "
+                                    "(exact three-way splits): di2p_point_head_x3"},
             "bf16x3": {"calls_per_step": x3_calls, "ms_per_step": x3_ms, "fp32_equivalent_tflops": 2.0 * x3_mac / max(x3_ms, 1e-9) / 1e9,
                        "frac_of_fp32_mfma_peak": 2.0 * x3_mac / max(x3_ms, 1e-9) / 1e9 / MFMA_F32_PEAK_TFLOPS,
                        "executed_bf16_tflops": 12.0 * x3_mac / max(x3_ms, 1e-9) / 1e9, "bf16_mfma_peak_tflops": MFMA_BF16_PEAK_TFLOPS,
@@ -492,7 +497,7 @@ def main():
             "metric": "frames/sec (img+pc infer + 60-restart GN pose) KITTI 20k-pt, 1/2/4/8 GPU",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if hyp else "weak", "vs_baseline": None,
-            "dtype": "f32 network (fp32-input MFMA; 3x3 convolutions and GEMM-shaped point layers: bf16 MFMA on exact three-way fp32 splits, fp32 accumulation) + f64 solver",
+            "dtype": "f32 network (fp32-input MFMA; 3x3 convolutions, GEMM-shaped point layers and the per-point head: bf16 MFMA on exact three-way fp32 splits, fp32 accumulation) + f64 solver",
             "data": "synthetic frames, random-init closed-form weights; solver labels = GT frustum labels with 5% flips (SURVEY 8d)",
             "config": {"workload": ("BASELINE configs[4]: Oxford-shaped %d-pt / %dx%d, %d frames per step on every rank, coarse classification "
                                     "+ %d 2D GN/LM hypotheses per frame sharded over the ranks, all_gather + argmin" % (N, H, W, B, R)) if hyp else
