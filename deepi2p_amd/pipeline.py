@@ -106,12 +106,12 @@ class RegistrationExecutor:
         self.h2d_mode = h2d_mode
         # double_buffer (option; h2d_mode "copy_stream" with graphs): TWO sets of device inputs per slot and one graph per set (sharing one
         # memory pool), so the copies of a slot's NEXT batch do not wait for its running step to stop reading the inputs.  Measured
-        # (tools/r04_dbuf.sh): the H2D-inclusive latency of a batch drops 51.5 -> 48.5 ms at 8 batches in flight, the H2D-inclusive RATE
+        # (tools/oneoff/r04_dbuf.sh): the H2D-inclusive latency of a batch drops 51.5 -> 48.5 ms at 8 batches in flight, the H2D-inclusive RATE
         # does not move (0.95 of the resident rate either way: the copies do not cost the step its inputs' wait) -- off by default
         self.double_buffer = bool(double_buffer) and h2d_mode == "copy_stream" and self.use_graph
         # split_solver (experiment, graphs only): the classifier and the pose solve of a step as TWO graphs on two streams of different
         # priority -- the classifier's ~90 short kernels on a high-priority queue, the solver's long-lived workgroups on a normal one, so
-        # that a freed compute unit goes to a waiting classifier kernel first (tools/r04_split.sh)
+        # that a freed compute unit goes to a waiting classifier kernel first (tools/oneoff/r04_split.sh)
         self.split_solver = bool(split_solver) and self.use_graph and step_fn is None
         mm.detector.prepack()                 # derive the kernel operands now, on the current stream, before other streams use them
         self._weights_version = mm.detector.weights_version
