@@ -138,3 +138,34 @@ def test_image_encoder_same_features_with_and_without_conv_x3(dev):
         b = [t.clone() for t in enc(img)]
     for u, v in zip(a, b):
         assert float((u - v).abs().max()) <= 2e-4 * float(v.abs().max()) + 1e-6
+
+
+def test_bf16x3_kernels_far_from_one(dev):
+    """Round-4 advisor finding: the bf16x3 kernels were only tested on operands around 1.  Measured behaviour (tools/probe_x3_ranges.py), now
+    asserted for the pointwise and the convolution kernel: (i) operands scaled by 2^-e / 2^+e give the SAME relative error down to e = 100 (a
+    split term keeps the fp32 exponent range); from |x| ~ 2^-120 on, the second and third split terms are bf16 denormals that the matrix
+    instruction flushes: the error grows to 1e-4 relative at 2^-120 (where an fp32 fma chain still has 5e-8) -- activations that small do not
+    occur behind a BatchNorm; (ii) a non-finite activation makes exactly the outputs non-finite that the fp32-MFMA kernel makes non-finite
+    (+-inf splits into (inf, NaN, NaN): the VALUE is NaN where fp32 gives +-inf)."""
+    from deepi2p_amd import ops
+    g = torch.Generator().manual_seed(0)
+    B, K, M, N = 1, 256, 256, 2048
+    x = torch.randn(B, K, N, generator=g).to(dev)
+    Wt = (torch.randn(K, M, generator=g) / K ** 0.5).to(dev)
+    ref = ops.pointwise_gemm([ops.Src(x)], Wt, M, N, x3=False)
+    Cin, H, W, Cout = 64, 8, 64, 64
+    xc = torch.randn(1, Cin, H, W, generator=g).to(dev)
+    Wtc = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(dev).permute(2, 3, 1, 0).reshape(-1, Cout).contiguous()
+    one, zero = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+    refc = ops.conv2d(xc, Wtc, one, zero, 3, 3, 1, 1, False, tap_major=True)
+    for e, lim in ((0, 2e-6), (60, 2e-6), (100, 2e-6), (120, 1e-3)):
+        y = ops.pointwise_gemm([ops.Src(x * 2.0 ** -e)], (Wt * 2.0 ** e).contiguous(), M, N, x3=True)
+        assert float((y - ref).abs().max() / ref.abs().max()) <= lim, ("pointwise", e)
+        y = ops.conv3x3_x3(xc * 2.0 ** -e, ops.bf16x3_pack((Wtc * 2.0 ** e).contiguous()), Cout, one, zero, 1, False)
+        assert float((y - refc).abs().max() / refc.abs().max()) <= lim, ("conv", e)
+    xi = x.clone(); xi[0, 5, 7] = float("inf")
+    y3, y1 = ops.pointwise_gemm([ops.Src(xi)], Wt, M, N, x3=True), ops.pointwise_gemm([ops.Src(xi)], Wt, M, N, x3=False)
+    assert torch.equal(torch.isfinite(y3), torch.isfinite(y1)) and bool(torch.isnan(y3).any())
+    xci = xc.clone(); xci[0, 3, 4, 5] = float("-inf")
+    y3, y1 = ops.conv3x3_x3(xci, ops.bf16x3_pack(Wtc), Cout, one, zero, 1, False), ops.conv2d(xci, Wtc, one, zero, 3, 3, 1, 1, False, tap_major=True)
+    assert torch.equal(torch.isfinite(y3), torch.isfinite(y1))

@@ -334,13 +334,15 @@ def test_solver_matches_oracle_other_cameras(dev, seed, is_2d, N, HW, flip):
     np.testing.assert_array_equal(it_g[ok], it_o[ok])            # same number of LM iterations where the iterates agree
 
 
-@pytest.mark.parametrize("scene", ["scan", "patchy", "collapsed", "duplicates"])
+@pytest.mark.parametrize("scene", ["scan", "patchy", "collapsed", "duplicates", "bucket_under_4096", "bucket_over_4096"])
 @pytest.mark.parametrize("N", [777, 20480])
 def test_frame_preparation_sort_paths_agree(dev, scene, N):
-    """Frame preparation sorts the records by (label, Hilbert cell, index).  The counting sort + per-bucket ranking (buckets of <= 64 keys by one
-    wavefront, 65..1024 by the workgroup, anything denser falls back) must produce the SAME order as the bitonic network: params, costs,
-    iteration and sweep counts bit-identical.  Scenes: a scan (small buckets), patchy (dense patches: workgroup-ranked buckets), collapsed
-    (a far outlier stretches the grid so that everything shares a few cells: fallback), duplicates (equal coordinates, unique keys by index)."""
+    """Frame preparation sorts the records by (label, Hilbert cell, index).  The shipped path is a counting sort into (label, cell) buckets
+    followed by a ranking of every key inside its bucket, ONE THREAD PER KEY (solver.hip prepare_kernel step 3a); a frame with a bucket above
+    4096 keys goes to the bitonic network instead.  Either way the order must be the SAME as the bitonic network's (knob solver_prep_bitonic):
+    params, costs, iteration and sweep counts bit-identical.  Scenes: a scan (small buckets), patchy (dense patches: large buckets), collapsed
+    (a far outlier stretches the grid so that everything shares a few cells: the fallback), duplicates (equal coordinates, unique keys by
+    index), and one bucket just under / just over the 4096-key limit (a 1 m patch of equally labelled points inside one 5 m cell)."""
     from deepi2p_amd import _lib, ops
     f, rng = _frame(900 + N, N)
     pts, lab = f["pc"].astype(np.float32).copy(), f["labels"].astype(np.int32).copy()
@@ -351,6 +353,10 @@ def test_frame_preparation_sort_paths_agree(dev, scene, N):
         pts[:, 0] = [4e4, 0.0, 4e4]
     elif scene == "duplicates":
         pts[:, N // 2:] = pts[:, :N - N // 2]
+    elif scene.startswith("bucket_"):
+        m = min(N - 1, 4040 if scene == "bucket_under_4096" else 4130)
+        pts[0, :m] = 11.0 + rng.uniform(0, 1.0, m); pts[2, :m] = 21.0 + rng.uniform(0, 1.0, m)
+        lab[:m] = 1
     R = 6
     ys = rng.normal(f["yaw_gt"], 0.2, R)
     Ts = np.stack((np.zeros(R), np.zeros(R), rng.uniform(-5, 5, R)), axis=1)
