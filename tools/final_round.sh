@@ -17,6 +17,8 @@ if [ "$STAGE" = "counters" ]; then
   # the bf16x3 convolution kernels, one instance per ResNet layer shape: matrix-pipe busy cycles, waits, LDS conflicts, instruction mix
   PASSES="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU;SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU;FETCH_SIZE;WRITE_SIZE" \
     timeout 600 bash tools/prof_kernel_counters.sh ${TAG}_convx3 conv3x3_x3 python tools/run_conv_x3_only.py > $OUT/${TAG}_convx3_counters.log 2>&1
+  PASSES="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU;SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU;FETCH_SIZE;WRITE_SIZE" \
+    timeout 400 bash tools/prof_kernel_counters.sh ${TAG}_headx3 point_head_x3 python tools/run_head_x3_only.py > $OUT/${TAG}_headx3_counters.log 2>&1
   ls $OUT | grep "^${TAG}_" | tr '\n' ' '
   exit 0
 fi
@@ -27,6 +29,8 @@ timeout 100 python tools/bench_index_max.py > $OUT/${TAG}_index_max_cold.txt 2>&
 timeout 300 python tools/bench_conv_x3.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_conv_layers.txt
 timeout 100 python tools/diag_conv_x3_accuracy.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_conv_x3_accuracy.txt
 tools/bin/probe_mfma_rounding > $OUT/${TAG}_mfma_rounding.txt 2>&1
+timeout 100 python tools/bench_head_x3.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_head_x3.txt
+timeout 100 python tools/probe_x3_ranges.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_x3_ranges.txt
 timeout 150 python tools/bench_winograd.py > $OUT/${TAG}_winograd_layers.txt 2>&1
 PROF=1 timeout 150 python tools/bench_solver.py > $OUT/${TAG}_solver_phases.txt 2>&1
 bash tools/profile_round.sh $TAG stats > $OUT/${TAG}_profile_round.log 2>&1
