@@ -396,9 +396,9 @@ void cx_launch_one(const CxArgs& a, int grid, size_t lds, hipStream_t st) {
 
 // The instantiated kernels.  Each row: configuration, stride, double-buffered patch, ITEMS, PWT (0 = any patch row length; a plan that
 // needs fewer items runs the next larger instance of its row length, the surplus items are masked).  Stride-2 instances carry the fused
-// downsample branch.  The PWT != 0 rows are the seven layer shapes of ResNet-34 at 160 x 512.
+// downsample branch.  The PWT != 0 rows are the seven layer shapes of ResNet-34 at 160 x 512 (in the configuration the plan picks for them).
 #define DI2P_CX_INSTANCES(X)                                                                                                            \
-    X(0, 32, 1, 5, 2, 2, 1, 1, 6, 130) X(0, 32, 1, 5, 2, 2, 1, 1, 4, 66) X(2, 16, 2, 5, 4, 1, 1, 1, 3, 34) X(3, 16, 1, 5, 4, 1, 1, 1, 2, 18) \
+    X(0, 32, 1, 5, 2, 2, 1, 1, 6, 130) X(1, 32, 1, 5, 4, 1, 1, 1, 3, 66) X(2, 16, 2, 5, 4, 1, 1, 1, 3, 34) X(3, 16, 1, 5, 4, 1, 1, 1, 2, 18) \
     X(1, 32, 1, 5, 4, 1, 2, 0, 8, 130) X(2, 16, 2, 5, 4, 1, 2, 0, 8, 66) X(3, 16, 1, 5, 4, 1, 2, 1, 6, 34)                                \
     X(0, 32, 1, 5, 2, 2, 1, 1, 6, 0) X(1, 32, 1, 5, 4, 1, 1, 1, 4, 0) X(2, 16, 2, 5, 4, 1, 1, 1, 4, 0) X(3, 16, 1, 5, 4, 1, 1, 1, 4, 0)     \
     X(1, 32, 1, 5, 4, 1, 2, 0, 8, 0) X(3, 16, 1, 5, 4, 1, 2, 0, 8, 0)
