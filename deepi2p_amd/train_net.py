@@ -114,10 +114,12 @@ def _conv_forward(x, W, stride, pad):
     """conv2d through the inference engine with an identity epilogue; Cin % 16 == 0 takes its tap-major (16-byte staged) path."""
     Cout, Cin, KH, KW = W.shape
     one, zero = _unit_affine(Cout, x.device)
-    if ((KH, KW, stride, pad) == (3, 3, 1, 1) and Cin % 16 == 0 and (_lib.get_option("conv_x3") & (1 << max(0, min(3, Cout.bit_length() - 7))))
-            and ops.conv3x3_x3_supported(x.shape, Cout, 1)):
+    if ((KH, KW, stride, pad) == (3, 3, 1, 1) and Cin % 16 == 0 and x.shape[0] >= 16
+            and (_lib.get_option("conv_x3") & (1 << max(0, min(3, Cout.bit_length() - 7)))) and ops.conv3x3_x3_supported(x.shape, Cout, 1)):
         # round 5: the direct convolution on the bf16 matrix instructions (exact three-way splits; the filters change every step: their
-        # split is one small launch per call, like the Winograd transform below) -- forward AND, through the flipped filter, the input gradient
+        # split is one small launch per call, like the Winograd transform below) -- forward AND, through the flipped filter, the input gradient.
+        # From 16 frames on: its workgroup tiles are sized for whole rounds of the chip at 32 frames; at the reference's training batch of 8 they
+        # number 64-128 per launch and the Winograd kernel's smaller tiles win (measured: 18.3 against 17.8 ms per step)
         Wt = W.permute(2, 3, 1, 0).reshape(-1, Cout).contiguous()
         return ops.conv3x3_x3(x, ops.bf16x3_pack(Wt), Cout, one, zero, 1, False)
     if (KH, KW, stride, pad) == (3, 3, 1, 1) and Cin % 16 == 0 and Cout % 32 == 0 and x.shape[3] % 2 == 0 and x.shape[3] >= 4:
