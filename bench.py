@@ -318,7 +318,7 @@ def main():
 
     # per-kernel-family durations: HIP events on the launch stream, in a SERIAL pass right after the timed region
     # (with several batches in flight, events inside the timed region would measure contention, not the kernels)
-    timed_names = ("di2p_conv2d", "di2p_conv2d_ws", "di2p_conv3x3_winograd", "di2p_conv3x3_x3", "di2p_conv7x7s2_stem", "di2p_pointwise_gemm", "di2p_pointwise_gemm_x3", "di2p_point_head", "di2p_point_head_x3", "di2p_point_chain", "di2p_index_max_values",
+    timed_names = ("di2p_conv2d", "di2p_conv2d_ws", "di2p_conv3x3_winograd", "di2p_conv3x3_x3", "di2p_conv7x7s2_stem", "di2p_stem_x3", "di2p_pointwise_gemm", "di2p_pointwise_gemm_x3", "di2p_point_head", "di2p_point_head_x3", "di2p_point_chain", "di2p_index_max_values",
                    "di2p_solve_batched_f32", "di2p_knn_nodes")
     prof_steps = 2
     _lib.TIMED = {n: [] for n in timed_names}
@@ -338,11 +338,15 @@ def main():
     # the convolution family = the plain entry point + the split-K one (K-slice kernel + ordered reduce pass)
     # and the fused Winograd kernel that runs the 3x3 stride-1 layers
     direct_ms, wino_ms, wino_calls = fam_ms["di2p_conv2d"] + fam_ms["di2p_conv2d_ws"], fam_ms["di2p_conv3x3_winograd"], launches["di2p_conv3x3_winograd"]
-    stem_ms = fam_ms["di2p_conv7x7s2_stem"]
+    stem_ms = fam_ms["di2p_conv7x7s2_stem"] + fam_ms["di2p_stem_x3"]      # (di2p_stem_x3: conv1 + bn1 + relu AND the max-pool, one launch)
     # ... and the 3x3 layers that run as direct convolutions on the bf16 matrix instructions with exact three-way fp32 splits (conv_x3.hip)
-    cx_ms, cx_calls, cx_mac = fam_ms["di2p_conv3x3_x3"], launches["di2p_conv3x3_x3"], work.get("di2p_conv3x3_x3", 0) / prof_steps
-    fam_ms["di2p_conv2d"] += fam_ms.pop("di2p_conv2d_ws") + fam_ms.pop("di2p_conv3x3_winograd") + fam_ms.pop("di2p_conv7x7s2_stem") + fam_ms.pop("di2p_conv3x3_x3")
-    launches["di2p_conv2d"] += launches.pop("di2p_conv2d_ws") + launches.pop("di2p_conv3x3_winograd") + launches.pop("di2p_conv7x7s2_stem") + launches.pop("di2p_conv3x3_x3")
+    # (the stem on the same instructions, di2p_stem_x3, is priced with them: by its 147 algorithmic taps per output -- it executes 176, the
+    #  kx pad and the 22nd (channel, ky) pair -- and its time includes the max-pool it carries)
+    cx_ms, cx_calls = fam_ms["di2p_conv3x3_x3"] + fam_ms["di2p_stem_x3"], launches["di2p_conv3x3_x3"] + launches["di2p_stem_x3"]
+    cx_mac = (work.get("di2p_conv3x3_x3", 0) + work.get("di2p_stem_x3", 0)) / prof_steps
+    for n in ("di2p_conv2d_ws", "di2p_conv3x3_winograd", "di2p_conv7x7s2_stem", "di2p_stem_x3", "di2p_conv3x3_x3"):
+        fam_ms["di2p_conv2d"] += fam_ms.pop(n)
+        launches["di2p_conv2d"] += launches.pop(n)
     wino_exec_flops = 2.0 * work.get("di2p_conv3x3_winograd", 0) / prof_steps
     # pointwise family = the single-layer launches + the fused three-layer point head
     # ... and the GEMM-shaped layers that run on the bf16 matrix instructions with exact three-way fp32 splits (priced separately below)

@@ -95,6 +95,9 @@ _SIGS = {
     "di2p_conv3x3_x3": [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 5,
     "di2p_conv3x3_x3_supported": [c_int] * 6,
     "di2p_head_x3_pack": [c_void_p, c_int, c_void_p, c_void_p],
+    "di2p_stem_x3_pack": [c_void_p, c_void_p, c_void_p],
+    "di2p_stem_x3_supported": [c_int, c_int],
+    "di2p_stem_x3": [c_void_p] * 5 + [c_int] * 3 + [c_void_p],
     "di2p_point_head_x3": [ctypes.POINTER(HeadX3T), c_void_p, c_int, c_int, c_void_p],
     "di2p_bn_train_forward": [c_void_p] * 9 + [c_float, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "di2p_bn_train_backward": [c_void_p] * 6 + [c_int] + [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p, c_void_p],
@@ -118,6 +121,7 @@ _WS_SIGS = {        # <name>_workspace_bytes helpers returning long long
     "di2p_conv2d_wgrad_workspace_bytes": [c_int] * 9,
     "di2p_bf16x3_packed_bytes": [c_int] * 2,
     "di2p_head_x3_packed_bytes": [c_int],
+    "di2p_stem_x3_packed_bytes": [],
 }
 EXPORTS = sorted(list(_SIGS) + ["di2p_last_error", "di2p_version", "di2p_solve_workspace_bytes", "di2p_solver_set_profile_buffer", "di2p_pnp_workspace_bytes",
                  "di2p_conv2d_workspace_bytes", "di2p_set_option", "di2p_get_option", "di2p_random_choice_workspace_bytes", "di2p_classifier_loss_workspace_bytes"] + list(_WS_SIGS))

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdeepi2p_hip.so")
-SOURCES = ["common.cpp", "index_max.hip", "ball_query.hip", "point_ops.hip", "gemm.hip", "conv.hip", "solver.hip", "prep.hip", "pnp.hip", "rng.hip", "loss.hip", "train.hip", "winograd.hip", "stem.hip", "conv_x3.hip", "head_x3.hip"]
+SOURCES = ["common.cpp", "index_max.hip", "ball_query.hip", "point_ops.hip", "gemm.hip", "conv.hip", "solver.hip", "prep.hip", "pnp.hip", "rng.hip", "loss.hip", "train.hip", "winograd.hip", "stem.hip", "conv_x3.hip", "head_x3.hip", "stem_x3.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"] + os.environ.get("DI2P_EXTRA_HIPCC_FLAGS", "").split()
 # hipcc's SLP vectoriser turns adjacent scalar fp32 adds / multiplies (epilogues, the Winograd transforms, the solver's fp32

@@ -309,6 +309,7 @@ class ImageEncoder(_PackedModule):
             w_stem = sd[r + ".conv1.weight"]
             if w_stem.is_cuda and tuple(w_stem.shape) == (64, 3, 7, 7):
                 p["stem_p"] = ops.stem_weights(w_stem)
+                p["stem_x3"] = ops.stem_x3_weights(w_stem)      # conv1 + bn1 + relu + maxpool as one launch on the bf16 matrix instructions
             for li, nb in enumerate(self.LAYERS, start=1):
                 for bi in range(nb):
                     q = "%s.layer%d.%d" % (r, li, bi)
@@ -335,11 +336,14 @@ class ImageEncoder(_PackedModule):
         p = self._pack()
         ops.require_cuda(x)
         Wt, sc, sh, _ = p["stem"]
-        if "stem_p" in p and not _lib.get_option("conv_nostem"):
-            x = ops.conv_stem(x, p["stem_p"], sc, sh, True)
+        if "stem_x3" in p and _lib.get_option("stem_x3") and not _lib.get_option("conv_nostem") and ops.stem_x3_supported(x.shape[2], x.shape[3]):
+            x = ops.stem_x3(x, p["stem_x3"], sc, sh)
         else:
-            x = ops.conv2d(x, Wt, sc, sh, 7, 7, 2, 3, True)
-        x = ops.maxpool3x3s2(x)
+            if "stem_p" in p and not _lib.get_option("conv_nostem"):
+                x = ops.conv_stem(x, p["stem_p"], sc, sh, True)
+            else:
+                x = ops.conv2d(x, Wt, sc, sh, 7, 7, 2, 3, True)
+            x = ops.maxpool3x3s2(x)
         stage_out = {}
         wino = not _lib.get_option("conv_nowinograd")
         # bit s-1: the stride-1 layers of stage s, bit 4: the stride-2 layers (+ their 1x1 downsample branch) on di2p_conv3x3_x3

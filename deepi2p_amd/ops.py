@@ -467,6 +467,34 @@ def conv_stem(x, Wp, scale, shift, relu=True):
     return y
 
 
+def stem_x3_weights(weight):
+    """weight f32[64,3,7,7] -> the split, fragment-ordered operand of stem_x3 (uint8 storage)."""
+    require_cuda(weight)
+    if tuple(weight.shape) != (64, 3, 7, 7) or weight.dtype != _f32:
+        raise RuntimeError("stem_x3_weights needs the f32[64,3,7,7] ResNet stem filter")
+    w = weight.detach().contiguous()
+    Wp = torch.empty((_lib.load().di2p_stem_x3_packed_bytes(),), dtype=torch.uint8, device=w.device)
+    call("di2p_stem_x3_pack", ptr(w), ptr(Wp), stream())
+    return Wp
+
+
+def stem_x3_supported(H, W):
+    return bool(_lib.load().di2p_stem_x3_supported(int(H), int(W)))
+
+
+def stem_x3(x, Wp, scale, shift):
+    """conv1 + bn1 + relu + maxpool of the image branch in one launch (di2p_stem_x3): x f32[B,3,H,W] -> f32[B,64,H/4,W/4]."""
+    require_cuda(x, Wp, scale, shift)
+    B, C, H, W = x.shape
+    if C != 3:
+        raise RuntimeError("the stem takes 3 input channels")
+    y = torch.empty((B, 64, H // 4, W // 4), dtype=_f32, device=x.device)
+    if _lib.WORK is not None:
+        _lib.WORK["di2p_stem_x3"] = _lib.WORK.get("di2p_stem_x3", 0) + B * 64 * 147 * (H // 2) * (W // 2)
+    call("di2p_stem_x3", ptr(x), ptr(Wp), ptr(scale), ptr(shift), ptr(y), B, H, W, stream())
+    return y
+
+
 def winograd_weights(weight):
     """weight f32[Cout,Cin,3,3] -> U f32[16,Cin,Cout] = G g G^T per (ci, co): the operand of conv3x3_winograd."""
     Cout, Cin, KH, KW = weight.shape

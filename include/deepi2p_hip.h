@@ -240,6 +240,16 @@ int di2p_stem_pack(const float* weight, float* Wp, void* stream);
 int di2p_conv7x7s2_stem(const float* x, const float* Wp, const float* scale, const float* shift, float* y, int B, int H, int W, int relu,
                         void* stream);
 int di2p_maxpool3x3s2(const float* x, float* y, int B, int C, int H, int W, void* stream);
+/* The same head of the image branch -- conv1 7x7/2 + bn1 + relu + maxpool 3x3/2 (models/resnet.py:137-141,197-201) -- as ONE launch on the
+ * bf16 matrix instructions with exact three-way fp32 splits (six bf16 products per fp32 product, fp32 accumulation: as accurate against fp64
+ * as the fp32-MFMA stem); the 64 x H/2 x W/2 activation between the convolution and the pool stays in the compute unit.
+ *   di2p_stem_x3_pack: weight f32[64,3,7,7] -> Wp (di2p_stem_x3_packed_bytes() bytes, 16-byte aligned), once per checkpoint load.
+ *   di2p_stem_x3_supported: 1 if the image size runs (H % 4 == 0, W % 128 == 0, W <= 512), else 0 -- the caller then uses the two launches above.
+ *   di2p_stem_x3: y f32[B,64,H/4,W/4] = maxpool3x3/2/pad1(relu(scale * conv7x7/2/pad3(x f32[B,3,H,W]) + shift)). */
+long long di2p_stem_x3_packed_bytes(void);
+int di2p_stem_x3_pack(const float* weight, void* Wp, void* stream);
+int di2p_stem_x3_supported(int H, int W);
+int di2p_stem_x3(const float* x, const void* Wp, const float* scale, const float* shift, float* y, int B, int H, int W, void* stream);
 int di2p_global_avgpool(const float* x, float* y, int B, int C, int HW, void* stream);
 /* out[b,c] = max_n x[b,c,n]  (networks_pc.py:115) */
 int di2p_channel_max(const float* x, float* y, int B, int C, int N, void* stream);

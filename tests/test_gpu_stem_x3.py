@@ -1,0 +1,102 @@
+"""GPU parity of di2p_stem_x3 (conv1 7x7/2 + bn1 + relu + maxpool 3x3/2 of the image branch as one launch on the bf16 matrix instructions,
+exact three-way fp32 splits, stem_x3.hip) against an fp64 evaluation of the same fp32 operands and against the two fp32-MFMA launches it
+replaces (di2p_conv7x7s2_stem + di2p_maxpool3x3s2): the bf16x3 bar of the other contraction tests -- max error <= 1.25 x and rms error
+<= 1.1 x the fp32-MFMA path's.  Reference: models/resnet.py:137-141,197-201."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from deepi2p_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+# (B, H, W): the benchmark image, the smallest image, widths that leave waves without columns, a single pooled row per workgroup and ragged
+# last workgroups (PH = 9, 11: 2 pooled rows per workgroup, the last one short)
+SIZES = [(2, 160, 512), (3, 4, 128), (2, 16, 256), (2, 36, 384), (1, 44, 128), (5, 8, 512)]
+
+
+def _operands(B, H, W, seed, positive_shift=False):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    scale = torch.rand(64, generator=g) + 0.5
+    shift = torch.randn(64, generator=g) * 0.5 + (1.0 if positive_shift else 0.0)
+    return x, w, scale, shift
+
+
+def _ref64(x, w, scale, shift):
+    y = F.conv2d(x.double(), w.double(), stride=2, padding=3)
+    y = torch.relu(y * scale.view(1, -1, 1, 1).double() + shift.view(1, -1, 1, 1).double())
+    return F.max_pool2d(y, 3, 2, 1)
+
+
+def _err(y, ref):
+    d = (y.double() - ref).abs()
+    return float(d.max()), float((d ** 2).mean().sqrt())
+
+
+@pytest.mark.parametrize("B,H,W", SIZES)
+def test_stem_x3_matches_fp64_and_is_as_accurate_as_fp32_mfma(dev, B, H, W):
+    from deepi2p_amd import ops
+    assert ops.stem_x3_supported(H, W)
+    x, w, scale, shift = _operands(B, H, W, 11 + H + W, positive_shift=True)      # most outputs positive: the ReLU does not hide errors
+    xd, wd, sc, sh = x.to(dev), w.to(dev), scale.to(dev), shift.to(dev)
+    y3 = ops.stem_x3(xd, ops.stem_x3_weights(wd), sc, sh)
+    assert tuple(y3.shape) == (B, 64, H // 4, W // 4)
+    y1 = ops.maxpool3x3s2(ops.conv_stem(xd, ops.stem_weights(wd), sc, sh, True))
+    ref = _ref64(x, w, scale, shift)
+    (m3, r3), (m1, r1) = _err(y3.cpu(), ref), _err(y1.cpu(), ref)
+    tol = 3e-6 * 147 ** 0.5 * float(ref.abs().max()) + 1e-6
+    assert m3 <= tol and m3 <= 1.25 * m1 + 1e-7 and r3 <= 1.1 * r1 + 1e-8, (m3, m1, r3, r1, tol)
+
+
+def test_stem_x3_pool_semantics_with_negative_rows(dev):
+    """shift so negative that whole regions are clipped by the ReLU, and a frame of zeros: the pooled maximum of clipped rows is exactly 0"""
+    from deepi2p_amd import ops
+    x, w, scale, shift = _operands(2, 32, 256, 5)
+    shift = shift - 3.0
+    x[1] = 0.0
+    y = ops.stem_x3(x.to(dev), ops.stem_x3_weights(w.to(dev)), scale.to(dev), shift.to(dev)).cpu()
+    ref = _ref64(x, w, scale, shift)
+    assert _err(y, ref)[0] <= 2e-5
+    assert torch.equal(y[1], ref[1].float())          # a zero image: relu(shift) exactly, pooled
+
+
+def test_stem_x3_is_deterministic_and_batch_independent(dev):
+    from deepi2p_amd import ops
+    x, w, scale, shift = _operands(4, 160, 512, 3)
+    xd, Wp, sc, sh = x.to(dev), ops.stem_x3_weights(w.to(dev)), scale.to(dev), shift.to(dev)
+    y = ops.stem_x3(xd, Wp, sc, sh)
+    assert torch.equal(y, ops.stem_x3(xd, Wp, sc, sh))
+    assert torch.equal(y[2:3], ops.stem_x3(xd[2:3].contiguous(), Wp, sc, sh))
+
+
+def test_stem_x3_argument_checks(dev):
+    from deepi2p_amd import ops
+    x, w, scale, shift = _operands(1, 30, 512, 1)
+    assert not ops.stem_x3_supported(30, 512) and not ops.stem_x3_supported(32, 640) and not ops.stem_x3_supported(32, 192)
+    Wp = ops.stem_x3_weights(w.to(dev))
+    with pytest.raises(RuntimeError):
+        ops.stem_x3(x.to(dev), Wp, scale.to(dev), shift.to(dev))
+    with pytest.raises(RuntimeError):
+        ops.stem_x3_weights(torch.zeros(64, 3, 3, 3, device=dev))
+    with pytest.raises(RuntimeError):
+        ops.stem_x3(torch.zeros(1, 4, 32, 128, device=dev), Wp, scale.to(dev), shift.to(dev))
+
+
+def test_image_encoder_with_and_without_stem_x3(dev):
+    """the image branch with the fused stem against the two fp32-MFMA launches: same feature maps within the contraction tolerance"""
+    from deepi2p_amd import synthetic as nt
+    from deepi2p_amd.networks import ImageEncoder
+    opt = nt.OptLike(20480, 160, 512, False)
+    sd = {k[len("img_encoder."):]: v for k, v in nt.synthetic_state_dict(opt).items() if k.startswith("img_encoder.")}
+    enc = ImageEncoder(opt)
+    enc.load_state_dict(sd)
+    enc = enc.to(dev)
+    img = torch.rand(2, 3, 160, 512, generator=torch.Generator().manual_seed(1)).to(dev) * 255
+    with _lib.option("stem_x3", 1):
+        a = [t.clone() for t in enc(img)]
+    with _lib.option("stem_x3", 0):
+        b = [t.clone() for t in enc(img)]
+    for u, v in zip(a, b):
+        assert float((u - v).abs().max()) <= 2e-4 * float(v.abs().max()) + 1e-6

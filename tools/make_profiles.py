@@ -131,7 +131,7 @@ files listed in KEEP_OLD (if present) come from earlier calls of the round.
   contention.
 * `{TAG}_bench_kernel_stats_serial.csv` / `{TAG}_bench_line_serial.json` -- the same with `--streams 1` ({ser['value']:.0f} frames/s): durations without
   contention.  `solve_kernel` averages {avg('solve_kernel')/1e3:.2f} ms (rocprof) against {ser['kernels']['solve_kernel']['ms_per_step']:.2f} ms from the HIP events of the same run's JSON
-  line; `conv3x3_x3_kernel` (all instances) {avg('conv3x3_x3_kernel'):.1f} us per call; `point_head_kernel` {avg('point_head_kernel'):.1f} us; `knn_nodes_kernel<3>` {avg('knn_nodes_kernel<3>'):.1f} us, `index_max` {avg('index_max'):.1f} us.
+  line; `conv3x3_x3_kernel` (all instances) {avg('conv3x3_x3_kernel'):.1f} us per call; `point_head_x3_kernel` {avg('point_head_x3_kernel'):.1f} us; `knn_nodes_kernel<3>` {avg('knn_nodes_kernel<3>'):.1f} us, `index_max` {avg('index_max'):.1f} us.
 * `{TAG}_pmc_conv_{{FETCH,WRITE}}_SIZE.csv`, `{TAG}_pmc_traffic.json` -- separate `--pmc` passes (kernel-trace only) on `tools/bench_conv.py`; the
   solver's entry is COPIED from `{TAG}_solver_counters.json` (one source for its traffic: the file the bench line's `counters_file` names).
   solve_kernel: {sp['FETCH_SIZE_KiB']/1024:.1f} MiB fetched raw (x2 = {sp['fetch_bytes_corrected']/1e6:.1f} MB) per launch against 10.8 MB
