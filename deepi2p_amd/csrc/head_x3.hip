@@ -58,7 +58,9 @@ __device__ __forceinline__ f32x16 hx_mma(const u32x4_t& a, const u32x4_t& b, con
 // SYNC (TAB_LDS only): the workgroup's waves take every K-step together (one s_barrier each), so that the 12 KB weight panel of a K-step is
 // fetched from L2 once per workgroup and served to the other seven waves by the L1
 // DEEP (one wave per SIMD, 512 registers): a K-step's weight fragments are requested a whole K-step ahead (else plane by plane, as registers free up)
-template <bool TAB_LDS, int KS0, int NW, int MINW, bool SYNC, bool DEEP>
+// LEAN (two waves per SIMD, 256 registers): the gathered rows are requested one row group ahead instead of two (48 registers less in epilogue 0)
+// and the output layer's four sums are pinned row group by row group -- together: no scratch at 256 registers
+template <bool TAB_LDS, int KS0, int NW, int MINW, bool SYNC, bool DEEP, bool LEAN = false>
 __global__ __launch_bounds__(NW * 64, MINW) void point_head_x3_kernel(const HxArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* ssl = lds;                                  // [4][128] scale / shift rows
@@ -210,13 +212,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void point_head_x3_kernel(const HxAr
 #pragma unroll
             for (int s = 0; s < 6; ++s) rp[s] = (s < 3 ? T0 : T1) + gi[s] * rs + hq;
         }
-        float4 q[4][6];
+        float4 q[LEAN ? 2 : 4][6];
         auto g_issue = [&](int k, float4 (&qq)[6]) __attribute__((always_inline)) {
 #pragma unroll
             for (int s = 0; s < 6; ++s) qq[s] = *reinterpret_cast<const float4*>(rp[s] + 32 * (k >> 2) + 8 * (k & 3));
         };
         g_issue(0, q[0]);
-        g_issue(1, q[1]);
+        if (!LEAN) g_issue(1, q[1]);
         float f1[2 * HX_TM][8];
 #pragma unroll
         for (int i = 0; i < HX_TM; ++i) {
@@ -224,13 +226,17 @@ __global__ __launch_bounds__(NW * 64, MINW) void point_head_x3_kernel(const HxAr
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int k = 4 * i + gq;
-                // two row groups are reduced per scheduling region while the next two are in flight
-                if ((k & 1) == 0) {
+                if (LEAN) {
+                    // one row group is reduced per scheduling region while the next one is in flight
+                    if (k + 1 < 4 * HX_TM) g_issue(k + 1, q[(k + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if ((k & 1) == 0) {
+                    // two row groups are reduced per scheduling region while the next two are in flight
                     if (k + 2 < 4 * HX_TM) g_issue(k + 2, q[(k + 2) & 3]);
                     if (k + 3 < 4 * HX_TM) g_issue(k + 3, q[(k + 3) & 3]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                const float4 (&qq)[6] = q[k & 3];
+                const float4 (&qq)[6] = q[LEAN ? (k & 1) : (k & 3)];
                 float4 t4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
                 for (int s = 0; s < 6; ++s) {
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void point_head_x3_kernel(const HxAr
                 const float4 sh = *reinterpret_cast<const float4*>(ssl + HX_M + 32 * i + 8 * gq + hq);
                 v[4 * gq + 0] = (acc[i][4 * gq + 0] + t4.x) * sc.x + sh.x; v[4 * gq + 1] = (acc[i][4 * gq + 1] + t4.y) * sc.y + sh.y;
                 v[4 * gq + 2] = (acc[i][4 * gq + 2] + t4.z) * sc.z + sh.z; v[4 * gq + 3] = (acc[i][4 * gq + 3] + t4.w) * sc.w + sh.w;
-                if (k & 1) __builtin_amdgcn_sched_barrier(0);
+                if (LEAN || (k & 1)) __builtin_amdgcn_sched_barrier(0);
             }
             if (a.relu0) {
 #pragma unroll
@@ -308,6 +314,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void point_head_x3_kernel(const HxAr
                     part[0] = fmaf(w.x, y[j], part[0]); part[1] = fmaf(w.y, y[j], part[1]);
                     part[2] = fmaf(w.z, y[j], part[2]); part[3] = fmaf(w.w, y[j], part[3]);
                 }
+                // (the four sums are pinned row group by row group: left alone at 256 registers, hipcc forms all 64 activations first and then
+                //  the four dot products one after the other -- 140 bytes of scratch per lane, reloaded four times)
+                if (LEAN) asm volatile("" : "+v"(part[0]), "+v"(part[1]), "+v"(part[2]), "+v"(part[3]));
             }
         // the two halves of a column meet through the LDS crossbar (ds_bpermute with lane ^ 32; hipcc folds the SUM of the two results of one
         // v_permlane32_swap into twice the first -- measured: outputs came out as 2 x the low half-wave's partial sum)
@@ -385,7 +394,7 @@ extern "C" int di2p_point_head_x3(const di2p_head_x3_t* hd, float* out, int B, i
     hipStream_t st = (hipStream_t)stream;
     const size_t lds_small = (size_t)8 * HX_M * sizeof(float);
     const size_t lds_tab = lds_small + (size_t)(hd->nodes[0] + hd->nodes[1]) * HX_TROW * sizeof(float);
-    const long long opt = di2p_opt(DI2P_OPT_HEAD_X3_TAB);      // 0: tables from memory, 1 (default): in LDS when they fit
+    const long long opt = di2p_opt(DI2P_OPT_HEAD_X3_TAB);      // 0: tables from memory, 1 (default) / 2: in LDS when they fit (eight / four waves)
     DI2P_CHECK_ARG(a.K0 == 96, "this build instantiates the head for 96 dense channels (32 + 64: first_pointnet + second_pointnet)");
     if (opt != 0 && lds_tab <= 160 * 1024) {
         // whole workgroups per frame: enough of them to fill the chip, each with at least two passes over its waves
@@ -393,14 +402,15 @@ extern "C" int di2p_point_head_x3(const di2p_head_x3_t* hd, float* out, int B, i
         int parts = di2p_cdiv(cus, B);
         while (parts > 1 && a.nblk < parts * 16) --parts;
         a.parts = parts;
-        // four waves per workgroup, one per SIMD (512 registers: at two waves per SIMD -- 256 registers -- the kernel spills 370 bytes per lane and
-        // is slower alone, 430 against 315 us); knob value 3: the 8-wave instance
-        if (opt == 3) {
-            (void)hipFuncSetAttribute((const void*)point_head_x3_kernel<true, 6, 8, 2, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tab);
-            hipLaunchKernelGGL((point_head_x3_kernel<true, 6, 8, 2, false, false>), dim3(B * parts), dim3(512), lds_tab, st, a);
-        } else {
+        // Eight waves per workgroup, two per SIMD (256 registers, no scratch in the LEAN form): one wave's epilogues run under the other's matrix
+        // instructions -- 242 us alone against 339 for four waves with 512 registers (knob value 2; the eight-wave form with the deeper request
+        // rings spilled 368 bytes per lane and took 385-430 us).  In the 8-stream pipeline the two are within 0.5 % of each other.
+        if (opt == 2) {
             (void)hipFuncSetAttribute((const void*)point_head_x3_kernel<true, 6, 4, 1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tab);
             hipLaunchKernelGGL((point_head_x3_kernel<true, 6, 4, 1, false, true>), dim3(B * parts), dim3(256), lds_tab, st, a);
+        } else {
+            (void)hipFuncSetAttribute((const void*)point_head_x3_kernel<true, 6, 8, 2, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tab);
+            hipLaunchKernelGGL((point_head_x3_kernel<true, 6, 8, 2, false, false, true>), dim3(B * parts), dim3(512), lds_tab, st, a);
         }
     } else {
         const int grid = (int)(a.total / 4 < 1ll * di2p_cu_count() ? di2p_cdiv(a.total, 4) : di2p_cu_count());

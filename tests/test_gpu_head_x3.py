@@ -51,9 +51,11 @@ def _run_fp32(d, N):
 
 
 @pytest.mark.parametrize("B,N,nodes,P,tab", [(2, 20480, (128, 128), 2, 1), (3, 1000, (128, 128), 2, 1), (2, 4100, (64, 96), 4, 1),
-                                              (2, 1000, (128, 128), 2, 0), (1, 33, (16, 16), 1, 1), (2, 2048, (700, 700), 2, 1)])
+                                              (2, 1000, (128, 128), 2, 0), (1, 33, (16, 16), 1, 1), (2, 2048, (700, 700), 2, 1),
+                                              (2, 20480, (128, 128), 2, 2), (3, 1000, (128, 128), 4, 2)])
 def test_point_head_x3_matches_fp64_and_is_as_accurate_as_the_fp32_head(dev, B, N, nodes, P, tab):
-    """tab = 0: the node tables are gathered from memory (knob head_x3_tab); 700 nodes do not fit the LDS: the same path by itself.
+    """tab = 1: tables in LDS, eight waves per workgroup (the default); 2: four waves (one per SIMD); 0: the node tables are gathered from memory
+    (knob head_x3_tab); 700 nodes do not fit the LDS: the same path by itself.
     N = 1000 / 4100 / 33: ragged last blocks."""
     d = _case(dev, B, N, nodes, P, 11 + N + P, weights=(N != 4100))
     ref = _ref64(d)
@@ -72,9 +74,10 @@ def test_point_head_x3_is_deterministic_and_tables_in_lds_equal_tables_in_memory
     d = _case(dev, 2, 5000, (128, 128), 2, 5)
     a = _run_x3(d, 5000)
     assert torch.equal(a, _run_x3(d, 5000))
-    with _lib.option("head_x3_tab", 0):
-        b = _run_x3(d, 5000)
-    assert torch.equal(a, b)              # the same arithmetic in the same order, whatever the tables are read from
+    for tab in (0, 2):
+        with _lib.option("head_x3_tab", tab):
+            b = _run_x3(d, 5000)
+        assert torch.equal(a, b)          # the same arithmetic in the same order, whatever the tables are read from and however many waves share a SIMD
 
 
 def test_network_logits_with_and_without_head_x3(dev):
