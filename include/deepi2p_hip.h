@@ -24,7 +24,7 @@ extern "C" {
 const char* di2p_last_error(void);
 int di2p_version(void);
 /* Tuning / test knobs, cached in the library (initialised once from the environment variable DI2P_<NAME>): "conv_nosplit",
- * "conv_split_blocks", "conv_novec", "conv_cfg", "conv_depth1", "conv_x3", "conv_x3_cfg", "pw_novec", "solver_cfg", "solver_nocull", "solver_noprefilter", "solver_tier_sweeps".
+ * "conv_split_blocks", "conv_novec", "conv_cfg", "conv_depth1", "conv_x3", "conv_x3_cfg", "head_x3", "head_x3_tab", "stem_x3", "pw_x3", "pw_novec", "solver_cfg", "solver_nocull", "solver_noprefilter", "solver_tier_sweeps".
  * set: 0, or -1 for an unknown name; get: the value, or -1 for an unknown name. */
 int di2p_set_option(const char* name, long long value);
 long long di2p_get_option(const char* name);

@@ -29,7 +29,8 @@ timeout 100 python tools/bench_index_max.py > $OUT/${TAG}_index_max_cold.txt 2>&
 timeout 300 python tools/bench_conv_x3.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_conv_layers.txt
 timeout 100 python tools/diag_conv_x3_accuracy.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_conv_x3_accuracy.txt
 tools/bin/probe_mfma_rounding > $OUT/${TAG}_mfma_rounding.txt 2>&1
-timeout 100 python tools/bench_head_x3.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_head_x3.txt
+ROUNDS=3 REPS=50 timeout 200 python tools/bench_head_x3.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_head_x3.txt
+REPS=50 timeout 100 python tools/bench_stem_x3.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_stem_x3.txt
 timeout 100 python tools/probe_x3_ranges.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_x3_ranges.txt
 timeout 150 python tools/bench_winograd.py > $OUT/${TAG}_winograd_layers.txt 2>&1
 PROF=1 timeout 150 python tools/bench_solver.py > $OUT/${TAG}_solver_phases.txt 2>&1

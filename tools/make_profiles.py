@@ -20,7 +20,7 @@ for f in os.listdir(G):
 
 # ---- counter-derived HBM traffic
 passes = 13            # tools/bench_conv.py: 3 warm-up + 10 timed encoder passes
-conv_kernels = ("conv3x3_x3_kernel", "wino_conv_kernel", "wino_reg_kernel", "conv2d_vec_kernel", "conv2d_kernel", "conv2d_stem_kernel", "stem_conv_kernel", "conv_splitk_reduce_kernel")
+conv_kernels = ("conv3x3_x3_kernel", "stem_x3_kernel", "wino_conv_kernel", "wino_reg_kernel", "conv2d_vec_kernel", "conv2d_kernel", "conv2d_stem_kernel", "stem_conv_kernel", "conv_splitk_reduce_kernel")
 fetch16 = ("wino_conv_kernel", "wino_reg_kernel", "conv2d_vec_kernel", "conv_splitk_reduce_kernel")
 F = {r["kernel"]: r for r in rows(TAG + "_pmc_conv_FETCH_SIZE.csv")}
 Wr = {r["kernel"]: r for r in rows(TAG + "_pmc_conv_WRITE_SIZE.csv")}
@@ -149,6 +149,13 @@ files listed in KEEP_OLD (if present) come from earlier calls of the round.
 * `{TAG}_convx3_counters.json` -- `tools/prof_kernel_counters.sh` on `tools/run_conv_x3_only.py`: per kernel instance (= layer shape) the matrix-pipe busy
   cycles (`SQ_VALU_MFMA_BUSY_CYCLES`, cycles summed over the SIMDs) against the waves' lifetime (`SQ_WAVE_CYCLES`, quad-cycles x 4), waits, LDS bank
   conflicts, VALU / LDS instructions per matrix instruction, FETCH / WRITE.
+* `{TAG}_stem_x3.txt`, `{TAG}_head_x3.txt` -- `tools/bench_stem_x3.py` (conv1 + bn1 + relu + max-pool as one launch on the bf16 matrix instructions against
+  the two fp32-MFMA launches) and `tools/bench_head_x3.py` (the coarse per-point head: eight / four waves per workgroup, tables in LDS / from memory;
+  alternating rounds -- the first timings of a process run at lower clocks):
+```
+{open(P + TAG + "_stem_x3.txt").read().strip() if os.path.exists(P + TAG + "_stem_x3.txt") else "(not collected)"}
+{open(P + TAG + "_head_x3.txt").read().strip() if os.path.exists(P + TAG + "_head_x3.txt") else "(not collected)"}
+```
 * `{TAG}_conv_x3_accuracy.txt` -- `tools/diag_conv_x3_accuracy.py`: error against an fp64 convolution, bf16x3 per configuration next to the fp32-MFMA kernels.
 * `{TAG}_mfma_rounding.txt` -- `tools/probe_mfma_rounding.hip`: how the bf16 matrix instructions round (products of one instruction are aligned to the
   largest addend and truncated below its last bit; the fp32-input instruction is an exact fma chain) -- why the bf16x3 kernels keep the small products apart.
