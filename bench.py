@@ -388,9 +388,11 @@ def main():
                        "note": "3x3 layers (and the 1x1 / stride-2 branches fused into the stride-2 ones) as direct implicit GEMMs on the bf16 matrix "
                                "instructions, both fp32 operands split EXACTLY into three bf16 terms (six products per fp32 product, fp32 accumulation): "
                                "fp32_equivalent = 2*MAC / time, executed = 6 x that, priced against the 2.5 PFLOP/s dense bf16 peak"},
-            "note": "achieved = reference-algorithmic 2*MAC of the 36 convolutions (SURVEY 8d) / time of the whole family; the 3x3 "
-                    "stride-1 layers run as Winograd F(2x2,3x3) (16 instead of 36 multiplications per tile and channel pair, exact "
-                    "arithmetic in fp32): `winograd.executed_mfma_tflops` is what the MFMA units actually issue for them"},
+            "note": "achieved = reference-algorithmic 2*MAC of the 36 convolutions (SURVEY 8d) / time of the whole family, priced against the "
+                    "fp32-input MFMA peak (the arithmetic the reference computes in).  Launches on the bf16 matrix instructions (exact three-way "
+                    "splits: `bf16x3`, priced there on EXECUTED bf16 products against the bf16 peak) execute 6 bf16 products per fp32 product at "
+                    "16x the fp32-input rate -- hence a fraction above 1; launches that run as Winograd F(2x2,3x3) (shapes / knob settings without "
+                    "a bf16x3 instance) execute 16 instead of 36 multiplications: `winograd.executed_mfma_tflops`"},
         "pointwise_gemm_kernel(+point_head)": {
             "bound": "mfma", "achieved": 2e9 * POINTWISE_REF_GMAC_COARSE * B / (fam_ms["di2p_pointwise_gemm"] * 1e-3) / 1e12,
             "achieved_executed": pw_exec_flops / (fam_ms["di2p_pointwise_gemm"] * 1e-3) / 1e12,
