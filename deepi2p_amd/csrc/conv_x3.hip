@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3_kernel(const CxArgs a) {
                 if constexpr (RES) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        rv[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, co_off[i][r] + so[j], 0, 0));
+                        rv[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (int)((unsigned)co_off[i][r] + (unsigned)so[j]), 0, 0));
                 }
             }
 #pragma unroll
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3_kernel(const CxArgs a) {
                     float v = ac[i][j][r] * sc[i][r] + sh[i][r];
                     if constexpr (RES) v += rv[i][j][r];
                     v = relu ? fmaxf(v, 0.0f) : v;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, co_off[i][r] + so[j], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, (int)((unsigned)co_off[i][r] + (unsigned)so[j]), 0, 0);
                 }
     };
     if (a.residual) store(acc, a.scale, a.shift, a.residual, a.y, a.relu != 0, std::true_type{});

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256, 1) void stem_x3_kernel(const SxArgs a) {
 
     // ---- staging items of this thread (two input rows x three channels x LW / 4 column quads; LDS column L = input column + 3)
     const int QPR = a.LW / 4;
-    int st_off[SX_ITEMS][4], st_l[SX_ITEMS], st_rr[SX_ITEMS];
+    unsigned st_off[SX_ITEMS][4];            // (unsigned: column part + row part may both be the out-of-range constant)
+    int st_l[SX_ITEMS], st_rr[SX_ITEMS];
     bool st_ok[SX_ITEMS];
 #pragma unroll
     for (int it = 0; it < SX_ITEMS; ++it) {
@@ -95,21 +96,21 @@ __global__ __launch_bounds__(256, 1) void stem_x3_kernel(const SxArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {       // byte offset of input column 4 qq - 3 + e in row 0 of channel ci; out of range: the load returns 0
             const int icol = 4 * qq - 3 + e;
-            st_off[it][e] = (st_ok[it] && icol >= 0 && icol < a.W) ? (ci * a.H * a.W + icol) * 4 : SX_OOB;
+            st_off[it][e] = (st_ok[it] && icol >= 0 && icol < a.W) ? (unsigned)((ci * a.H * a.W + icol) * 4) : (unsigned)SX_OOB;
         }
     }
     float raw[SX_ITEMS][4];
     // (offsets are SUMS of a column part and a row part, either of which may be the out-of-range constant: no branches -- hipcc turned
     //  `ok ? offset : OOB` on a conjunction into a ladder of exec-mask branches around single loads)
     auto stage_load = [&](float (&raw)[SX_ITEMS][4], int irow_new) __attribute__((always_inline)) {
-        const int radd0 = (irow_new >= 0 && irow_new < a.H) ? irow_new * a.W * 4 : SX_OOB;
-        const int radd1 = (irow_new + 1 >= 0 && irow_new + 1 < a.H) ? (irow_new + 1) * a.W * 4 : SX_OOB;
+        const unsigned radd0 = (irow_new >= 0 && irow_new < a.H) ? (unsigned)(irow_new * a.W * 4) : (unsigned)SX_OOB;
+        const unsigned radd1 = (irow_new + 1 >= 0 && irow_new + 1 < a.H) ? (unsigned)((irow_new + 1) * a.W * 4) : (unsigned)SX_OOB;
 #pragma unroll
         for (int it = 0; it < SX_ITEMS; ++it) {
-            const int radd = st_rr[it] ? radd1 : radd0;
+            const unsigned radd = st_rr[it] ? radd1 : radd0;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                raw[it][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, st_off[it][e] + radd, 0, 0));
+                raw[it][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)(st_off[it][e] + radd), 0, 0));
         }
     };
     auto stage_store = [&](const float (&raw)[SX_ITEMS][4], int irow_new) __attribute__((always_inline)) {
