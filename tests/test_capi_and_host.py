@@ -45,6 +45,26 @@ def test_argument_errors_are_reported_not_crashed():
     _lib.call("di2p_index_max_forward", None, None, None, 0, 4, 10, 8, None, None)
 
 
+def test_host_side_shape_queries_of_the_bf16x3_entry_points():
+    """Pure host logic behind the C ABI (no device needed): which shapes the round-5 kernels take, and the sizes of their packed operands."""
+    from deepi2p_amd import _lib
+    lib = _lib.load()
+    # stem + pool in one launch: H % 4 == 0, W % 128 == 0, W <= 512 (include/deepi2p_hip.h)
+    assert lib.di2p_stem_x3_supported(160, 512) == 1 and lib.di2p_stem_x3_supported(4, 128) == 1
+    for H, W in ((30, 512), (160, 640), (160, 192), (0, 128), (2, 128)):
+        assert lib.di2p_stem_x3_supported(H, W) == 0, (H, W)
+    assert lib.di2p_stem_x3_packed_bytes() == 11 * 2 * 3 * 64 * 16           # [K-step][channel tile][plane][lane] x 16 B
+    # the head's fragment-ordered weights: [K / 16][4 row tiles][3 planes][64 lanes] x 16 B
+    assert lib.di2p_head_x3_packed_bytes(96) == 6 * 4 * 3 * 1024 and lib.di2p_head_x3_packed_bytes(128) == 8 * 4 * 3 * 1024
+    assert lib.di2p_head_x3_packed_bytes(100) == 0                           # K % 16 != 0: nothing to pack
+    # the seven 3x3 layer shapes of ResNet-34 at 160 x 512 have a bf16x3 instance; odd sizes under stride 2 and Cin < 16 do not
+    for Cin, H, W, Cout, s in ((64, 40, 128, 64, 1), (128, 20, 64, 128, 1), (256, 10, 32, 256, 1), (512, 5, 16, 512, 1),
+                               (64, 40, 128, 128, 2), (128, 20, 64, 256, 2), (256, 10, 32, 512, 2)):
+        assert lib.di2p_conv3x3_x3_supported(32, Cin, H, W, Cout, s) == 1, (Cin, H, W, Cout, s)
+    assert lib.di2p_conv3x3_x3_supported(32, 64, 41, 128, 128, 2) == 0 and lib.di2p_conv3x3_x3_supported(32, 8, 40, 128, 64, 1) == 0
+    assert lib.di2p_conv3x3_x3_supported(1, 64, 40, 128, 64, 1) == lib.di2p_conv3x3_x3_supported(64, 64, 40, 128, 64, 1) == 1     # batch independent
+
+
 def test_no_cpu_fallback_paths():
     from deepi2p_amd import ball_query, index_max, ops
     x = torch.zeros(1, 2, 8)
