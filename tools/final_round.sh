@@ -19,6 +19,8 @@ if [ "$STAGE" = "counters" ]; then
     timeout 600 bash tools/prof_kernel_counters.sh ${TAG}_convx3 conv3x3_x3 python tools/run_conv_x3_only.py > $OUT/${TAG}_convx3_counters.log 2>&1
   PASSES="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU;SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU;FETCH_SIZE;WRITE_SIZE" \
     timeout 400 bash tools/prof_kernel_counters.sh ${TAG}_headx3 point_head_x3 python tools/run_head_x3_only.py > $OUT/${TAG}_headx3_counters.log 2>&1
+  PASSES="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU;SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU;FETCH_SIZE;WRITE_SIZE" \
+    timeout 300 bash tools/prof_kernel_counters.sh ${TAG}_stemx3 stem_x3_kernel python tools/run_stem_x3_only.py > $OUT/${TAG}_stemx3_counters.log 2>&1
   ls $OUT | grep "^${TAG}_" | tr '\n' ' '
   exit 0
 fi
