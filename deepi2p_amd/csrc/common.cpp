@@ -17,7 +17,7 @@ void di2p_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* di2p_last_error(void) { return g_err; }
-extern "C" int di2p_version(void) { return 5; }
+extern "C" int di2p_version(void) { return 6; }
 
 namespace {
 struct OptDef { const char* name; const char* env; long long def; };

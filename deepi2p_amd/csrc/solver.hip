@@ -33,7 +33,19 @@
 #define DI2P_SOLVER_DEFAULT_WPH 4
 #endif
 #ifndef DI2P_SOLVER_PF
-#define DI2P_SOLVER_PF 4          // clusters classified per straight-line batch of the cluster walk
+#define DI2P_SOLVER_PF 4          // guard-only clusters walked per straight-line batch of the cluster walk (sizes the per-wave queue as well)
+#endif
+#ifndef DI2P_SOLVER_PFC
+#define DI2P_SOLVER_PFC 4         // clusters CLASSIFIED per straight-line batch (1, 2 or 4)
+#endif
+#ifndef DI2P_SOLVER_NOVALID
+#define DI2P_SOLVER_NOVALID 0     // 1: no per-lane validity masks in the walk (padding lanes are copies of valid records; the ballot is cut by a scalar mask)
+#endif
+#ifndef DI2P_SOLVER_CAMF
+#define DI2P_SOLVER_CAMF 0        // 1: the normalised plane coefficients come from a per-frame table (prepare_kernel) instead of being re-derived per wave and sweep
+#endif
+#ifndef DI2P_SOLVER_WRITELANE
+#define DI2P_SOLVER_WRITELANE 0   // 1: a batch's results go into the owning lane by v_writelane (one instruction per value) instead of compare + select
 #endif
 
 namespace {
@@ -178,7 +190,8 @@ template <typename PT>
 __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ points, const int* __restrict__ labels, int N, int P,
                                                        int NCMAX, unsigned long long* __restrict__ keys_all,
                                                        Rec<PT>* __restrict__ packed, Box* __restrict__ boxes_all,
-                                                       int* __restrict__ counts, int force_bitonic) {
+                                                       int* __restrict__ counts, int force_bitonic, const double* __restrict__ Kmat, double H,
+                                                       double W, float* __restrict__ camf_all) {
     constexpr int CH = 8192;                       // LDS chunk (64 KB)
     __shared__ unsigned long long chunk[CH];
     __shared__ float s_f[4][16];
@@ -446,7 +459,18 @@ __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ po
             boxes[c] = bx;
         }
     }
-    if (tid == 0) { counts[4 * f] = n1; counts[4 * f + 1] = n0; counts[4 * f + 2] = nc1; counts[4 * f + 3] = nc0; }
+    if (tid == 0) {
+        counts[4 * f] = n1; counts[4 * f + 1] = n0; counts[4 * f + 2] = nc1; counts[4 * f + 3] = nc0;
+        // the frame's NORMALISED frustum-plane coefficients in fp32 (see Pre32 below): they depend on the camera only, so every sweep of every
+        // hypothesis reads them back with scalar loads instead of re-deriving them (six conversions, four divisions, eight products per wave and sweep)
+        const double* Kf = Kmat + (long long)f * 9;
+        float* cf = camf_all + (long long)f * 8;
+        const float fx = (float)Kf[0], cx = (float)Kf[2], wcx = (float)((W - 1.0) - Kf[2]), fy = (float)Kf[4], cy = (float)Kf[5], hcy = (float)((H - 1.0) - Kf[5]);
+        const float iL = 1.0f / (fabsf(fx) + fabsf(cx)), iR = 1.0f / (fabsf(fx) + fabsf(wcx));
+        const float iT = 1.0f / (fabsf(fy) + fabsf(cy)), iB = 1.0f / (fabsf(fy) + fabsf(hcy));
+        cf[0] = fx * iL; cf[1] = cx * iL; cf[2] = fx * iR; cf[3] = wcx * iR;
+        cf[4] = fy * iT; cf[5] = cy * iT; cf[6] = fy * iB; cf[7] = hcy * iB;
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -461,6 +485,7 @@ __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ po
 //   reduction: xor-butterfly inside each wave, then the 4 wave partials are combined through LDS in a FIXED
 //     order by every thread, so all 256 threads hold bit-identical sums and the LM control flow that
 //     follows is workgroup-uniform.
+constexpr int PROF_WORDS = 28;      // int64 words per hypothesis of the diagnostics buffer (library version >= 6; 20 in versions 4-5)
 constexpr int QCAP = DI2P_SOLVER_PF * 64 + 128;        // per-wave queue capacity (ids); phase B drains it when a batch of the cluster walk (PF clusters) may not fit
 
 constexpr int BOXTEST_WORDS = 16;   // sizeof(BoxAbs) / 4 (the table is fetched as 16-byte LDS reads)
@@ -736,11 +761,21 @@ struct Pre32 {
     float aL, bL, aR, bR, aT, bT, aB, bB;      // f_L = aL p0 + bL p2, f_R = -aR p0 + bR p2, f_T = aT p1 + bT p2, f_B = -aB p1 + bB p2
 };
 template <int NP>
-__device__ __forceinline__ void make_pre32(const Rot<NP>& rot, double tx, double ty, double tz, const Cam& k, Pre32& q) {
+__device__ __forceinline__ void make_pre32(const Rot<NP>& rot, double tx, double ty, double tz, const Cam& k, const float* camf, Pre32& q) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) q.R[i] = (float)rot.R[i];
     q.t[0] = (float)tx; q.t[1] = (float)ty; q.t[2] = (float)tz;
     q.T1 = (fabsf(q.t[0]) + fabsf(q.t[1]) + fabsf(q.t[2])) * 1.000001f;
+#if DI2P_SOLVER_CAMF
+    // the camera-only part comes from the frame's table (prepare_kernel: the same expressions, the same bits), through scalar loads
+    q.aL = camf[0]; q.bL = camf[1]; q.aR = camf[2]; q.bR = camf[3]; q.aT = camf[4]; q.bT = camf[5]; q.aB = camf[6]; q.bB = camf[7];
+    {
+        float* f = reinterpret_cast<float*>(&q);
+#pragma unroll
+        for (int i = 0; i < 13; ++i) f[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, f[i])));      // R, t, T1
+    }
+    return;
+#endif
     const float fx = (float)k.fx, cx = (float)k.cx, wcx = (float)(k.W1 - k.cx), fy = (float)k.fy, cy = (float)k.cy, hcy = (float)(k.H1 - k.cy);
     const float iL = 1.0f / (fabsf(fx) + fabsf(cx)), iR = 1.0f / (fabsf(fx) + fabsf(wcx));
     const float iT = 1.0f / (fabsf(fy) + fabsf(cy)), iB = 1.0f / (fabsf(fy) + fabsf(hcy));
@@ -848,6 +883,52 @@ __device__ __forceinline__ void wave_min4_nonneg(float& a, float& b, float& c, f
     d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), 63));
 }
 
+// The same for TWO values and for ONE (batches of the classification walk smaller than four): fewer independent instructions separate a value's
+// consecutive joins, so the DPP read-after-write wait states are filled with s_nop.
+__device__ __forceinline__ void wave_min2_nonneg(float& a, float& b) {
+#define DI2P_MIN2(CTRL) "v_min_u32_dpp %0, %0, %0 " CTRL "\n\t" "v_min_u32_dpp %1, %1, %1 " CTRL "\n\t" "s_nop 0\n\t"
+    asm volatile("s_nop 1\n\t"
+                 DI2P_MIN2("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 DI2P_MIN2("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 DI2P_MIN2("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 DI2P_MIN2("row_mirror row_mask:0xf bank_mask:0xf")
+                 DI2P_MIN2("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 DI2P_MIN2("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(a), "+v"(b));
+#undef DI2P_MIN2
+    a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
+    b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 63));
+}
+__device__ __forceinline__ void wave_min1_nonneg(float& a) {
+#define DI2P_MIN1(CTRL) "v_min_u32_dpp %0, %0, %0 " CTRL "\n\t" "s_nop 1\n\t"
+    asm volatile("s_nop 1\n\t"
+                 DI2P_MIN1("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 DI2P_MIN1("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 DI2P_MIN1("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 DI2P_MIN1("row_mirror row_mask:0xf bank_mask:0xf")
+                 DI2P_MIN1("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 DI2P_MIN1("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(a));
+#undef DI2P_MIN1
+    a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
+}
+// old with lane `sel` (wave-uniform) replaced by the wave-uniform value `val`: one v_writelane_b32 per value (ignores the exec mask).  The lane
+// select travels in m0: gfx9 allows ONE scalar register per vector instruction, m0 next to it.
+__device__ __forceinline__ int di2p_writelane(int val, int sel, int old) {
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(sel) : "m0");
+    return old;
+}
+__device__ __forceinline__ void di2p_writelane3(int sel, int v0, int v1, int v2, int& o0, int& o1, int& o2) {
+    asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0"
+                 : "+v"(o0), "+v"(o1), "+v"(o2) : "s"(sel), "s"(v0), "s"(v1), "s"(v2) : "m0");
+}
+template <int N> __device__ __forceinline__ void wave_min_nonneg(float* v) {
+    static_assert(N == 1 || N == 2 || N == 4, "batch sizes of the cluster walk");
+    if (N == 4) wave_min4_nonneg(v[0], v[1], v[2], v[3]);
+    if (N == 2) wave_min2_nonneg(v[0], v[1]);
+    if (N == 1) wave_min1_nonneg(v[0]);
+}
+
 // CLASSIFICATION CACHE (temporal coherence of the cluster walk).  Between two sweeps of a hypothesis the iterate moves little (line-search
 // trials along one step, LM steps that shrink towards the minimum), while a cluster that needs per-point work needs it sweep after sweep
 // because a frustum plane passes through its box.  When a cluster IS classified per point, the wave also takes the minimum of the points'
@@ -914,7 +995,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                 const int n_nxt = queue[min(pos + 64 + lane, QCAP - 1)];
                 const Rec<PT> r_nxt = recs[min(max(n_nxt, 0), cnt - 1)];          // unconditional, clamped (the last one is wasted)
                 if (pos + lane < total) eval_active<NP, PT, LAB, MODE>(r_cur, rot, x, k, cost, lg, lA, bad);
-                if (PROFILE) n_active[0] += min(64, total - pos);
+                if (PROFILE) { n_active[0] += min(64, total - pos); n_active[LAB == 1 ? 9 : 10] += 1; }
                 n_cur = n_nxt; r_cur = r_nxt;
             }
             acc[0][lane] = cost.m; acc_e[lane] = cost.e;
@@ -1014,6 +1095,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
         if (PROFILE) {
             n_active[1] += __popcll(mA); n_active[2] += __popcll(mB); n_active[3] += __popcll(mC);
             n_active[4] += __popcll(mD); n_active[5] += __popcll(__ballot(cached_guard));
+            n_active[11] += 1; n_active[8] += __popcll(mA | mB | mD);
             tp[0] += clock64() - ts0;
         }
         // ---- phase I.  The flagged clusters are walked PF AT A TIME in straight-line code (a cluster's 64 records are one 16-byte load per
@@ -1027,6 +1109,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
 #pragma unroll
             for (int u = 0; u < PF; ++u) { nb[u] = take_bit(mg); ring_r[u] = load_rec((j0 + nb[u]) * WPH + wave); }
             while (nb[0] >= 0) {
+                if (PROFILE) n_active[6] += 1;
                 float sm[PF];
                 int nbp[PF];
                 Rec<PT> cur[PF];
@@ -1034,67 +1117,110 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                 for (int u = 0; u < PF; ++u) {
                     cur[u] = ring_r[u];
                     nbp[u] = nb[u];
+#if !DI2P_SOLVER_NOVALID
                     const bool valid = nb[u] >= 0 && ((j0 + nb[u]) * WPH + wave) * CL + lane < cnt;      // exhausted slots / padding lanes
+#endif
                     nb[u] = take_bit(mg);
                     ring_r[u] = load_rec((j0 + nb[u]) * WPH + wave);
                     bool a;
                     float sl;
                     prefilter32<NP, 0>(pre, (float)cur[u].x, (float)cur[u].y, (float)cur[u].z, a, sl);
                     sl = (use_pre && sl > 0.0f) ? sl : 0.0f;                    // not certified (or NaN) -> 0
+#if DI2P_SOLVER_NOVALID
+                    // no lane mask: the padding lanes of a block's last cluster hold COPIES of its last record (prepare_kernel), so they change
+                    // neither the minimum nor the verdict of the exact test; the value of an exhausted slot (nbp < 0) is never used
+                    sm[u] = sl;
+#else
                     sm[u] = valid ? sl : __builtin_inff();
+#endif
                 }
-                static_assert(PF == 4, "wave_min4_nonneg joins four values");
-                wave_min4_nonneg(sm[0], sm[1], sm[2], sm[3]);
+                wave_min_nonneg<PF>(sm);
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
                     if (nbp[u] >= 0) {              // wave-uniform
                         if (!(sm[u] > 0.0f)) {      // rare: some record the fp32 guard cannot certify -> exact test of this cluster
+#if DI2P_SOLVER_NOVALID
+                            (void)exact_active(cur[u], true);                      // sets `bad` on a zero
+#else
                             const int c = (j0 + nbp[u]) * WPH + wave;
                             (void)exact_active(cur[u], c * CL + lane < cnt);       // sets `bad` on a zero
+#endif
                         }
-                        slack = lane == nbp[u] ? sm[u] : slack;            // into the lane that owns the cluster
+                        // into the lane that owns the cluster
+#if DI2P_SOLVER_WRITELANE
+                        slack = __builtin_bit_cast(float, di2p_writelane(__builtin_bit_cast(int, sm[u]), nbp[u], __builtin_bit_cast(int, slack)));
+#else
+                        slack = lane == nbp[u] ? sm[u] : slack;
+#endif
                     }
                 }
             }
         }
         if (mA) {
-            // (b) clusters classified per point (status 1)
+            // (b) clusters classified per point (status 1), PFC at a time
+            constexpr int PFC = DI2P_SOLVER_PFC;
             unsigned long long mo = mA;
-            int nb[PF];
-            Rec<PT> ring_r[PF];
+            int nb[PFC];
+            Rec<PT> ring_r[PFC];
 #pragma unroll
-            for (int u = 0; u < PF; ++u) { nb[u] = take_bit(mo); ring_r[u] = load_rec((j0 + nb[u]) * WPH + wave); }
+            for (int u = 0; u < PFC; ++u) { nb[u] = take_bit(mo); ring_r[u] = load_rec((j0 + nb[u]) * WPH + wave); }
             while (nb[0] >= 0) {
-                Rec<PT> cur[PF];
-                int nbp[PF];
-                bool valid[PF], act[PF];
-                float sm[PF];
+                if (PROFILE) n_active[7] += 1;
+                Rec<PT> cur[PFC];
+                int nbp[PFC];
+                bool act[PFC];
+                float sm[PFC];
+#if !DI2P_SOLVER_NOVALID
+                bool valid[PFC];
+#endif
 #pragma unroll
-                for (int u = 0; u < PF; ++u) {
+                for (int u = 0; u < PFC; ++u) {
                     cur[u] = ring_r[u];
                     nbp[u] = nb[u];
+#if !DI2P_SOLVER_NOVALID
                     valid[u] = nb[u] >= 0 && ((j0 + nb[u]) * WPH + wave) * CL + lane < cnt;
+#endif
                     nb[u] = take_bit(mo);
                     ring_r[u] = load_rec((j0 + nb[u]) * WPH + wave);
                 }
 #pragma unroll
-                for (int u = 0; u < PF; ++u) {          // no short circuits: PF independent, branch-free instruction streams
+                for (int u = 0; u < PFC; ++u) {          // no short circuits: PFC independent, branch-free instruction streams
                     bool a;
                     float sl;
                     prefilter32<NP, LAB>(pre, (float)cur[u].x, (float)cur[u].y, (float)cur[u].z, a, sl);
                     sl = (use_pre && sl > 0.0f) ? sl : 0.0f;
+#if DI2P_SOLVER_NOVALID
+                    act[u] = a;           // the padding lanes (copies of the block's last record) are cut from the BALLOT by a scalar mask below
+                    sm[u] = sl;
+#else
                     act[u] = valid[u] & a;
                     sm[u] = valid[u] ? sl : __builtin_inff();
+#endif
                 }
-                wave_min4_nonneg(sm[0], sm[1], sm[2], sm[3]);
+                wave_min_nonneg<PFC>(sm);
 #pragma unroll
-                for (int u = 0; u < PF; ++u) {
+                for (int u = 0; u < PFC; ++u) {
                     if (nbp[u] >= 0) {              // wave-uniform
+#if DI2P_SOLVER_NOVALID
+                        if (!(sm[u] > 0.0f)) act[u] = exact_active(cur[u], true);        // rare: some record is not certified -> exact test for THAT cluster
+                        const int nvr = cnt - ((j0 + nbp[u]) * WPH + wave) * CL;          // valid records of the cluster (scalar), >= 1
+                        const unsigned long long bal = __ballot(act[u]) & (nvr >= CL ? ~0ull : ((1ull << nvr) - 1ull));
+#else
                         if (!(sm[u] > 0.0f)) act[u] = exact_active(cur[u], valid[u]);        // rare: some record is not certified -> exact test for THAT cluster
                         const unsigned long long bal = __ballot(act[u]);
+#endif
+                        // into the lane that owns the cluster
+#if DI2P_SOLVER_WRITELANE
+                        {
+                            int o0 = (int)mlo, o1 = (int)mhi, o2 = __builtin_bit_cast(int, slack);
+                            di2p_writelane3(nbp[u], (int)(unsigned)bal, (int)(unsigned)(bal >> 32), __builtin_bit_cast(int, sm[u]), o0, o1, o2);
+                            mlo = (unsigned)o0; mhi = (unsigned)o1; slack = __builtin_bit_cast(float, o2);
+                        }
+#else
                         mlo = lane == nbp[u] ? (unsigned)bal : mlo;
                         mhi = lane == nbp[u] ? (unsigned)(bal >> 32) : mhi;
-                        slack = lane == nbp[u] ? sm[u] : slack;            // into the lane that owns the cluster
+                        slack = lane == nbp[u] ? sm[u] : slack;
+#endif
                     }
                 }
             }
@@ -1136,7 +1262,7 @@ template <int CTRL> __device__ __forceinline__ double dpp_double(double v) {
 // specialised loops.
 template <int NP, typename PT, int WPH, int MODE, bool PROFILE>
 __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Box* __restrict__ boxes, int cnt1, int cnt0, int nc1,
-                                     int nc0, const Cam& k, const double* x, int nocull, SweepShared<NP, WPH>& sh, CacheEnt* __restrict__ cache, int s_now,
+                                     int nc0, const Cam& k, const float* camf, const double* x, int nocull, SweepShared<NP, WPH>& sh, CacheEnt* __restrict__ cache, int s_now,
                                      int* n_active, long long* tp) {
     constexpr int NV = Tri<NP>::N + NP + 2;
     const long long tq0 = PROFILE ? clock64() : 0;
@@ -1162,7 +1288,7 @@ __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Bo
         for (int i = 1; i < 1 + NP + Tri<NP>::N; ++i) acc[i][lane] = 0.0;
     }
     Pre32 pre;        // fp32 table of the iterate (SGPRs), shared by the cluster test and the per-point pre-filter of both label blocks
-    make_pre32<NP>(rot, x[TOFF], x[TOFF + 1], x[TOFF + 2], k, pre);
+    make_pre32<NP>(rot, x[TOFF], x[TOFF + 1], x[TOFF + 2], k, camf, pre);
     if (!(nocull & 1)) {   // box-test table of this iterate: every lane computes the same values, lane 0 stores them
         BoxAbs ab;
         make_box_abs(pre, ab);
@@ -1684,6 +1810,7 @@ struct SolveArgs {
     unsigned long long* state_buf;
     int* pending;
     CacheEnt* cache;           // classification cache: [F * R][NCMAX + CACHE_PAD]
+    const float* camf;         // [F][8] normalised frustum-plane coefficients (prepare_kernel)
     double H, W;
     Bounds bnd;
     int NCMAX, nocull, max_iter, F, R, N, budget, resume;
@@ -1709,6 +1836,7 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
     const int* counts = a->counts;
     const int cnt1 = counts[4 * f], cnt0 = counts[4 * f + 1], nc1 = counts[4 * f + 2], nc0 = counts[4 * f + 3];
     const double* Kf = a->Kmat + (long long)f * 9;
+    const float* camf = a->camf + (long long)f * 8;       // the frame's normalised plane coefficients (prepare_kernel)
     const int nocull = a->nocull;
     const long long hr = (long long)f * R + r;
     CacheEnt* cache = a->cache + hr * (a->NCMAX + CACHE_PAD);
@@ -1737,7 +1865,10 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
     }
     __syncthreads();
     long long c_sweep = 0, c_wait = 0, c_lm = 0, c_comb = 0;
-    int n_act[6] = {0, 0, 0, 0, 0, 0};   // wave 0: phase-B evaluations, clusters classified per point / all active / guard-only, cache hits {classification, guard}
+    // wave 0: [0] phase-B evaluations, [1..3] clusters classified per point / all active / guard-only, [4..5] cache hits {classification, guard},
+    // [6..7] straight-line batches of the guard / classification walk, [8] clusters appended by phase II, [9..10] phase-B rounds {label 1, label 0},
+    // [11] cluster-test rounds
+    int n_act[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // sweep numbers of the classification cache count from this launch's first sweep (resume: the cache and the ring start empty)
     const int s_base = a->resume ? st.nsweep : 0;
     if (threadIdx.x == 0) {
@@ -1760,7 +1891,9 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
         asm volatile("" : "+s"(Kq));
         const Cam k{Kq[0], Kq[4], Kq[2], Kq[5], a->H - 1.0, a->W - 1.0};
         const long long t0 = PROFILE ? clock64() : 0;
-        sweep<NP, PT, WPH, 2, PROFILE>(recs, boxes, cnt1, cnt0, nc1, nc0, k, xe, nocull, sh, cache, s_now, n_act, tp);
+        const float* cfq = camf;
+        asm volatile("" : "+s"(cfq));
+        sweep<NP, PT, WPH, 2, PROFILE>(recs, boxes, cnt1, cnt0, nc1, nc0, k, cfq, xe, nocull, sh, cache, s_now, n_act, tp);
         const long long t1 = PROFILE ? clock64() : 0;
         __syncthreads();
         const long long t2 = PROFILE ? clock64() : 0;
@@ -1830,12 +1963,13 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
             for (int i = threadIdx.x; i < ST_WORDS; i += WPH * 64) state_buf[hr * ST_WORDS + i] = src[i];
         }
     }
-    if (PROFILE && threadIdx.x == 0) {   // diagnostics, 20 int64 per hypothesis (wave 0's shader-clock cycles and counts; see di2p_solver_set_profile_buffer)
-        long long* prof = a->prof + hr * 20;
-        long long v[20] = {c_sweep, c_wait, c_lm, n_act[0], n_act[1], n_act[2], c_comb,
+    if (PROFILE && threadIdx.x == 0) {   // diagnostics, PROF_WORDS int64 per hypothesis (wave 0's shader-clock cycles and counts; see di2p_solver_set_profile_buffer)
+        long long* prof = a->prof + hr * PROF_WORDS;
+        long long v[PROF_WORDS] = {c_sweep, c_wait, c_lm, n_act[0], n_act[1], n_act[2], c_comb,
                            (long long)st.n_ls_extra | ((long long)st.n_ls_late_accept << 20) | ((long long)st.n_resweep << 40),
-                           c_decide, c_poly, c_apply, n_act[3], tp[0], tp[1], tp[2], tp[3], n_act[4], n_act[5], 0, 0};
-        for (int i = 0; i < 20; ++i) prof[i] = (a->resume && i != 7 ? prof[i] : 0) + v[i];
+                           c_decide, c_poly, c_apply, n_act[3], tp[0], tp[1], tp[2], tp[3], n_act[4], n_act[5],
+                           n_act[6], n_act[7], n_act[8], n_act[9], n_act[10], n_act[11], 0, 0, 0, 0};
+        for (int i = 0; i < PROF_WORDS; ++i) prof[i] = (a->resume && i != 7 ? prof[i] : 0) + v[i];
     }
     if (threadIdx.x == 0 && st.done) {
         double* params_out = a->params_out;
@@ -2019,7 +2153,7 @@ __global__ __launch_bounds__(256) void residuals_kernel(const double* __restrict
 static long long* g_prof = nullptr;   // diagnostics hook, see di2p_solver_set_profile_buffer
 
 constexpr size_t kStateBytes = sizeof(LMState<6>) > sizeof(LMState<4>) ? sizeof(LMState<6>) : sizeof(LMState<4>);
-struct SolveWs { int P, NCMAX; size_t off_recs, off_boxes, off_keys, off_pending, off_state, off_cache, bytes; };
+struct SolveWs { int P, NCMAX; size_t off_recs, off_boxes, off_keys, off_pending, off_state, off_cache, off_camf, bytes; };
 static SolveWs solve_ws_layout(int F, int R, int N) {
     SolveWs w;
     w.P = 64;
@@ -2032,7 +2166,8 @@ static SolveWs solve_ws_layout(int F, int R, int N) {
     w.off_pending = up(w.off_keys + (size_t)F * 2 * w.P * 8);
     w.off_state = up(w.off_pending + (size_t)F * R * sizeof(int));
     w.off_cache = up(w.off_state + (size_t)F * R * kStateBytes);
-    w.bytes = up(w.off_cache + (size_t)F * R * (w.NCMAX + CACHE_PAD) * sizeof(CacheEnt)) + 256;
+    w.off_camf = up(w.off_cache + (size_t)F * R * (w.NCMAX + CACHE_PAD) * sizeof(CacheEnt));
+    w.bytes = up(w.off_camf + (size_t)F * 8 * sizeof(float)) + 256;
     return w;
 }
 
@@ -2043,15 +2178,16 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
     Bounds b;
     for (int i = 0; i < 3; ++i) { b.lb[i] = lb[i]; b.ub[i] = ub[i]; }
     // workspace: counts i32[F][4] | records Rec[F][N] | cluster boxes [F][NCMAX] | sort keys u64[F][P] | pending i32[F][R] | parked LM states [F][R] |
-    // classification cache [F][R][NCMAX + CACHE_PAD]
+    // classification cache [F][R][NCMAX + CACHE_PAD] | normalised plane coefficients f32[F][8]
     const SolveWs ws = solve_ws_layout(F, R, N);
     char* base = (char*)workspace;
     int* counts = (int*)base;
     Rec<PT>* packed = (Rec<PT>*)(base + ws.off_recs);
     Box* boxes = (Box*)(base + ws.off_boxes);
     unsigned long long* keys = (unsigned long long*)(base + ws.off_keys);
+    float* camf = (float*)(base + ws.off_camf);
     hipLaunchKernelGGL(prepare_kernel<PT>, dim3(F), dim3(1024), 0, st, points, labels, N, ws.P, ws.NCMAX, keys, packed, boxes, counts,
-                       (int)(di2p_opt(DI2P_OPT_SOLVER_PREP_BITONIC) != 0));
+                       (int)(di2p_opt(DI2P_OPT_SOLVER_PREP_BITONIC) != 0), K, H, W, camf);
     // DI2P_SOLVER_CFG=<waves per hypothesis><min waves/SIMD>, e.g. 43 (default); DI2P_SOLVER_NOCULL=1 classifies every
     // cluster per point (the sums are bit-identical by construction: tests compare the two)
     const int cfg = (int)di2p_opt(DI2P_OPT_SOLVER_CFG);
@@ -2070,6 +2206,7 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
     ka.packed = packed; ka.boxes_all = boxes; ka.counts = counts; ka.Kmat = K; ka.init_y = init_y; ka.init_T = init_T; ka.yaw0 = yaw0;
     ka.params_out = params; ka.cost_out = cost; ka.iters_out = iters; ka.sweeps_out = sweeps; ka.prof = g_prof; ka.state_buf = state;
     ka.cache = (CacheEnt*)(base + ws.off_cache);
+    ka.camf = camf;
     ka.H = H; ka.W = W; ka.bnd = b; ka.NCMAX = ws.NCMAX; ka.nocull = nocull; ka.max_iter = max_iter; ka.F = F; ka.R = R; ka.N = N;
     // the diagnostics (phase clocks, cluster / evaluation counters) are a separate instantiation: the production kernel carries none of it
 #define DI2P_LAUNCH_SOLVE_P(NPV, MW, WP, PEND, BUDGET, RESUME)                                                                   \
@@ -2171,10 +2308,11 @@ extern "C" long long di2p_solve_workspace_bytes(int F, int R, int N) {
     return (long long)solve_ws_layout(F, R, N).bytes;
 }
 
-// Diagnostics: when set to a device buffer of F*R*20 int64 (library version >= 4; 16 before), every solve launch (a separate instantiation of the kernel) records per
+// Diagnostics: when set to a device buffer of F*R*28 int64 (library version >= 6; 20 in versions 4-5; 16 before), every solve launch (a separate instantiation of the kernel) records per
 // hypothesis: [0..2] shader-clock cycles wave 0 spent in {sweep, waiting at the reduction barrier, LM update}, [3] its phase-B
 // evaluations, [4..5] its clusters {classified per point, taken as all-active}, [6] cycles combining the wave partials, [7] packed
 // line-search counters, [8..10] LM stages {decide, wave-wide interpolant minimiser, finish + begin iteration}, [11] guard-only
 // clusters, [12..15] inside the sweep: {cluster-test rounds, drains = phase B, set-up, log + wave reduction}, [16..17] classification-cache
-// hits {clusters whose recorded mask was re-used, guard-only clusters skipped} ([4] and [11] count the misses), [18..19] reserved.
+// hits {clusters whose recorded mask was re-used, guard-only clusters skipped} ([4] and [11] count the misses), [18..19] straight-line batches of the
+// {guard-only, classification} walk, [20] clusters appended by phase II, [21..22] phase-B rounds of 64 {label 1, label 0}, [23] cluster-test rounds, [24..27] reserved.
 extern "C" void di2p_solver_set_profile_buffer(void* buf) { g_prof = (long long*)buf; }

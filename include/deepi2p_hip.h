@@ -289,8 +289,9 @@ int di2p_solve_batched_f32(const float* points, const int32_t* labels, const dou
                            int max_iter, int is_2d, int F, int R, int N,
                            double* params, double* cost, int32_t* iters, int32_t* sweeps /* may be NULL: #passes over the points */, void* workspace, void* stream);
 long long di2p_solve_workspace_bytes(int F, int R, int N);
-/* diagnostics only: device buffer of F*R*16 int64 (or NULL) receiving per-hypothesis phase cycle counts and cluster statistics
- * (layout: csrc/solver.hip at the definition; F*R*8 words up to version 2).  While set, solves run a separate, instrumented kernel. */
+/* diagnostics only: device buffer of F*R*28 int64 (or NULL) receiving per-hypothesis phase cycle counts and cluster statistics
+ * (layout: csrc/solver.hip at the definition; F*R*8 words up to version 2, 16 in version 3, 20 in versions 4-5).  While set, solves run
+ * a separate, instrumented kernel. */
 void di2p_solver_set_profile_buffer(void* buf);
 int di2p_select_best(const double* params, const double* cost, const int32_t* has_inside, int is_2d,
                      int F, int R, int32_t* best, double* P, double* best_cost, void* stream);

@@ -5,6 +5,7 @@
                   coarse+fine models; split-K on and off (the split-K / tile / XCD-order choices are shape dependent).
   configs[0]      Oxford single pair: N=8192, 160x512, B=1, R=1 -- network -> argmax -> solvePGivenK against the oracle.
   configs[2]      B=64 and configs[3] B=16: the stated batch sizes through the size-independent properties.
+  configs[3]/[4]  one frame at the config's own shape (30000 pts / 896x1600 fine; 40960 pts / 384x640 coarse): every logit vs the oracle.
 Tolerances: |dlogit| <= 1e-3 * max|logit|, label flips < 0.1 % (and none where the reference's own margin
 exceeds the tolerance)."""
 import math
@@ -172,6 +173,29 @@ def test_config3_shape_logits_vs_oracle(dev):
     assert float((fine - rf).abs().max()) <= REL * float(rf.abs().max()) + 1e-7
     assert (coarse.argmax(1) != rc.argmax(1)).float().mean() < 1e-3
     assert (fine.argmax(1) != rf.argmax(1)).float().mean() < 1e-3
+
+
+def test_config4_shape_logits_vs_oracle(dev):
+    """BASELINE configs[4] at its frame shape (Oxford: 40960 points, 384 x 640 image, coarse head), B = 1: every logit against the
+    oracle restatement run here on the same frame.  At 384 x 640 the 3x3 layers take the RUN-TIME-row-length instances of
+    `conv3x3_x3_kernel` (the template instances are the 160 x 512 shapes) and the fp32 stem + pool (`stem_x3` needs W % 128 == 0): a tile
+    path no golden covers.  Also against the library's own fp32 kernels (conv_x3 / stem_x3 / pw_x3 / head_x3 off)."""
+    from deepi2p_amd import _lib
+    N, H, W = 40960, 384, 640
+    det, opt = _det(dev, N, H, W, False)
+    b = synthetic.make_batch(404, 1, N=N, H=H, W=W)
+    x = [torch.from_numpy(b[k]).to(dev) for k in fg.NAMES]
+    coarse = det(*x)
+    assert coarse.shape == (1, 2, N)
+    with _lib.option("conv_x3", 0), _lib.option("stem_x3", 0), _lib.option("pw_x3", 0), _lib.option("head_x3", 0):
+        coarse_fp32 = det(*x)
+    torch.set_num_threads(32)
+    sd = nt.synthetic_state_dict(nt.OptLike(N, H, W, False))
+    with torch.no_grad():
+        rc = nt.keypoint_detector(sd, nt.OptLike(N, H, W, False), *[torch.from_numpy(b[k]) for k in fg.NAMES])
+    for name, got in (("bf16x3 paths on", coarse.cpu()), ("fp32 kernels", coarse_fp32.cpu())):
+        assert float((got - rc).abs().max()) <= REL * float(rc.abs().max()) + 1e-7, name
+        assert (got.argmax(1) != rc.argmax(1)).float().mean() < 1e-3, name
 
 
 def test_config3_stated_batch_16_per_gpu(dev):

@@ -207,7 +207,7 @@ def test_classification_cache_is_bit_identical_in_both_tiers(dev, seed, is_2d, N
 
     def run(profile=False):
         sweeps = torch.zeros((1, R), dtype=torch.int32, device=dev)
-        prof = torch.zeros((R, 20), dtype=torch.int64, device=dev) if profile else None
+        prof = torch.zeros((R, 28), dtype=torch.int64, device=dev) if profile else None      # 28 words per hypothesis since library version 6
         if profile:
             _lib.load().di2p_solver_set_profile_buffer(prof.data_ptr())
         try:

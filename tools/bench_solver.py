@@ -5,6 +5,7 @@ import numpy as np, torch
 from deepi2p_amd import ops, synthetic
 from deepi2p_amd.registration import RegistrationPipeline
 
+PFC = int(os.environ.get("PFC", 4))     # clusters per straight-line batch of the classification walk (for the fill figure)
 F, N, R, H, W = int(os.environ.get("F", 32)), int(os.environ.get("N", 20480)), 60, 160, 512
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(0)
@@ -40,7 +41,7 @@ for name, lab_np in (("noisy-gt", np.stack([f["labels"] for f in frames])),):
     if os.environ.get("PROF"):
         from deepi2p_amd import _lib
         ver = _lib.load().di2p_version()
-        PW = 20 if ver >= 4 else (16 if ver >= 3 else 8)       # int64 words per hypothesis (version 3: finer phases, 4: classification-cache hits)
+        PW = 28 if ver >= 6 else (20 if ver >= 4 else (16 if ver >= 3 else 8))       # int64 words per hypothesis (version 3: finer phases, 4: classification-cache hits, 6: walk batches / rounds)
         prof = torch.zeros((F, R, PW), dtype=torch.int64, device=dev)
         _lib.load().di2p_solver_set_profile_buffer(prof.data_ptr())
         ops.solve_batched(pc, lab_front, K, restarts[0], restarts[1], H, W, pipe.lb, pipe.ub, 500, True, yaw0=yaw0, sweeps=sweeps)
@@ -55,6 +56,10 @@ for name, lab_np in (("noisy-gt", np.stack([f["labels"] for f in frames])),):
         if PW >= 20:
             print("  classification cache (wave 0, clusters per sweep): re-used masks %.1f (misses = per-point above)  guard walks skipped %.1f (misses = guard-only above)" % (
                 (p[:, 16] / sw).mean(), (p[:, 17] / sw).mean()))
+        if PW >= 28:
+            print("  walk (wave 0, per sweep): cluster-test rounds %.2f  guard batches %.2f (fill %.2f)  classification batches %.2f (fill %.2f)  phase-II appends %.1f  phase-B rounds label-1 %.2f label-0 %.2f" % (
+                (p[:, 23] / sw).mean(), (p[:, 18] / sw).mean(), p[:, 11].sum() / max(4 * p[:, 18].sum(), 1), (p[:, 19] / sw).mean(), p[:, 4].sum() / max(PFC * p[:, 19].sum(), 1),
+                (p[:, 20] / sw).mean(), (p[:, 21] / sw).mean(), (p[:, 22] / sw).mean()))
         if PW >= 16:
             print("  LM stages per sweep: combine %.0f  decide %.0f  wave minimiser %.0f  finish+begin %.0f" % tuple((p[:, i] / sw).mean() for i in (6, 8, 9, 10)))
             print("  inside the sweep (wave 0, cycles per sweep): set-up %.0f  cluster-test rounds %.0f  phase B (drains) %.0f  log+reduction %.0f  -> cluster walk / phase A %.0f" % (
