@@ -452,13 +452,24 @@ CxPlan cx_best(int B, int Cin, int H, int W, int Cout, int stride, long long for
     return best;
 }
 
+// The size limits of the kernels' 31-bit buffer offsets and of the grid: ONE predicate for `supported()` and for the launch entry (a layer
+// that `supported()` admits must not fail at the call: the host layers fall back to the fp32 kernels on `supported() == 0` only).
+const char* cx_size_limit(int B, int Cin, int H, int W, int Cout, const CxPlan* plan) {
+    if ((long long)Cout * H * W * 4 >= (1ll << 30)) return "per-frame output must stay below 2^30 bytes";
+    if ((long long)Cin * H * W * 4 >= (1ll << 31) || (long long)9 * (Cin / 8) * (di2p_cdiv(Cout, 128) * 128) * 48 >= (1ll << 31))
+        return "per-frame input and the packed weights must fit 31-bit byte offsets";
+    if (plan && (long long)B * plan->tiles_per_frame * plan->n_mt >= (1ll << 31)) return "too many workgroups";
+    return nullptr;
+}
+
 }  // namespace
 
-// 1 if di2p_conv3x3_x3 can run this layer (some tile configuration fits its shape and the LDS), else 0.
+// 1 if di2p_conv3x3_x3 can run this layer (some tile configuration fits its shape and the LDS, and the sizes fit the kernels' offsets), else 0.
 extern "C" int di2p_conv3x3_x3_supported(int B, int Cin, int H, int W, int Cout, int stride) {
     if (B < 1 || Cin < 16 || H < 1 || W < 1 || Cout < 1 || (stride != 1 && stride != 2)) return 0;
     if (stride == 2 && (H % 2 || W % 2)) return 0;
-    return cx_best(B, Cin, H, W, Cout, stride, di2p_opt(DI2P_OPT_CONV_X3_CFG), nullptr).cfg >= 0 ? 1 : 0;
+    const CxPlan best = cx_best(B, Cin, H, W, Cout, stride, di2p_opt(DI2P_OPT_CONV_X3_CFG), nullptr);
+    return best.cfg >= 0 && cx_size_limit(B, Cin, H, W, Cout, &best) == nullptr ? 1 : 0;
 }
 
 // y f32[B,Cout,OH,OW] = relu?( scale * conv3x3(x f32[B,Cin,H,W]; pad 1, stride 1|2) + shift + residual ), weights Wp = di2p_bf16x3_pack of
@@ -475,9 +486,10 @@ extern "C" int di2p_conv3x3_x3(const float* x, const void* Wp, const float* scal
     const bool ds = Wp_ds != nullptr;
     DI2P_CHECK_ARG(ds == (stride == 2), "stride 2 runs WITH the fused 1x1 / stride-2 branch of the same input (and only stride 2 has one)");
     DI2P_CHECK_ARG(!ds || (scale_ds && shift_ds && y_ds), "the fused 1x1 branch needs its scale / shift / output");
-    DI2P_CHECK_ARG((long long)Cout * H * W * 4 < (1ll << 30), "per-frame output must stay below 2^30 bytes");
-    DI2P_CHECK_ARG((long long)Cin * H * W * 4 < (1ll << 31) && (long long)9 * (Cin / 8) * (di2p_cdiv(Cout, 128) * 128) * 48 < (1ll << 31),
-                   "per-frame input and the packed weights must fit 31-bit byte offsets");
+    {
+        const char* why = cx_size_limit(B, Cin, H, W, Cout, nullptr);
+        DI2P_CHECK_ARG(why == nullptr, why);
+    }
     if (B == 0) return 0;
     int inst = -1;
     const CxPlan best = cx_best(B, Cin, H, W, Cout, stride, di2p_opt(DI2P_OPT_CONV_X3_CFG), &inst);
@@ -490,7 +502,7 @@ extern "C" int di2p_conv3x3_x3(const float* x, const void* Wp, const float* scal
     a.spr = best.spr; a.nseg = best.nseg; a.tiles_per_frame = best.tiles_per_frame; a.n_mt = best.n_mt;
     a.PW = best.PW; a.PWH = best.PWH; a.PP = best.PP; a.PPU = best.PPU; a.relu = relu;
     const long long grid = (long long)B * best.tiles_per_frame * best.n_mt;
-    DI2P_CHECK_ARG(grid < (1ll << 31), "too many workgroups");
+    DI2P_CHECK_ARG(cx_size_limit(B, Cin, H, W, Cout, &best) == nullptr, "too many workgroups");
     hipStream_t st = (hipStream_t)stream;
     const bool ok = cx_launch(inst, best, a, (int)grid, st);
     DI2P_CHECK_ARG(ok, "internal: no kernel instance for the plan");

@@ -22,6 +22,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 
 // default instantiation of the 2-D solver: <min waves per SIMD> x <waves per hypothesis> (override for experiments: -D...).
 // 4 x 4: four workgroups of four waves per CU (128 VGPRs; 39.5 KB of LDS each); measured 7.40 vs 7.80 ms per launch and 3679 vs 3555
@@ -36,13 +37,28 @@
 #define DI2P_SOLVER_PF 4          // guard-only clusters walked per straight-line batch of the cluster walk (sizes the per-wave queue as well)
 #endif
 #ifndef DI2P_SOLVER_PFC
-#define DI2P_SOLVER_PFC 4         // clusters CLASSIFIED per straight-line batch (1, 2 or 4)
+#define DI2P_SOLVER_PFC 2         // clusters CLASSIFIED per straight-line batch (1, 2 or 4): ~2 per label block and round need it since the cache (round 6: 4 -> 2, -2 % vector instructions)
 #endif
 #ifndef DI2P_SOLVER_NOVALID
-#define DI2P_SOLVER_NOVALID 0     // 1: no per-lane validity masks in the walk (padding lanes are copies of valid records; the ballot is cut by a scalar mask)
+#define DI2P_SOLVER_NOVALID 1     // 1: no per-lane validity masks in the walk (padding lanes are copies of valid records; the ballot is cut by a scalar mask)
 #endif
 #ifndef DI2P_SOLVER_CAMF
-#define DI2P_SOLVER_CAMF 0        // 1: the normalised plane coefficients come from a per-frame table (prepare_kernel) instead of being re-derived per wave and sweep
+#define DI2P_SOLVER_CAMF 1        // 1: the normalised plane coefficients come from a per-frame table (prepare_kernel) instead of being re-derived per wave and sweep
+#endif
+#ifndef DI2P_SOLVER_BOXMS
+#define DI2P_SOLVER_BOXMS 0       // 1: the per-point margin m S of the walk is the CLUSTER's (from its box: >= every point's), read from the lane that owns the cluster
+#endif
+#ifndef DI2P_SOLVER_EXEC_APPEND
+#define DI2P_SOLVER_EXEC_APPEND 0 // 1: phase II stores a cluster's active ids under exec = its active mask (no per-lane bit test)
+#endif
+#ifndef DI2P_SOLVER_LMROT
+#define DI2P_SOLVER_LMROT 0       // 1: the wave that advances the LM state rotates with the sweep number (spreads the single-lane code over the SIMDs)
+#endif
+#ifndef DI2P_SOLVER_FLATROUND
+#define DI2P_SOLVER_FLATROUND 0   // 1: the cluster-test round (status decision table, cache look-up) as selects instead of nested divergent branches
+#endif
+#ifndef DI2P_SOLVER_GUARD_TBZ
+#define DI2P_SOLVER_GUARD_TBZ 0   // 1: guard-only clusters whose box clears the left / right planes by DI2P_GUARD_LR_MIN are guarded on the top / bottom / z planes only
 #endif
 #ifndef DI2P_SOLVER_WRITELANE
 #define DI2P_SOLVER_WRITELANE 0   // 1: a batch's results go into the owning lane by v_writelane (one instruction per value) instead of compare + select
@@ -767,8 +783,12 @@ __device__ __forceinline__ void make_pre32(const Rot<NP>& rot, double tx, double
     q.t[0] = (float)tx; q.t[1] = (float)ty; q.t[2] = (float)tz;
     q.T1 = (fabsf(q.t[0]) + fabsf(q.t[1]) + fabsf(q.t[2])) * 1.000001f;
 #if DI2P_SOLVER_CAMF
-    // the camera-only part comes from the frame's table (prepare_kernel: the same expressions, the same bits), through scalar loads
-    q.aL = camf[0]; q.bL = camf[1]; q.aR = camf[2]; q.bR = camf[3]; q.aT = camf[4]; q.bT = camf[5]; q.aB = camf[6]; q.bB = camf[7];
+    // the camera-only part comes from the frame's table (prepare_kernel: the same expressions, the same bits), through SCALAR loads: the table
+    // was written by an earlier kernel and is read through the constant address space (a uniform load from plain global memory becomes a
+    // per-lane vector load as soon as the kernel also stores to global memory)
+    typedef const float __attribute__((address_space(4))) * ConstF;
+    const ConstF cf = (ConstF)camf;
+    q.aL = cf[0]; q.bL = cf[1]; q.aR = cf[2]; q.bR = cf[3]; q.aT = cf[4]; q.bT = cf[5]; q.aB = cf[6]; q.bB = cf[7];
     {
         float* f = reinterpret_cast<float*>(&q);
 #pragma unroll
@@ -792,8 +812,8 @@ __device__ __forceinline__ void make_pre32(const Rot<NP>& rot, double tx, double
 // evaluation failure in the reference).  slack > 0 <=> the point is certified (act is then the exact test's answer); NaN / inf anywhere
 // fails that comparison.
 template <int NP, int LAB>
-__device__ __forceinline__ void prefilter32(const Pre32& q, float X, float Y, float Z, bool& act, float& slack) {
-    const float mS = kPreRel * ((fabsf(X) + fabsf(Y)) + (fabsf(Z) + q.T1));
+__device__ __forceinline__ void prefilter32(const Pre32& q, float X, float Y, float Z, bool& act, float& slack, float mS_given = -1.0f) {
+    const float mS = DI2P_SOLVER_BOXMS ? mS_given : kPreRel * ((fabsf(X) + fabsf(Y)) + (fabsf(Z) + q.T1));
     float p0, p1, p2;
     if (NP == 4) {
         p0 = fmaf(q.R[0], X, fmaf(q.R[2], Z, q.t[0])); p1 = Y + q.t[1]; p2 = fmaf(q.R[6], X, fmaf(q.R[8], Z, q.t[2]));
@@ -815,6 +835,21 @@ __device__ __forceinline__ void prefilter32(const Pre32& q, float X, float Y, fl
     }
 }
 
+// The guard of a status-5 cluster: slack towards the top / bottom / z planes only (8 instead of 16 instructions for the plane functions).
+template <int NP>
+__device__ __forceinline__ float guard32_tbz(const Pre32& q, float X, float Y, float Z, float mS_given = -1.0f) {
+    const float mS = DI2P_SOLVER_BOXMS ? mS_given : kPreRel * ((fabsf(X) + fabsf(Y)) + (fabsf(Z) + q.T1));
+    float p1, p2;
+    if (NP == 4) {
+        p1 = Y + q.t[1]; p2 = fmaf(q.R[6], X, fmaf(q.R[8], Z, q.t[2]));
+    } else {
+        p1 = fmaf(q.R[3], X, fmaf(q.R[4], Y, fmaf(q.R[5], Z, q.t[1])));
+        p2 = fmaf(q.R[6], X, fmaf(q.R[7], Y, fmaf(q.R[8], Z, q.t[2])));
+    }
+    const float fT = fmaf(q.aT, p1, q.bT * p2), fB = fmaf(-q.aB, p1, q.bB * p2);
+    return fminf(fminf(fabsf(fT), fabsf(fB)), fabsf(p2)) - mS;       // one v_min3_f32
+}
+
 // The box-test table of an iterate, from the pre-filter's table (same fp32 R, t and normalised plane coefficients).
 __device__ __forceinline__ void make_box_abs(const Pre32& p, BoxAbs& q) {
     const float g = 1.0f + 1e-5f;
@@ -828,8 +863,13 @@ __device__ __forceinline__ void make_box_abs(const Pre32& p, BoxAbs& q) {
     }
     q.T1 = fabsf(p.t[0]) + fabsf(p.t[1]) + fabsf(p.t[2]);
 }
+// Status 5 (label 0, DI2P_SOLVER_GUARD_TBZ): a guard-only cluster whose box clears BOTH the left and the right plane by more than kGuardLrMin
+// (normalised plane units = metres).  No point of it can sit on those two planes, and the box's clearance *lr_slack is a lower bound of every
+// point's |f_L|, |f_R| minus its margin (the box margin contains the point margin: mS_box >= mS_point, support >= the point's offset): the
+// per-point guard evaluates the top / bottom / z planes only and the recorded slack is min(point slack on those three, *lr_slack).
+constexpr float kGuardLrMin = 0.25f;
 template <int NP, int LAB>
-__device__ __forceinline__ int cluster_status(const Box& bx, const Pre32& q, const BoxAbs& ab) {
+__device__ __forceinline__ int cluster_status(const Box& bx, const Pre32& q, const BoxAbs& ab, float* lr_slack = nullptr) {
     const float mS = kPreRel * (((fabsf(bx.cx) + fabsf(bx.cy)) + (fabsf(bx.cz) + ab.T1)) + ((bx.hx + bx.hy) + bx.hz));
     float p0, p1, p2;
     if (NP == 4) {
@@ -847,13 +887,37 @@ __device__ __forceinline__ int cluster_status(const Box& bx, const Pre32& q, con
     const float lo = fminf(fminf(fminf(fL - tL, fR - tR), fminf(fT - tT, fB - tB)), p2 - tZ);
     const float cm = fminf(fminf(fminf(fabsf(fL) - tL, fabsf(fR) - tR), fminf(fabsf(fT) - tT, fabsf(fB) - tB)), fabsf(p2) - tZ);
     const bool inside = lo > 0.0f;
+#if DI2P_SOLVER_FLATROUND
+    {   // the same decision table without divergent branches (every lane of a round takes another path through the nested form: the wave runs
+        // all of them anyway, plus the register copies at their joins); a NaN fails every comparison -> 1, as below
+        const float hi_ = fminf(fminf(fminf(fL + tL, fR + tR), fminf(fT + tT, fB + tB)), p2 + tZ);
+        const bool decided = cm > 0.0f, neg = hi_ < 0.0f;
+        if (LAB == 1) return decided ? (inside ? 0 : 2) : (neg ? 2 : 1);
+        int g = 3;
+#if DI2P_SOLVER_GUARD_TBZ
+        const float lrs = fminf(fabsf(fL) - tL, fabsf(fR) - tR);
+        *lr_slack = lrs;
+        g = lrs > kGuardLrMin ? 5 : 3;
+#endif
+        return decided ? (inside ? 2 : 0) : (neg ? g : 1);
+    }
+#endif
     if (cm > 0.0f) return (LAB == 1) ? (inside ? 0 : 2) : (inside ? 2 : 0);
     // a decided-negative plane already decides every point: not inside.  Label 1: all active.  Label-0 points of such a
     // cluster may still sit exactly on one of the undecided planes (dx, dy or p2 == 0 is an evaluation failure in the
     // reference): status 3 = no point can be active, but every point is still checked against exact zeros (fp32 guard,
     // exact test when the guard cannot certify) -- without the ballot / queue work of a real classification.
     const float hi = fminf(fminf(fminf(fL + tL, fR + tR), fminf(fT + tT, fB + tB)), p2 + tZ);
-    if (hi < 0.0f) return LAB == 1 ? 2 : 3;      // label 0: nothing is active, but an exact zero on an undecided plane must still be found
+    if (hi < 0.0f) {
+        if (LAB == 1) return 2;
+#if DI2P_SOLVER_GUARD_TBZ
+        const float lrs = fminf(fabsf(fL) - tL, fabsf(fR) - tR);
+        *lr_slack = lrs;
+        return lrs > kGuardLrMin ? 5 : 3;      // NaN -> 3
+#else
+        return 3;      // label 0: nothing is active, but an exact zero on an undecided plane must still be found
+#endif
+    }
     return 1;
 }
 
@@ -1033,15 +1097,76 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
     constexpr int PF = DI2P_SOLVER_PF;
     auto take_bit = [](unsigned long long& m) { int b = -1; if (m) { b = (int)__builtin_ctzll(m); m &= m - 1; } return b; };
     const unsigned bit_lo = lane < 32 ? 1u << lane : 0u, bit_hi = lane >= 32 ? 1u << (lane - 32) : 0u;
+    const int nv_last = cnt - (nc - 1) * CL;                 // valid records of the block's last cluster (scalar), 1..CL
+    const unsigned long long tail_mask = nv_last >= CL ? ~0ull : ((1ull << (nv_last & 63)) - 1ull);
+    const unsigned tail_lo = (unsigned)tail_mask, tail_hi = (unsigned)(tail_mask >> 32);
+#if DI2P_SOLVER_EXEC_APPEND
+    const unsigned queue_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int*)queue;      // LDS byte address of the wave's queue
+#endif
     for (int j0 = 0; j0 < mine; j0 += 64) {
         const long long ts0 = PROFILE ? clock64() : 0;
         const int j = j0 + lane;
         int status = 0;
         unsigned mlo = 0u, mhi = 0u;      // active mask of the lane's cluster (status 4: cached, 2: its valid records, 1: filled in by phase I)
         float slack = 0.0f;               // min slack of the lane's cluster (phase I)
+        float lr_slack = 0.0f;            // status 5: the box's clearance of the left / right planes
         bool cached_guard = false;
+        // DI2P_SOLVER_BOXMS: the margin m S of the per-point tests of the lane's cluster, from its box (|x|_1 <= |c|_1 + |h|_1 for every point of it: a
+        // margin that is never smaller than the point's own -- more points fall to the exact test, none is certified wrongly); +inf switches the
+        // fp32 tests off (solver_noprefilter), NaN (a poisoned box) certifies nothing
+        float ms_box = 0.0f;
         if (j < mine) {
             const int c = j * WPH + wave;
+            const Box bx = boxes[c];           // (solver_nocull needs it for the margin only)
+#if DI2P_SOLVER_BOXMS
+            ms_box = use_pre ? kPreRel * (((fabsf(bx.cx) + fabsf(bx.cy)) + (fabsf(bx.cz) + pre.T1)) + ((bx.hx + bx.hy) + bx.hz)) : __builtin_inff();
+#endif
+#if DI2P_SOLVER_FLATROUND
+            {
+                // the table is wave-uniform and only needed here (<= 2 rounds per label block): fetched from LDS per round instead of
+                // staying in VGPRs through the cluster walk
+                BoxAbs ab;
+                asm volatile("" ::: "memory");
+                const float4* bt4 = reinterpret_cast<const float4*>(btest_lds);
+                float4* dst4 = reinterpret_cast<float4*>(&ab);
+#pragma unroll
+                for (int i = 0; i < (int)(sizeof(BoxAbs) / 16); ++i) dst4[i] = bt4[i];
+                CacheEnt e;                                     // fetched together with the box, whatever the box test will say
+                e.mlo = e.mhi = 0u; e.slack = 0.0f; e.stamp = 0u;
+                if (use_cache) e = cache_w[j];                  // wave-uniform
+                const int st = nocull ? 1 : cluster_status<NP, LAB>(bx, pre, ab, &lr_slack);       // (solver_nocull: the table is stale, the result unused)
+                // the cache look-up of every lane, as selects: hit <=> the cluster needs per-point work, its entry is in the ring and its slack
+                // covers the motion since the recorded iterate (an empty entry -- stamp 0 -- reads ring slot 7: any iterate, unused)
+                const unsigned age = (unsigned)s_now + 1u - e.stamp;               // e.stamp <= s_now + 1
+                const double* xr = ring + ((e.stamp - 1u) & (unsigned)(RING - 1)) * NP;
+                float mu;
+                if (NP == 4) {
+                    const double dth = fabs(x[0] - xr[0]);
+                    const double dt = fmax(fmax(fabs(x[1] - xr[1]), fabs(x[2] - xr[2])), fabs(x[3] - xr[3]));
+                    mu = fmaf((float)dth, bx.rxz, (float)dt);
+                } else {
+                    const double dth = (fabs(x[0] - xr[0]) + fabs(x[1] - xr[1])) + fabs(x[2] - xr[2]);     // >= |d w|_2
+                    const double dt = fmax(fmax(fabs(x[3] - xr[3]), fabs(x[4] - xr[4])), fabs(x[5] - xr[5]));
+                    mu = fmaf((float)dth, bx.r3, (float)dt);
+                }
+                const float need = fmaf(1.0001f, mu, 1e-6f);
+                const bool walk = st == 1 || st == 3 || st == 5;
+                const bool hit = use_cache & walk & (e.stamp != 0u) & (age < (unsigned)RING) & (e.slack > need);       // NaN fails
+                cached_guard = hit & (st != 1);
+                status = hit ? (st == 1 ? 4 : 0) : st;
+                const bool last = c == nc - 1;
+                // active mask: the recorded one (hit), the cluster's valid records (all active: all 64 but for the block's last cluster, whose
+                // mask is wave-uniform), else filled in by phase I
+                mlo = hit ? e.mlo : (st == 2 ? (last ? tail_lo : ~0u) : 0u);
+                mhi = hit ? e.mhi : (st == 2 ? (last ? tail_hi : ~0u) : 0u);
+                if (hit && age >= (unsigned)(RING / 2)) {
+                    // still valid but about to leave the ring: re-record against THIS iterate with what is left of the slack
+                    CacheEnt ne;
+                    ne.mlo = e.mlo; ne.mhi = e.mhi; ne.slack = (e.slack - need) * 0.99999f; ne.stamp = (unsigned)s_now + 1u;
+                    cache_w[j] = ne;
+                }
+            }
+#else
             if (nocull) {
                 status = 1;
             } else {
@@ -1053,12 +1178,11 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                 float4* dst4 = reinterpret_cast<float4*>(&ab);
 #pragma unroll
                 for (int i = 0; i < (int)(sizeof(BoxAbs) / 16); ++i) dst4[i] = bt4[i];
-                const Box bx = boxes[c];
                 CacheEnt e;                                     // fetched together with the box, whatever the box test will say
                 e.mlo = e.mhi = 0u; e.slack = 0.0f; e.stamp = 0u;
                 if (use_cache) e = cache_w[j];
-                status = cluster_status<NP, LAB>(bx, pre, ab);
-                if (use_cache && (status == 1 || status == 3)) {
+                status = cluster_status<NP, LAB>(bx, pre, ab, &lr_slack);
+                if (use_cache && (status == 1 || status == 3 || status == 5)) {
                     const unsigned age = (unsigned)s_now + 1u - e.stamp;               // e.stamp <= s_now + 1
                     const double* xr = ring + ((e.stamp - 1u) & (unsigned)(RING - 1)) * NP;
                     float mu;
@@ -1073,8 +1197,8 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                     }
                     const float need = fmaf(1.0001f, mu, 1e-6f);
                     if (e.stamp != 0u && age < (unsigned)RING && e.slack > need) {       // NaN fails
-                        cached_guard = status == 3;
-                        status = status == 3 ? 0 : 4;
+                        cached_guard = status == 3 || status == 5;
+                        status = cached_guard ? 0 : 4;
                         mlo = e.mlo; mhi = e.mhi;
                         if (age >= (unsigned)(RING / 2)) {
                             // still valid but about to leave the ring: re-record against THIS iterate with what is left of the slack
@@ -1085,25 +1209,28 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                     }
                 }
             }
-            if (status == 2) {       // all active: the cluster's valid records
-                const int nv = min(cnt - c * CL, CL);
-                mlo = nv >= 32 ? ~0u : ((1u << nv) - 1u);
-                mhi = nv >= 64 ? ~0u : (nv > 32 ? ((1u << (nv - 32)) - 1u) : 0u);
+            if (status == 2) {       // all active: the cluster's valid records -- all 64 but for the block's last cluster (its mask is wave-uniform)
+                const bool last = c == nc - 1;
+                mlo = last ? tail_lo : ~0u;
+                mhi = last ? tail_hi : ~0u;
             }
+#endif
         }
         const unsigned long long mA = __ballot(status == 1), mB = __ballot(status == 2), mC = __ballot(status == 3), mD = __ballot(status == 4);
+        const unsigned long long mE = DI2P_SOLVER_GUARD_TBZ ? __ballot(status == 5) : 0ull;
         if (PROFILE) {
-            n_active[1] += __popcll(mA); n_active[2] += __popcll(mB); n_active[3] += __popcll(mC);
+            n_active[1] += __popcll(mA); n_active[2] += __popcll(mB); n_active[3] += __popcll(mC | mE);
             n_active[4] += __popcll(mD); n_active[5] += __popcll(__ballot(cached_guard));
-            n_active[11] += 1; n_active[8] += __popcll(mA | mB | mD);
+            n_active[11] += 1; n_active[8] += __popcll(mA | mB | mD); n_active[12] += __popcll(mE);
             tp[0] += clock64() - ts0;
         }
         // ---- phase I.  The flagged clusters are walked PF AT A TIME in straight-line code (a cluster's 64 records are one 16-byte load per
         // lane): the pre-filters are independent instruction streams and the records of the next PF are in flight meanwhile.
-        if (LAB == 0 && mC) {
-            // (a) zero-guard-only clusters (status 3): no point is active; only an exact zero / non-finite value on an undecided plane must
-            // be found (sets `bad`).  The cluster's min slack says both whether every record is certified (> 0) and for how long.
-            unsigned long long mg = mC;
+        // (a) zero-guard-only clusters (status 3; status 5: on the top / bottom / z planes only): no point is active; only an exact zero /
+        // non-finite value on an undecided plane must be found (sets `bad`).  The cluster's min slack says both whether every record is
+        // certified (> 0) and for how long.
+        auto guard_walk = [&](auto tbz_tag, unsigned long long mg) {
+            constexpr bool TBZ = decltype(tbz_tag)::value;
             int nb[PF];
             Rec<PT> ring_r[PF];
 #pragma unroll
@@ -1122,10 +1249,23 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
 #endif
                     nb[u] = take_bit(mg);
                     ring_r[u] = load_rec((j0 + nb[u]) * WPH + wave);
-                    bool a;
                     float sl;
-                    prefilter32<NP, 0>(pre, (float)cur[u].x, (float)cur[u].y, (float)cur[u].z, a, sl);
+#if DI2P_SOLVER_BOXMS
+                    const float msu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ms_box), nbp[u]));
+#else
+                    const float msu = -1.0f;
+#endif
+                    if (TBZ) {
+                        sl = guard32_tbz<NP>(pre, (float)cur[u].x, (float)cur[u].y, (float)cur[u].z, msu);
+                    } else {
+                        bool a;
+                        prefilter32<NP, 0>(pre, (float)cur[u].x, (float)cur[u].y, (float)cur[u].z, a, sl, msu);
+                    }
+#if DI2P_SOLVER_BOXMS
+                    sl = __builtin_fmaxf(sl, 0.0f);                             // not certified (<= 0, or NaN: v_max returns the other operand) -> 0
+#else
                     sl = (use_pre && sl > 0.0f) ? sl : 0.0f;                    // not certified (or NaN) -> 0
+#endif
 #if DI2P_SOLVER_NOVALID
                     // no lane mask: the padding lanes of a block's last cluster hold COPIES of its last record (prepare_kernel), so they change
                     // neither the minimum nor the verdict of the exact test; the value of an exhausted slot (nbp < 0) is never used
@@ -1155,6 +1295,11 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                     }
                 }
             }
+        };
+        if (LAB == 0 && mC) guard_walk(std::false_type(), mC);
+        if (DI2P_SOLVER_GUARD_TBZ && LAB == 0 && mE) {
+            guard_walk(std::true_type(), mE);
+            if (status == 5) slack = fminf(slack, lr_slack);       // the box's clearance of the two planes the walk left out (lane-parallel)
         }
         if (mA) {
             // (b) clusters classified per point (status 1), PFC at a time
@@ -1187,8 +1332,14 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                 for (int u = 0; u < PFC; ++u) {          // no short circuits: PFC independent, branch-free instruction streams
                     bool a;
                     float sl;
+#if DI2P_SOLVER_BOXMS
+                    const float msu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ms_box), nbp[u]));
+                    prefilter32<NP, LAB>(pre, (float)cur[u].x, (float)cur[u].y, (float)cur[u].z, a, sl, msu);
+                    sl = __builtin_fmaxf(sl, 0.0f);
+#else
                     prefilter32<NP, LAB>(pre, (float)cur[u].x, (float)cur[u].y, (float)cur[u].z, a, sl);
                     sl = (use_pre && sl > 0.0f) ? sl : 0.0f;
+#endif
 #if DI2P_SOLVER_NOVALID
                     act[u] = a;           // the padding lanes (copies of the block's last record) are cut from the BALLOT by a scalar mask below
                     sm[u] = sl;
@@ -1225,7 +1376,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                 }
             }
         }
-        if (use_cache && (status == 1 || status == 3)) {       // what phase I found, one entry per lane
+        if (use_cache && (status == 1 || status == 3 || status == 5)) {       // what phase I found, one entry per lane
             CacheEnt ne;
             ne.mlo = mlo; ne.mhi = mhi; ne.slack = slack; ne.stamp = (unsigned)s_now + 1u;
             cache_w[j] = ne;
@@ -1238,8 +1389,20 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                 mo &= mo - 1;
                 if (qn > QCAP - 64) drain(false);      // queue nearly full: evaluate the full rounds, keep the remainder queued
                 const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)mlo, b), hi = (unsigned)__builtin_amdgcn_readlane((int)mhi, b);
+#if DI2P_SOLVER_EXEC_APPEND
+                {   // the store runs under exec = the cluster's active mask: mbcnt does not depend on exec, so no per-lane bit test is needed
+                    const unsigned rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+                    const unsigned addr = (queue_addr + 4u * (unsigned)qn) + 4u * rank;              // (scalar) + 4 * rank
+                    const unsigned id = (unsigned)(((j0 + b) * WPH + wave) * CL) + (unsigned)lane;   // (scalar) + lane
+                    const unsigned long long m64 = ((unsigned long long)hi << 32) | lo;
+                    unsigned long long saved;
+                    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
+                                 : "=&s"(saved) : "s"(m64), "v"(addr), "v"(id) : "memory");
+                }
+#else
                 const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
                 if (((lo & bit_lo) | (hi & bit_hi)) != 0u) queue[pos] = ((j0 + b) * WPH + wave) * CL + lane;
+#endif
                 qn += __builtin_popcount(lo) + __builtin_popcount(hi);
             }
         }
@@ -1867,8 +2030,8 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
     long long c_sweep = 0, c_wait = 0, c_lm = 0, c_comb = 0;
     // wave 0: [0] phase-B evaluations, [1..3] clusters classified per point / all active / guard-only, [4..5] cache hits {classification, guard},
     // [6..7] straight-line batches of the guard / classification walk, [8] clusters appended by phase II, [9..10] phase-B rounds {label 1, label 0},
-    // [11] cluster-test rounds
-    int n_act[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // [11] cluster-test rounds, [12] guard-only clusters walked on the top / bottom / z planes only (status 5; included in [3])
+    int n_act[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // sweep numbers of the classification cache count from this launch's first sweep (resume: the cache and the ring start empty)
     const int s_base = a->resume ? st.nsweep : 0;
     if (threadIdx.x == 0) {
@@ -1885,6 +2048,13 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
 #pragma unroll
         for (int i = 0; i < NP; ++i) xe[i] = st.xe[i];
         const int s_now = st.nsweep - s_base;
+        // The wave that advances the LM state after THIS sweep.  The waves of a workgroup are placed round-robin on the four SIMDs of a compute
+        // unit, so with four-wave workgroups wave 0 of every resident workgroup shares ONE SIMD: with the LM update always on wave 0 that SIMD
+        // carries all of the compute unit's single-lane LM code on top of its share of the sweeps while the other three idle at the barrier.
+        // Rotating the LM wave with the sweep number spreads it (the state lives in LDS: any wave can advance it; same operations, same bits).
+        const int lm_wave = (DI2P_SOLVER_LMROT && !PROFILE) ? (int)((unsigned)st.nsweep % (unsigned)WPH) : 0;
+        const bool lm_wave_here = (int)(threadIdx.x >> 6) == lm_wave;
+        const int lm_lane = (int)(threadIdx.x & 63);
         // the camera is re-read (scalar loads, cache hits) at the head of every sweep through a laundered pointer: hoisted out of the sweep
         // loop its twelve dwords were kept in VGPRs and SPILLED (nine scratch reloads per sweep)
         const double* Kq = Kf;
@@ -1897,8 +2067,8 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
         const long long t1 = PROFILE ? clock64() : 0;
         __syncthreads();
         const long long t2 = PROFILE ? clock64() : 0;
-        if (threadIdx.x < 64) {                 // wave 0: fixed-order combination of the wave partials, one value per lane
-            const int i = threadIdx.x < NV ? threadIdx.x : NV - 1;
+        if (lm_wave_here) {                     // the LM wave of this sweep: fixed-order combination of the wave partials, one value per lane
+            const int i = lm_lane < NV ? lm_lane : NV - 1;
             double part[WPH];
             int ex = 0;
 #pragma unroll
@@ -1911,32 +2081,32 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
             const double cost = 0.5 * (ln_pos(i == 0 ? prod : 1.0) + (double)ex * 0.69314718055994530942);
             double t = i == 0 ? cost : sum;
             // a non-finite Jacobian entry or residual (evaluation failure in the reference) makes a sum non-finite: one vote per sweep
-            const bool nonfinite = __any(threadIdx.x < NV - 1 && !isfinite(t)) != 0;
-            if (threadIdx.x == NV - 1 && nonfinite) t = 1.0;
-            if (threadIdx.x < NV) sh.comb[threadIdx.x] = t;
+            const bool nonfinite = __any(lm_lane < NV - 1 && !isfinite(t)) != 0;
+            if (lm_lane == NV - 1 && nonfinite) t = 1.0;
+            if (lm_lane < NV) sh.comb[lm_lane] = t;
         }
         __builtin_amdgcn_wave_barrier();        // same wave: its LDS operations retire in order
         const long long t2b = PROFILE ? clock64() : 0;
         int action = ACT_NONE;
-        if (threadIdx.x == 0) {
+        if (lm_wave_here && lm_lane == 0) {
             const bool ok = sh.comb[NV - 1] == 0.0 && isfinite(sh.comb[0]);
             action = lm_decide<NP>(st, ok, sh.comb[0], sh.comb + 1, sh.comb + 1 + NP);
         }
         const long long t2c = PROFILE ? clock64() : 0;
         asm volatile("" ::: "memory");          // the interpolant is read back from LDS by all 64 lanes (not forwarded from lane 0's registers)
-        if (threadIdx.x < 64) {                 // wave 0: a failed trial left an interpolant to minimise (wave-uniform branch)
+        if (lm_wave_here) {                     // the LM wave: a failed trial left an interpolant to minimise (wave-uniform branch)
             __builtin_amdgcn_wave_barrier();
             if (st.poly_req) {
                 lm_poly_wave<NP>(st);
                 __builtin_amdgcn_wave_barrier();
-                if (threadIdx.x == 0) { st.poly_req = 0; action = ACT_TRIAL_NEXT; }
+                if (lm_lane == 0) { st.poly_req = 0; action = ACT_TRIAL_NEXT; }
             }
         }
         const long long t2d = PROFILE ? clock64() : 0;
         // the last stage re-reads the combined sums from LDS: kept in registers across the wave-wide minimiser (the compiler merges these
         // loads with lm_decide's) they were spilled -- three scratch reloads with a full wait on the lane everybody waits for, four times per sweep
         asm volatile("" ::: "memory");
-        if (threadIdx.x == 0) {
+        if (lm_wave_here && lm_lane == 0) {
             if (action == ACT_TRIAL_NEXT) action = lm_trial_next_decide<NP>(st);
             lm_apply<NP>(st, action, sh.comb[0], sh.comb + 1, sh.comb + 1 + NP);
             // the iterate of the NEXT sweep enters the ring of the classification cache (slot = its sweep number % RING)
@@ -1968,7 +2138,7 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
         long long v[PROF_WORDS] = {c_sweep, c_wait, c_lm, n_act[0], n_act[1], n_act[2], c_comb,
                            (long long)st.n_ls_extra | ((long long)st.n_ls_late_accept << 20) | ((long long)st.n_resweep << 40),
                            c_decide, c_poly, c_apply, n_act[3], tp[0], tp[1], tp[2], tp[3], n_act[4], n_act[5],
-                           n_act[6], n_act[7], n_act[8], n_act[9], n_act[10], n_act[11], 0, 0, 0, 0};
+                           n_act[6], n_act[7], n_act[8], n_act[9], n_act[10], n_act[11], n_act[12], 0, 0, 0};
         for (int i = 0; i < PROF_WORDS; ++i) prof[i] = (a->resume && i != 7 ? prof[i] : 0) + v[i];
     }
     if (threadIdx.x == 0 && st.done) {
@@ -2314,5 +2484,6 @@ extern "C" long long di2p_solve_workspace_bytes(int F, int R, int N) {
 // line-search counters, [8..10] LM stages {decide, wave-wide interpolant minimiser, finish + begin iteration}, [11] guard-only
 // clusters, [12..15] inside the sweep: {cluster-test rounds, drains = phase B, set-up, log + wave reduction}, [16..17] classification-cache
 // hits {clusters whose recorded mask was re-used, guard-only clusters skipped} ([4] and [11] count the misses), [18..19] straight-line batches of the
-// {guard-only, classification} walk, [20] clusters appended by phase II, [21..22] phase-B rounds of 64 {label 1, label 0}, [23] cluster-test rounds, [24..27] reserved.
+// {guard-only, classification} walk, [20] clusters appended by phase II, [21..22] phase-B rounds of 64 {label 1, label 0}, [23] cluster-test rounds, [24] guard-only
+// clusters walked on three planes only (status 5, part of [11]), [25..27] reserved.
 extern "C" void di2p_solver_set_profile_buffer(void* buf) { g_prof = (long long*)buf; }

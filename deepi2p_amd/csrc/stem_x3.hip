@@ -315,15 +315,17 @@ extern "C" int di2p_stem_x3_pack(const float* weight, void* Wp, void* stream) {
 }
 
 // 1 if di2p_stem_x3 runs an H x W image: H % 4 == 0, W % 128 == 0, W <= 512 (a workgroup spans the full width: four waves x 64 convolution columns)
-extern "C" int di2p_stem_x3_supported(int H, int W) { return (H >= 4 && H % 4 == 0 && W >= 128 && W % 128 == 0 && W <= 512) ? 1 : 0; }
+// (includes the size limit of the kernel's buffer offsets -- a per-frame input below 2^30 bytes -- so that an image it admits never fails at the call)
+extern "C" int di2p_stem_x3_supported(int H, int W) {
+    return (H >= 4 && H % 4 == 0 && W >= 128 && W % 128 == 0 && W <= 512 && (long long)3 * H * W * 4 < (1ll << 30)) ? 1 : 0;
+}
 
 // y f32[B,64,H/4,W/4] = maxpool3x3/2/pad1( relu( scale * conv7x7/2/pad3(x f32[B,3,H,W]) + shift ) )
 extern "C" int di2p_stem_x3(const float* x, const void* Wp, const float* scale, const float* shift, float* y, int B, int H, int W, void* stream) {
     DI2P_CHECK_ARG(x && Wp && scale && shift && y, "null pointer");
     DI2P_CHECK_ARG(B >= 0, "bad batch");
-    DI2P_CHECK_ARG(di2p_stem_x3_supported(H, W), "needs H % 4 == 0, W % 128 == 0, W <= 512");
+    DI2P_CHECK_ARG(di2p_stem_x3_supported(H, W), "needs H % 4 == 0, W % 128 == 0, W <= 512 and a per-frame input below 2^30 bytes");
     DI2P_CHECK_ARG(((uintptr_t)Wp & 15) == 0, "packed weights must be 16-byte aligned");
-    DI2P_CHECK_ARG((long long)3 * H * W * 4 < (1ll << 30), "per-frame input must stay below 2^30 bytes");
     if (B == 0) return 0;
     SxArgs a{};
     a.x = x; a.Wp = (const u32x4_t*)Wp; a.scale = scale; a.shift = shift; a.y = y;

@@ -190,9 +190,34 @@ def x3_invalidate():
     _X3_CACHE.clear()
 
 
-def x3_live_operands():
-    """The split operands currently cached (a holder of raw pointers to them keeps this list)."""
-    return [e[1] for e in _X3_CACHE.values()]
+def x3_live_operands(owners=None):
+    """The split operands currently cached (a holder of raw pointers to them keeps this list).  owners: packed-operand containers
+    (networks._PackedModule.packed_operands()) -- only the splits whose fp32 operand lives in one of them, so that a holder pins the
+    splits of ITS model and not those of every other model (or test) that happens to be alive in the process."""
+    if owners is None:
+        return [e[1] for e in _X3_CACHE.values()]
+    mine = set()
+
+    def walk(o):
+        if isinstance(o, torch.Tensor):
+            mine.add(id(o._base if o._base is not None else o))
+        elif isinstance(o, dict):
+            for v in o.values():
+                walk(v)
+        elif isinstance(o, (list, tuple)):
+            for v in o:
+                walk(v)
+        elif hasattr(o, "__dict__"):
+            for v in vars(o).values():
+                walk(v)
+
+    walk(owners)
+    out = []
+    for ref, wp in list(_X3_CACHE.values()):
+        base = ref()
+        if base is not None and id(base) in mine:
+            out.append(wp)
+    return out
 
 
 def bf16x3_pack(Wt):
@@ -313,6 +338,19 @@ def point_head_x3(src0, src1, packed, gathered, N):
     require_cuda(src0, src1, packed["W0p"], packed["W1p"], packed["ss"], packed["W2t"], packed["sc2"], packed["sh2"])
     B = src0.shape[0]
     P = packed["W2t"].shape[1]
+    # raw pointers below: the packs must be the ones made for THIS head (layer 0's dense rows, layer 1), the small operands fp32 of the right size
+    k0 = int(src0.shape[1]) + int(src1.shape[1])
+    hb = _lib.load().di2p_head_x3_packed_bytes
+    if k0 % 16 or packed["W0p"].numel() * packed["W0p"].element_size() != hb(k0) or packed["W1p"].numel() * packed["W1p"].element_size() != hb(128):
+        raise RuntimeError("point_head_x3: W0p / W1p must be head_x3_pack of the [%d,128] dense rows and of the [128,128] second layer" % k0)
+    for name, n in (("ss", 4 * 128), ("W2t", 128 * P), ("sc2", P), ("sh2", P)):
+        if packed[name] is None and name in ("sc2", "sh2"):          # the output layer may come without scale / shift
+            continue
+        _chk(packed[name], _f32, "point_head_x3 " + name)
+        if packed[name].numel() < n:
+            raise RuntimeError("point_head_x3: %s holds %d values, needs %d" % (name, packed[name].numel(), n))
+    if tuple(packed["W2t"].shape) != (128, P) or not 1 <= P <= 4:
+        raise RuntimeError("point_head_x3: W2t must be f32[128,P] with P <= 4")
     h = _lib.HeadX3T()
     for t, x in enumerate((src0, src1)):
         _chk(x, _f32, "head source")
@@ -430,13 +468,33 @@ def conv3x3_x3(x, Wp, Cout, scale, shift, stride, relu, residual=None, downsampl
     downsample = (Wp_ds, scale_ds, shift_ds) -- the BasicBlock's 1x1 / stride-2 branch of the same input (resnet.py:160-164) -- and
     returns (y, y_ds)."""
     require_cuda(x, Wp, scale, shift, residual)
+    _chk(x, _f32, "conv3x3_x3 input")
+    if x.dim() != 4:
+        raise RuntimeError("conv3x3_x3 takes x f32[B,Cin,H,W]")
     B, Cin, H, W = x.shape
     OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    # the kernel reads the operands through raw pointers: a pack made for another layer shape or a smaller residual would be read out of bounds
+    packed_bytes = _lib.load().di2p_bf16x3_packed_bytes
+    if Wp.numel() * Wp.element_size() != packed_bytes(9 * Cin, int(Cout)):
+        raise RuntimeError("conv3x3_x3: Wp is not bf16x3_pack of a [9*%d, %d] matrix (%d bytes, expected %d)" % (Cin, Cout, Wp.numel() * Wp.element_size(), packed_bytes(9 * Cin, int(Cout))))
+    for name, v in (("scale", scale), ("shift", shift)):
+        _chk(v, _f32, "conv3x3_x3 " + name)
+        if v.numel() < Cout:
+            raise RuntimeError("conv3x3_x3: %s holds %d values, needs %d" % (name, v.numel(), Cout))
+    if residual is not None:
+        _chk(residual, _f32, "conv3x3_x3 residual")
+        if tuple(residual.shape) != (B, Cout, OH, OW):
+            raise RuntimeError("conv3x3_x3: residual must be f32%s, got %s" % ((B, Cout, OH, OW), tuple(residual.shape)))
     y = torch.empty((B, Cout, OH, OW), dtype=_f32, device=x.device)
     Wd = sd = hd = yd = None
     if downsample is not None:
         Wd, sd, hd = downsample
         require_cuda(Wd, sd, hd)
+        if Wd.numel() * Wd.element_size() != packed_bytes(Cin, int(Cout)):
+            raise RuntimeError("conv3x3_x3: the downsample pack is not bf16x3_pack of a [%d, %d] matrix" % (Cin, Cout))
+        _chk(sd, _f32, "conv3x3_x3 downsample scale"); _chk(hd, _f32, "conv3x3_x3 downsample shift")
+        if sd.numel() < Cout or hd.numel() < Cout:
+            raise RuntimeError("conv3x3_x3: downsample scale / shift need %d values" % Cout)
         yd = torch.empty((B, Cout, OH, OW), dtype=_f32, device=x.device)
     if _lib.WORK is not None:
         _lib.WORK["di2p_conv3x3_x3"] = _lib.WORK.get("di2p_conv3x3_x3", 0) + B * Cout * Cin * (9 + (1 if downsample is not None else 0)) * OH * OW
@@ -485,9 +543,14 @@ def stem_x3_supported(H, W):
 def stem_x3(x, Wp, scale, shift):
     """conv1 + bn1 + relu + maxpool of the image branch in one launch (di2p_stem_x3): x f32[B,3,H,W] -> f32[B,64,H/4,W/4]."""
     require_cuda(x, Wp, scale, shift)
+    _chk(x, _f32, "stem_x3 input"); _chk(scale, _f32, "stem_x3 scale"); _chk(shift, _f32, "stem_x3 shift")
+    if x.dim() != 4:
+        raise RuntimeError("stem_x3 takes x f32[B,3,H,W]")
     B, C, H, W = x.shape
     if C != 3:
         raise RuntimeError("the stem takes 3 input channels")
+    if Wp.numel() * Wp.element_size() != _lib.load().di2p_stem_x3_packed_bytes() or scale.numel() < 64 or shift.numel() < 64:
+        raise RuntimeError("stem_x3: Wp must be stem_x3_weights(...) and scale / shift hold 64 values")
     y = torch.empty((B, 64, H // 4, W // 4), dtype=_f32, device=x.device)
     if _lib.WORK is not None:
         _lib.WORK["di2p_stem_x3"] = _lib.WORK.get("di2p_stem_x3", 0) + B * 64 * 147 * (H // 2) * (W // 2)

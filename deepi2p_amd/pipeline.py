@@ -198,7 +198,7 @@ class RegistrationExecutor:
         # the graph will hold raw pointers to the split (bf16x3) weights too: ACCUMULATE them (a later capture must not drop what an
         # earlier graph points to); the list is emptied only when every graph is (_follow_weights)
         have = {id(t) for t in self._x3_refs}
-        self._x3_refs += [t for t in ops.x3_live_operands() if id(t) not in have]
+        self._x3_refs += [t for t in ops.x3_live_operands(self._packed_refs) if id(t) not in have]      # this model's splits only
         if self.split_solver:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, stream=slot.stream, **kw):

@@ -117,8 +117,20 @@ def test_conv3x3_x3_argument_checks(dev):
     x = torch.zeros(1, 64, 8, 32, device=dev)
     with pytest.raises(_lib.DeepI2PHipError):                               # stride 2 comes with its downsample branch
         ops.conv3x3_x3(x, Wp, 64, one, one, 2, False)
+    Wpd = ops.bf16x3_pack(torch.zeros(64, 64, device=dev))
     with pytest.raises(_lib.DeepI2PHipError):                               # ... and stride 1 has none
-        ops.conv3x3_x3(x, Wp, 64, one, one, 1, False, downsample=(Wp, one, one))
+        ops.conv3x3_x3(x, Wp, 64, one, one, 1, False, downsample=(Wpd, one, one))
+    # host-side checks of what the kernel would read through raw pointers (round-5 advisor finding): a pack made for another layer shape, a
+    # residual of another shape, a non-fp32 input
+    with pytest.raises(RuntimeError, match="not bf16x3_pack"):
+        ops.conv3x3_x3(x, Wpd, 64, one, one, 1, False)
+    with pytest.raises(RuntimeError, match="downsample pack"):
+        ops.conv3x3_x3(x, Wp, 64, one, one, 2, False, downsample=(Wp, one, one))
+    with pytest.raises(RuntimeError, match="residual must be"):
+        ops.conv3x3_x3(x, Wp, 64, one, one, 1, False, residual=torch.zeros(1, 64, 4, 32, device=dev))
+    with pytest.raises(RuntimeError, match="must be torch.float32"):
+        ops.conv3x3_x3(x.double(), Wp, 64, one, one, 1, False)
+    assert not ops.conv3x3_x3_supported((1, 64, 16384, 16384), 64, 1)   # a per-frame output of 2^36 bytes: `supported` applies the launch entry's size limits
 
 
 def test_image_encoder_same_features_with_and_without_conv_x3(dev):

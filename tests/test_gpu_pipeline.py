@@ -174,3 +174,15 @@ def test_per_batch_camera_matrix_shape_check_and_weight_updates(dev):
     for k in KEYS:
         assert torch.equal(after[k], ref[k]), k
     assert not torch.equal(after["pred"], before)
+    # (4) round-5 advisor finding: an executor pins the bf16x3 splits of ITS model only -- a split made for some other operand that happens
+    # to be cached in the process when the graphs are captured is not kept alive by it
+    from deepi2p_amd import ops
+    g = torch.Generator().manual_seed(5)
+    other_w = (torch.randn(256, 256, generator=g) / 16).to(dev)
+    ops.pointwise_gemm([ops.Src(torch.randn(1, 256, 2048, generator=g).to(dev))], other_w, 256, 2048, x3=True)
+    foreign = [t for t in ops.x3_live_operands() if all(t is not u for u in ops.x3_live_operands(mm.detector.packed_operands()))]
+    assert len(foreign) >= 1
+    ex3 = RegistrationExecutor(mm, pipe, K, host[0], n_streams=1, restarts=restarts)
+    ex3.result(ex3.submit(host[1]))                    # the graphs are captured at the first step of a slot
+    assert len(ex3._x3_refs) >= 1
+    assert all(all(t is not f for f in foreign) for t in ex3._x3_refs)

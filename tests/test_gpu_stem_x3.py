@@ -71,6 +71,33 @@ def test_stem_x3_is_deterministic_and_batch_independent(dev):
     assert torch.equal(y[2:3], ops.stem_x3(xd[2:3].contiguous(), Wp, sc, sh))
 
 
+def test_stem_x3_non_finite_pixel_is_contained(dev):
+    """Round-5 advisor finding.  A non-finite pixel does NOT propagate through this kernel the way it does through the reference (and the
+    fp32 stem + pool): +-inf splits into (inf, NaN, NaN), the padded eighth tap column multiplies it by a zero weight (0 * inf = NaN, one
+    convolution column outside the true 7x7 window), and relu / max-pool are v_max (which return the OTHER operand of a NaN).  What is
+    asserted is the contract DESIGN.md states for it: the damage stays inside the pixel's pooled neighbourhood -- every output further than
+    two pooled rows / columns from it, and every other frame, is bit-identical to the clean run.  (Images are 0..255; a non-finite pixel is
+    an input error, not a case of the path.)"""
+    from deepi2p_amd import ops
+    x, w, scale, shift = _operands(2, 160, 512, 11)
+    Wp, sc, sh = ops.stem_x3_weights(w.to(dev)), scale.to(dev), shift.to(dev)
+    clean = ops.stem_x3(x.to(dev), Wp, sc, sh).cpu()
+    for val in (float("inf"), float("-inf"), float("nan")):
+        xi = x.clone()
+        py, px = 37, 201
+        xi[0, 1, py, px] = val
+        y = ops.stem_x3(xi.to(dev), Wp, sc, sh).cpu()
+        assert torch.equal(y[1], clean[1])
+        far = torch.ones_like(clean[0], dtype=torch.bool)
+        far[:, max(py // 4 - 2, 0):py // 4 + 3, max(px // 4 - 2, 0):px // 4 + 3] = False
+        assert torch.equal(y[0][far], clean[0][far]), val
+    # the fp32 pair propagates an infinite pixel (the reference's behaviour): non-finite values inside the neighbourhood
+    xi = x.clone()
+    xi[0, 1, py, px] = float("inf")
+    yf = ops.maxpool3x3s2(ops.conv_stem(xi.to(dev), ops.stem_weights(w.to(dev)), sc, sh, True)).cpu()
+    assert not bool(torch.isfinite(yf[0][~far]).all())
+
+
 def test_stem_x3_argument_checks(dev):
     from deepi2p_amd import ops
     x, w, scale, shift = _operands(1, 30, 512, 1)

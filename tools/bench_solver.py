@@ -57,9 +57,9 @@ for name, lab_np in (("noisy-gt", np.stack([f["labels"] for f in frames])),):
             print("  classification cache (wave 0, clusters per sweep): re-used masks %.1f (misses = per-point above)  guard walks skipped %.1f (misses = guard-only above)" % (
                 (p[:, 16] / sw).mean(), (p[:, 17] / sw).mean()))
         if PW >= 28:
-            print("  walk (wave 0, per sweep): cluster-test rounds %.2f  guard batches %.2f (fill %.2f)  classification batches %.2f (fill %.2f)  phase-II appends %.1f  phase-B rounds label-1 %.2f label-0 %.2f" % (
+            print("  walk (wave 0, per sweep): cluster-test rounds %.2f  guard batches %.2f (fill %.2f)  classification batches %.2f (fill %.2f)  phase-II appends %.1f  phase-B rounds label-1 %.2f label-0 %.2f  guard-only clusters on T/B/Z only %.1f" % (
                 (p[:, 23] / sw).mean(), (p[:, 18] / sw).mean(), p[:, 11].sum() / max(4 * p[:, 18].sum(), 1), (p[:, 19] / sw).mean(), p[:, 4].sum() / max(PFC * p[:, 19].sum(), 1),
-                (p[:, 20] / sw).mean(), (p[:, 21] / sw).mean(), (p[:, 22] / sw).mean()))
+                (p[:, 20] / sw).mean(), (p[:, 21] / sw).mean(), (p[:, 22] / sw).mean(), (p[:, 24] / sw).mean()))
         if PW >= 16:
             print("  LM stages per sweep: combine %.0f  decide %.0f  wave minimiser %.0f  finish+begin %.0f" % tuple((p[:, i] / sw).mean() for i in (6, 8, 9, 10)))
             print("  inside the sweep (wave 0, cycles per sweep): set-up %.0f  cluster-test rounds %.0f  phase B (drains) %.0f  log+reduction %.0f  -> cluster walk / phase A %.0f" % (

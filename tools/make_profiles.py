@@ -121,10 +121,10 @@ files listed in KEEP_OLD (if present) come from earlier calls of the round.
   host->device copy of every batch inside the step; device time of one batch {line['latency_ms_per_batch']['streams_%d' % line['config']['streams']]:.1f} ms with all streams busy,
   {line['latency_ms_per_batch']['one_step_in_flight']:.1f} ms with a single step in flight.  Roofline object = time-dominant family = `solve_kernel`:
   {k['solve_kernel']['ms_per_step']:.2f} ms per step, {k['solve_kernel']['achieved']:.1f} TFLOP/s by SURVEY 8(d)'s unit = {k['solve_kernel']['frac']:.2f} of the 78.6 TFLOP/s fp64 vector peak.
-  Per family (`kernels`): convolution {cv['ms_per_step']:.2f} ms = {cv['achieved']:.1f} TFLOP/s algorithmic = **{cv['frac']:.2f}** of the fp32-MFMA peak ({cv['bf16x3']['calls_per_step']} bf16x3
+  Per family (`kernels`): convolution {cv['ms_per_step']:.2f} ms = {cv['achieved_reference_algorithmic']:.1f} TFLOP/s algorithmic; **{cv['frac']:.2f}** of the matrix pipes it runs on (executed products at peak rate / time; {cv['bf16x3']['calls_per_step']} bf16x3
   launches {cv['bf16x3']['ms_per_step']:.2f} ms = {cv['bf16x3']['fp32_equivalent_tflops']:.0f} TFLOP/s fp32-equivalent = {cv['bf16x3']['executed_bf16_tflops']:.0f} TFLOP/s of executed bf16 products = {cv['bf16x3']['frac_of_bf16_mfma_peak']:.2f} of the 2.5 PFLOP/s bf16 peak;
   {cv['winograd']['calls_per_step']} Winograd launches {cv['winograd']['ms_per_step']:.2f} ms; other implicit-GEMM launches {cv['winograd']['direct_kernel_ms_per_step']:.2f} ms; stem
-  {cv['winograd']['stem_kernel_ms_per_step']:.2f} ms); pointwise {pw['ms_per_step']:.2f} ms ({pw['achieved_executed']:.0f} TFLOP/s executed = {pw['frac']:.2f} of the fp32-MFMA peak; {pw['achieved']:.0f} TFLOP/s by the reference's layer sizes); index_max
+  {cv['winograd']['stem_kernel_ms_per_step']:.2f} ms); pointwise {pw['ms_per_step']:.2f} ms ({pw['achieved_executed']:.0f} TFLOP/s executed = {pw['frac']:.2f} of the matrix pipes its launches run on; {pw['achieved_reference_algorithmic']:.0f} TFLOP/s by the reference's layer sizes); index_max
   {k['index_max_kernel']['ms_per_step']*1e3:.0f} us in-pipeline ({k['index_max_kernel']['achieved']:.0f} GB/s).  CPU baseline: {line['cpu_baseline']['value']:.3f} frames/s on {line['cpu_baseline']['cores']} threads.
 * `{TAG}_bench_kernel_stats_pipelined.csv` / `{TAG}_bench_line_pipelined.json` -- `rocprofv3 --kernel-trace --stats --output-format csv --
   python bench.py --no-cpu-baseline --no-h2d-pass` ({s3['value']:.0f} frames/s under the profiler); several batches in flight: durations include
