@@ -33,7 +33,7 @@ const OptDef kOpts[DI2P_OPT_COUNT] = {
     {"wino_kc", "DI2P_WINO_KC", 0},                 {"conv_nostem", "DI2P_CONV_NOSTEM", 0},
     {"pw_cfg", "DI2P_PW_CFG", 0},                   {"wino_reg", "DI2P_WINO_REG", 0},                 {"wino_reg_min", "DI2P_WINO_REG_MIN", 256},
     {"solver_lds_pad", "DI2P_SOLVER_LDS_PAD", 0},   {"solver_nocache", "DI2P_SOLVER_NOCACHE", 0},
-    {"solver_prep_bitonic", "DI2P_SOLVER_PREP_BITONIC", 0},
+    {"solver_prep_single", "DI2P_SOLVER_PREP_SINGLE", 0}, {"solver_prep_bitonic", "DI2P_SOLVER_PREP_BITONIC", 0},
     {"pw_x3", "DI2P_PW_X3", 1},                     {"pw_nochain", "DI2P_PW_NOCHAIN", 0},
     {"head_reg", "DI2P_HEAD_REG", 0},               {"conv_s2scalar", "DI2P_CONV_S2SCALAR", 0},
     {"conv_x3", "DI2P_CONV_X3", 31},                 {"conv_x3_cfg", "DI2P_CONV_X3_CFG", -1},

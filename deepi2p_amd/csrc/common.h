@@ -55,6 +55,7 @@ enum Di2pOption {
     DI2P_OPT_WINO_REG_MIN,          // automatic choice: register-resident Winograd kernel from this many 64-tile workgroups on (default 256: all but the 512-channel stage)
     DI2P_OPT_SOLVER_LDS_PAD,        // bytes of unused dynamic LDS per solver workgroup (caps its workgroups per CU; experiments)
     DI2P_OPT_SOLVER_NOCACHE,        // 1: no classification cache in the cluster walk (bit-identical by construction)
+    DI2P_OPT_SOLVER_PREP_SINGLE,    // 1: frame preparation as ONE workgroup per frame (the round-4 kernel; default: five multi-workgroup launches; same results)
     DI2P_OPT_SOLVER_PREP_BITONIC,   // 1: frame preparation always sorts with the bitonic network (default: counting sort + per-bucket ranking; same order)
     DI2P_OPT_PW_X3,                 // 1 (default): the host layer runs the GEMM-shaped pointwise layers (K >= 128, M % 128 == 0) on the bf16x3 kernel (read by ops.py)
     DI2P_OPT_PW_NOCHAIN,            // 1: the host layer runs the narrow PointNet chains as separate launches instead of di2p_point_chain (bit-identical; read by ops.py)

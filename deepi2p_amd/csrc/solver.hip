@@ -46,19 +46,19 @@
 #define DI2P_SOLVER_CAMF 1        // 1: the normalised plane coefficients come from a per-frame table (prepare_kernel) instead of being re-derived per wave and sweep
 #endif
 #ifndef DI2P_SOLVER_BOXMS
-#define DI2P_SOLVER_BOXMS 0       // 1: the per-point margin m S of the walk is the CLUSTER's (from its box: >= every point's), read from the lane that owns the cluster
+#define DI2P_SOLVER_BOXMS 1       // 1: the per-point margin m S of the walk is the CLUSTER's (from its box: >= every point's), read from the lane that owns the cluster
 #endif
 #ifndef DI2P_SOLVER_EXEC_APPEND
-#define DI2P_SOLVER_EXEC_APPEND 0 // 1: phase II stores a cluster's active ids under exec = its active mask (no per-lane bit test)
+#define DI2P_SOLVER_EXEC_APPEND 1 // 1: phase II stores a cluster's active ids under exec = its active mask (no per-lane bit test)
 #endif
 #ifndef DI2P_SOLVER_LMROT
 #define DI2P_SOLVER_LMROT 0       // 1: the wave that advances the LM state rotates with the sweep number (spreads the single-lane code over the SIMDs)
 #endif
 #ifndef DI2P_SOLVER_FLATROUND
-#define DI2P_SOLVER_FLATROUND 0   // 1: the cluster-test round (status decision table, cache look-up) as selects instead of nested divergent branches
+#define DI2P_SOLVER_FLATROUND 1   // 1: the cluster-test round (status decision table, cache look-up) as selects instead of nested divergent branches
 #endif
 #ifndef DI2P_SOLVER_GUARD_TBZ
-#define DI2P_SOLVER_GUARD_TBZ 0   // 1: guard-only clusters whose box clears the left / right planes by DI2P_GUARD_LR_MIN are guarded on the top / bottom / z planes only
+#define DI2P_SOLVER_GUARD_TBZ 1   // 1: guard-only clusters whose box clears the left / right planes by DI2P_GUARD_LR_MIN are guarded on the top / bottom / z planes only
 #endif
 #ifndef DI2P_SOLVER_WRITELANE
 #define DI2P_SOLVER_WRITELANE 0   // 1: a batch's results go into the owning lane by v_writelane (one instruction per value) instead of compare + select
@@ -207,7 +207,10 @@ __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ po
                                                        int NCMAX, unsigned long long* __restrict__ keys_all,
                                                        Rec<PT>* __restrict__ packed, Box* __restrict__ boxes_all,
                                                        int* __restrict__ counts, int force_bitonic, const double* __restrict__ Kmat, double H,
-                                                       double W, float* __restrict__ camf_all) {
+                                                       double W, float* __restrict__ camf_all, const int* __restrict__ only_flagged) {
+    // only_flagged != nullptr: this launch is the FALLBACK behind the multi-workgroup preparation (prep_*_kernel below): it runs for the
+    // frames whose flag is set (a bucket above 4096 keys: a degenerate scene) and leaves the others alone
+    if (only_flagged && only_flagged[blockIdx.x] == 0) return;
     constexpr int CH = 8192;                       // LDS chunk (64 KB)
     __shared__ unsigned long long chunk[CH];
     __shared__ float s_f[4][16];
@@ -486,6 +489,272 @@ __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ po
         const float iT = 1.0f / (fabsf(fy) + fabsf(cy)), iB = 1.0f / (fabsf(fy) + fabsf(hcy));
         cf[0] = fx * iL; cf[1] = cx * iL; cf[2] = fx * iR; cf[3] = wcx * iR;
         cf[4] = fy * iT; cf[5] = cy * iT; cf[6] = fy * iB; cf[7] = hcy * iB;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// MULTI-WORKGROUP frame preparation (round 6).  prepare_kernel runs one 1024-thread workgroup per frame: 32 of 256 compute units for 0.26 ms at
+// the head of every solve.  The same five steps as five launches, G workgroups per frame each (same keys, same total order, same records and
+// boxes, bit for bit -- tests compare the paths):
+//   prep_bounds_kernel   partial ground-plane bounds + label counts per slice; zeroes the frame's histogram / cursors / flag
+//   prep_hist_kernel     keys of the slice (stored), bucket histogram (LDS atomics, flushed with global atomics)
+//   prep_scatter_kernel  exclusive scan of the histogram (every workgroup, into LDS), keys scattered to their buckets (global cursors)
+//   prep_rank_kernel     one thread per key: rank inside its bucket by counting -> sorted keys
+//   prep_records_kernel  one wavefront per cluster: gathers its 64 records, writes them and reduces the box FROM ITS REGISTERS
+// A frame with a bucket above 4096 keys is flagged by the scatter step, skipped by the last two and prepared by prepare_kernel (launched
+// behind them with `only_flagged`).
+constexpr int PREP_NBK = 2048;        // buckets: the top 11 key bits (label + 32 x 32 grid of the Hilbert curve)
+constexpr int PREP_G = 8;             // workgroups per frame of the slice kernels (PREP_NBK % PREP_G == 0)
+constexpr int PREP_CPW = 16;          // clusters per wavefront of prep_records_kernel (parked in lanes 0..15, finished lane-parallel)
+struct PrepWs { float* partial; int* hist; int* cursor; int* bases; int* flag; };      // [F][G][8] | [F][NBK] | [F][NBK] | [F][NBK + 1] | [F]
+
+// bounds, scale and label counts of a frame from its G partial results (same min / max / sums whatever the slicing: exact operations)
+struct PrepFrame { float mnx, mnz, scale; int n1, n0; };
+__device__ __forceinline__ PrepFrame prep_frame(const float* __restrict__ partial, int f) {
+    float mnx = __builtin_inff(), mxx = -__builtin_inff(), mnz = __builtin_inff(), mxz = -__builtin_inff();
+    int n1 = 0, n0 = 0;
+    for (int g = 0; g < PREP_G; ++g) {
+        const float* q = partial + ((long long)f * PREP_G + g) * 8;
+        mnx = fminf(mnx, q[0]); mxx = fmaxf(mxx, q[1]); mnz = fminf(mnz, q[2]); mxz = fmaxf(mxz, q[3]);
+        n1 += __builtin_bit_cast(int, q[4]); n0 += __builtin_bit_cast(int, q[5]);
+    }
+    const float ext = fmaxf(mxx - mnx, mxz - mnz);
+    PrepFrame r;
+    r.mnx = mnx; r.mnz = mnz; r.scale = (ext > 0.0f && ext < __builtin_inff()) ? 1023.0f / ext : 0.0f; r.n1 = n1; r.n0 = n0;
+    return r;
+}
+__device__ __forceinline__ void prep_slice(int N, int g, int& lo, int& hi) {
+    const int S = ((N + PREP_G - 1) / PREP_G + 255) & ~255;
+    lo = min(g * S, N); hi = min(lo + S, N);
+}
+
+template <typename PT>
+__global__ __launch_bounds__(256) void prep_bounds_kernel(const PT* __restrict__ points, const int* __restrict__ labels, int N, PrepWs w) {
+    __shared__ float s_f[4][4];
+    __shared__ int s_i[2][4];
+    const int f = blockIdx.x / PREP_G, g = blockIdx.x % PREP_G, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const PT* px = points + (long long)f * 3 * N;
+    const PT* pz = px + 2 * (long long)N;
+    const int* lab = labels + (long long)f * N;
+    for (int i = tid; i < PREP_NBK / PREP_G; i += 256) {
+        w.hist[(long long)f * PREP_NBK + g * (PREP_NBK / PREP_G) + i] = 0;
+        w.cursor[(long long)f * PREP_NBK + g * (PREP_NBK / PREP_G) + i] = 0;
+    }
+    if (g == 0 && tid == 0) w.flag[f] = 0;
+    int lo, hi;
+    prep_slice(N, g, lo, hi);
+    float mnx = __builtin_inff(), mxx = -__builtin_inff(), mnz = __builtin_inff(), mxz = -__builtin_inff();
+    int c1 = 0, c0 = 0;
+    for (int n = lo + tid; n < hi; n += 256) {
+        const int l = lab[n];
+        if (l == 0 || l == 1) {
+            const float x = (float)px[n], z = (float)pz[n];
+            mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mnz = fminf(mnz, z); mxz = fmaxf(mxz, z);
+            c1 += l == 1; c0 += l == 0;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mnx = fminf(mnx, __shfl_xor(mnx, o)); mxx = fmaxf(mxx, __shfl_xor(mxx, o));
+        mnz = fminf(mnz, __shfl_xor(mnz, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o));
+        c1 += __shfl_xor(c1, o); c0 += __shfl_xor(c0, o);
+    }
+    if (lane == 0) { s_f[0][wave] = mnx; s_f[1][wave] = mxx; s_f[2][wave] = mnz; s_f[3][wave] = mxz; s_i[0][wave] = c1; s_i[1][wave] = c0; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int v = 1; v < 4; ++v) {
+            mnx = fminf(mnx, s_f[0][v]); mxx = fmaxf(mxx, s_f[1][v]); mnz = fminf(mnz, s_f[2][v]); mxz = fmaxf(mxz, s_f[3][v]);
+            c1 += s_i[0][v]; c0 += s_i[1][v];
+        }
+        float* q = w.partial + ((long long)f * PREP_G + g) * 8;
+        q[0] = mnx; q[1] = mxx; q[2] = mnz; q[3] = mxz; q[4] = __builtin_bit_cast(float, c1); q[5] = __builtin_bit_cast(float, c0);
+    }
+}
+
+// the sort key of point n (prepare_kernel's key_of: the same expressions, the same bits)
+template <typename PT>
+__device__ __forceinline__ unsigned long long prep_key(const PT* px, const PT* pz, const int* lab, int n, const PrepFrame& fr) {
+    const int l = lab[n];
+    const float qx = fminf(fmaxf(((float)px[n] - fr.mnx) * fr.scale, 0.0f), 1023.0f);
+    const float qz = fminf(fmaxf(((float)pz[n] - fr.mnz) * fr.scale, 0.0f), 1023.0f);
+    const unsigned m = hilbert10((unsigned)qx, (unsigned)qz);
+    const unsigned long long k = ((unsigned long long)((l == 1 ? 0u : 1u << 20) | m) << 32) | (unsigned)n;
+    return (l == 0 || l == 1) ? k : ~0ull;
+}
+
+template <typename PT>
+__global__ __launch_bounds__(256) void prep_hist_kernel(const PT* __restrict__ points, const int* __restrict__ labels, int N, int P,
+                                                        unsigned long long* __restrict__ keys_all, PrepWs w) {
+    __shared__ int cnt[PREP_NBK];
+    const int f = blockIdx.x / PREP_G, g = blockIdx.x % PREP_G, tid = threadIdx.x;
+    const PT* px = points + (long long)f * 3 * N;
+    const PT* pz = px + 2 * (long long)N;
+    const int* lab = labels + (long long)f * N;
+    unsigned long long* raw = keys_all + (long long)f * 2 * P + P;         // the second key buffer holds the unsorted keys until the ranking
+    const PrepFrame fr = prep_frame(w.partial, f);
+    for (int i = tid; i < PREP_NBK; i += 256) cnt[i] = 0;
+    __syncthreads();
+    int lo, hi;
+    prep_slice(N, g, lo, hi);
+    for (int n = lo + tid; n < hi; n += 256) {
+        const unsigned long long k = prep_key(px, pz, lab, n, fr);
+        raw[n] = k;
+        if (k != ~0ull) atomicAdd(&cnt[(int)(k >> 42)], 1);
+    }
+    __syncthreads();
+    for (int i = tid; i < PREP_NBK; i += 256)
+        if (cnt[i]) atomicAdd(&w.hist[(long long)f * PREP_NBK + i], cnt[i]);
+}
+
+__global__ __launch_bounds__(1024) void prep_scatter_kernel(int N, int P, unsigned long long* __restrict__ keys_all, PrepWs w) {
+    __shared__ int basev[PREP_NBK + 1];
+    __shared__ int s_w[16];
+    const int f = blockIdx.x / PREP_G, g = blockIdx.x % PREP_G, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long* keys = keys_all + (long long)f * 2 * P;
+    const unsigned long long* raw = keys + P;
+    {   // exclusive scan of the 2048 counts: two per thread, wave scan, 16 wave totals (prepare_kernel's scan)
+        const int a0 = w.hist[(long long)f * PREP_NBK + 2 * tid], a1 = w.hist[(long long)f * PREP_NBK + 2 * tid + 1];
+        int v = a0 + a1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o); if (lane >= o) v += u; }
+        if (lane == 63) s_w[wave] = v;
+        __syncthreads();
+        int woff = 0;
+        for (int q = 0; q < wave; ++q) woff += s_w[q];
+        const int excl = woff + v - (a0 + a1);
+        basev[2 * tid] = excl; basev[2 * tid + 1] = excl + a0;
+        if (tid == 1023) basev[PREP_NBK] = excl + a0 + a1;
+        if (a0 > 4096 || a1 > 4096) w.flag[f] = 1;            // a degenerate scene: the frame goes to prepare_kernel's bitonic network
+    }
+    __syncthreads();
+    if (g == 0)
+        for (int i = tid; i <= PREP_NBK; i += 1024) w.bases[(long long)f * (PREP_NBK + 1) + i] = basev[i];
+    int lo, hi;
+    prep_slice(N, g, lo, hi);
+    for (int n = lo + tid; n < hi; n += 1024) {
+        const unsigned long long k = raw[n];
+        if (k != ~0ull) { const int bk = (int)(k >> 42); keys[basev[bk] + atomicAdd(&w.cursor[(long long)f * PREP_NBK + bk], 1)] = k; }
+    }
+}
+
+__global__ __launch_bounds__(256) void prep_rank_kernel(int P, unsigned long long* __restrict__ keys_all, PrepWs w) {
+    const int f = blockIdx.y;
+    if (w.flag[f]) return;
+    const int* bases = w.bases + (long long)f * (PREP_NBK + 1);
+    const unsigned long long* keys = keys_all + (long long)f * 2 * P;
+    unsigned long long* keys2 = keys_all + (long long)f * 2 * P + P;
+    const int nv = bases[PREP_NBK];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= nv) return;
+    // rank inside the bucket by counting (#{j : key_j < key}; the keys are unique): neighbouring threads sit in the same bucket and read the
+    // same addresses (broadcast)
+    const unsigned long long k = keys[p];
+    const int bk = (int)(k >> 42), b0 = bases[bk], c = bases[bk + 1] - b0;
+    int rank = 0;
+    for (int j = 0; j < c; j += 8) {            // eight loads in flight (clamped; the duplicates do not count)
+        unsigned long long q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = keys[b0 + min(j + u, c - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rank += (j + u < c && q[u] < k) ? 1 : 0;
+    }
+    keys2[b0 + rank] = k;
+}
+
+// Records in sorted order (every label block cluster-aligned and padded with copies of its last record) and the cluster boxes: one wavefront
+// per cluster holds the cluster's 64 records in its lanes -- written out and reduced from registers; PREP_CPW clusters per wavefront, their
+// reduced values parked in lanes 0 .. PREP_CPW - 1, which then finish their own boxes (prepare_kernel steps 4 and 5, the same operations).
+template <typename PT>
+__global__ __launch_bounds__(256) void prep_records_kernel(const PT* __restrict__ points, const int* __restrict__ labels, int N, int P, int NCMAX,
+                                                           const unsigned long long* __restrict__ keys_all, Rec<PT>* __restrict__ packed,
+                                                           Box* __restrict__ boxes_all, int* __restrict__ counts, const double* __restrict__ Kmat,
+                                                           double H, double W, float* __restrict__ camf_all, PrepWs w) {
+    const int f = blockIdx.y;
+    if (w.flag[f]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const PT* px = points + (long long)f * 3 * N;
+    const PT* py = px + N;
+    const PT* pz = px + 2 * (long long)N;
+    const int* lab = labels + (long long)f * N;
+    const unsigned long long* skeys = keys_all + (long long)f * 2 * P + P;
+    Rec<PT>* out = packed + (long long)f * (N + 2 * CL);
+    Box* boxes = boxes_all + (long long)f * NCMAX;
+    const PrepFrame fr = prep_frame(w.partial, f);
+    const int n1 = fr.n1, n0 = fr.n0;
+    const int nc1 = (n1 + CL - 1) / CL, nc0 = (n0 + CL - 1) / CL, nct = nc1 + nc0;
+    if (blockIdx.x == 0 && tid == 0) {
+        counts[4 * f] = n1; counts[4 * f + 1] = n0; counts[4 * f + 2] = nc1; counts[4 * f + 3] = nc0;
+        const double* Kf = Kmat + (long long)f * 9;
+        float* cf = camf_all + (long long)f * 8;
+        const float fx = (float)Kf[0], cx = (float)Kf[2], wcx = (float)((W - 1.0) - Kf[2]), fy = (float)Kf[4], cy = (float)Kf[5], hcy = (float)((H - 1.0) - Kf[5]);
+        const float iL = 1.0f / (fabsf(fx) + fabsf(cx)), iR = 1.0f / (fabsf(fx) + fabsf(wcx));
+        const float iT = 1.0f / (fabsf(fy) + fabsf(cy)), iB = 1.0f / (fabsf(fy) + fabsf(hcy));
+        cf[0] = fx * iL; cf[1] = cx * iL; cf[2] = fx * iR; cf[3] = wcx * iR;
+        cf[4] = fy * iT; cf[5] = cy * iT; cf[6] = fy * iB; cf[7] = hcy * iB;
+    }
+    const int c_first = (blockIdx.x * 4 + wave) * PREP_CPW;
+    if (c_first >= nct) return;              // wave-uniform
+    double mlo[3] = {0, 0, 0}, mhi[3] = {0, 0, 0};
+    float mrxz = 0.0f, mr3 = 0.0f;
+    bool mnan = false;
+    for (int tt = 0; tt < PREP_CPW && c_first + tt < nct; ++tt) {
+        const int c = c_first + tt;
+        const int i = c * CL + lane;
+        const bool first = c < nc1;
+        const int rank = first ? min(i, n1 - 1) : n1 + min(i - nc1 * CL, n0 - 1);       // position in the sorted key list (padding: the block's last record)
+        const int nn = (int)(unsigned)(skeys[rank] & 0xffffffffull);
+        Rec<PT> r;
+        r.x = px[nn]; r.y = py[nn]; r.z = pz[nn]; r.lab = lab[nn];
+        out[i] = r;
+        const int end = first ? n1 : nc1 * CL + n0;
+        const bool valid = i < end;
+        const double x = valid ? (double)r.x : 0.0, y = valid ? (double)r.y : 0.0, z = valid ? (double)r.z : 0.0;
+        double lo[3] = {valid ? x : __builtin_inf(), valid ? y : __builtin_inf(), valid ? z : __builtin_inf()};
+        double hi[3] = {valid ? x : -__builtin_inf(), valid ? y : -__builtin_inf(), valid ? z : -__builtin_inf()};
+        double rxz = valid ? x * x + z * z : 0.0, r3 = valid ? x * x + y * y + z * z : 0.0;
+        float frxz, fr3;
+        if (sizeof(PT) == 4) {
+            float l0 = (float)lo[0], l1 = (float)lo[1], l2 = (float)lo[2], h0 = (float)hi[0], h1 = (float)hi[1], h2 = (float)hi[2];
+            float pad0 = __builtin_inff(), pad1 = 0.0f;
+            frxz = (float)(sqrt(rxz) * (1.0 + 1e-6)) + 1e-30f; fr3 = (float)(sqrt(r3) * (1.0 + 1e-6)) + 1e-30f;
+            wave_min4_f32(l0, l1, l2, pad0);
+            wave_max4_f32(h0, h1, h2, pad1);
+            float pad2 = 0.0f, pad3 = 0.0f;
+            wave_max4_f32(frxz, fr3, pad2, pad3);
+            lo[0] = l0; lo[1] = l1; lo[2] = l2; hi[0] = h0; hi[1] = h1; hi[2] = h2;
+        } else {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { lo[a] = fmin(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmax(hi[a], __shfl_xor(hi[a], o)); }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { rxz = fmax(rxz, __shfl_xor(rxz, o)); r3 = fmax(r3, __shfl_xor(r3, o)); }
+            frxz = (float)(sqrt(rxz) * (1.0 + 1e-6)) + 1e-30f; fr3 = (float)(sqrt(r3) * (1.0 + 1e-6)) + 1e-30f;
+        }
+        const bool nan_any = __any(valid && !(x == x && y == y && z == z)) != 0;
+        if (lane == tt) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { mlo[a] = lo[a]; mhi[a] = hi[a]; }
+            mrxz = frxz; mr3 = fr3; mnan = nan_any;
+        }
+    }
+    const int c = c_first + lane;
+    if (lane < PREP_CPW && c < nct) {
+        Box bx;
+        float* bc = &bx.cx;
+        float* bh = &bx.hx;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double cd = 0.5 * (mlo[a] + mhi[a]);
+            const float cf = (float)cd;
+            const double hd = fmax(mhi[a] - (double)cf, (double)cf - mlo[a]);
+            bc[a] = cf;
+            bh[a] = (float)(hd * (1.0 + 1e-6)) + 1e-30f;
+        }
+        if (mnan) bx.hx = __builtin_nanf("");
+        bx.rxz = mrxz;
+        bx.r3 = mr3;
+        boxes[c] = bx;
     }
 }
 
@@ -2323,7 +2592,7 @@ __global__ __launch_bounds__(256) void residuals_kernel(const double* __restrict
 static long long* g_prof = nullptr;   // diagnostics hook, see di2p_solver_set_profile_buffer
 
 constexpr size_t kStateBytes = sizeof(LMState<6>) > sizeof(LMState<4>) ? sizeof(LMState<6>) : sizeof(LMState<4>);
-struct SolveWs { int P, NCMAX; size_t off_recs, off_boxes, off_keys, off_pending, off_state, off_cache, off_camf, bytes; };
+struct SolveWs { int P, NCMAX; size_t off_recs, off_boxes, off_keys, off_pending, off_state, off_cache, off_camf, off_partial, off_hist, off_cursor, off_bases, off_flag, bytes; };
 static SolveWs solve_ws_layout(int F, int R, int N) {
     SolveWs w;
     w.P = 64;
@@ -2337,7 +2606,12 @@ static SolveWs solve_ws_layout(int F, int R, int N) {
     w.off_state = up(w.off_pending + (size_t)F * R * sizeof(int));
     w.off_cache = up(w.off_state + (size_t)F * R * kStateBytes);
     w.off_camf = up(w.off_cache + (size_t)F * R * (w.NCMAX + CACHE_PAD) * sizeof(CacheEnt));
-    w.bytes = up(w.off_camf + (size_t)F * 8 * sizeof(float)) + 256;
+    w.off_partial = up(w.off_camf + (size_t)F * 8 * sizeof(float));
+    w.off_hist = up(w.off_partial + (size_t)F * PREP_G * 8 * sizeof(float));
+    w.off_cursor = up(w.off_hist + (size_t)F * PREP_NBK * sizeof(int));
+    w.off_bases = up(w.off_cursor + (size_t)F * PREP_NBK * sizeof(int));
+    w.off_flag = up(w.off_bases + (size_t)F * (PREP_NBK + 1) * sizeof(int));
+    w.bytes = up(w.off_flag + (size_t)F * sizeof(int)) + 256;
     return w;
 }
 
@@ -2348,7 +2622,8 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
     Bounds b;
     for (int i = 0; i < 3; ++i) { b.lb[i] = lb[i]; b.ub[i] = ub[i]; }
     // workspace: counts i32[F][4] | records Rec[F][N] | cluster boxes [F][NCMAX] | sort keys u64[F][P] | pending i32[F][R] | parked LM states [F][R] |
-    // classification cache [F][R][NCMAX + CACHE_PAD] | normalised plane coefficients f32[F][8]
+    // classification cache [F][R][NCMAX + CACHE_PAD] | normalised plane coefficients f32[F][8] | multi-workgroup preparation: partial bounds
+    // f32[F][G][8], bucket histogram / cursors i32[F][2048] each, bucket offsets i32[F][2049], fallback flag i32[F]
     const SolveWs ws = solve_ws_layout(F, R, N);
     char* base = (char*)workspace;
     int* counts = (int*)base;
@@ -2356,8 +2631,26 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
     Box* boxes = (Box*)(base + ws.off_boxes);
     unsigned long long* keys = (unsigned long long*)(base + ws.off_keys);
     float* camf = (float*)(base + ws.off_camf);
-    hipLaunchKernelGGL(prepare_kernel<PT>, dim3(F), dim3(1024), 0, st, points, labels, N, ws.P, ws.NCMAX, keys, packed, boxes, counts,
-                       (int)(di2p_opt(DI2P_OPT_SOLVER_PREP_BITONIC) != 0), K, H, W, camf);
+    // frame preparation: five multi-workgroup launches + the single-workgroup kernel as the fallback of flagged (degenerate) frames;
+    // solver_prep_bitonic = 1: the bitonic network for every frame, solver_prep_single = 1: the round-4 single-workgroup kernel (same results)
+    const int prep_bitonic = (int)(di2p_opt(DI2P_OPT_SOLVER_PREP_BITONIC) != 0);
+    if (prep_bitonic || di2p_opt(DI2P_OPT_SOLVER_PREP_SINGLE) != 0) {
+        hipLaunchKernelGGL(prepare_kernel<PT>, dim3(F), dim3(1024), 0, st, points, labels, N, ws.P, ws.NCMAX, keys, packed, boxes, counts,
+                           prep_bitonic, K, H, W, camf, (const int*)nullptr);
+    } else {
+        static_assert(PREP_NBK % PREP_G == 0 && PREP_NBK == 2048, "the slice kernels zero / scan the histogram in these shapes");
+        PrepWs pw;
+        pw.partial = (float*)(base + ws.off_partial); pw.hist = (int*)(base + ws.off_hist); pw.cursor = (int*)(base + ws.off_cursor);
+        pw.bases = (int*)(base + ws.off_bases); pw.flag = (int*)(base + ws.off_flag);
+        hipLaunchKernelGGL(prep_bounds_kernel<PT>, dim3(F * PREP_G), dim3(256), 0, st, points, labels, N, pw);
+        hipLaunchKernelGGL(prep_hist_kernel<PT>, dim3(F * PREP_G), dim3(256), 0, st, points, labels, N, ws.P, keys, pw);
+        hipLaunchKernelGGL(prep_scatter_kernel, dim3(F * PREP_G), dim3(1024), 0, st, N, ws.P, keys, pw);
+        hipLaunchKernelGGL(prep_rank_kernel, dim3((N + 255) / 256, F), dim3(256), 0, st, ws.P, keys, pw);
+        hipLaunchKernelGGL(prep_records_kernel<PT>, dim3((ws.NCMAX + 4 * PREP_CPW - 1) / (4 * PREP_CPW), F), dim3(256), 0, st, points, labels, N, ws.P,
+                           ws.NCMAX, (const unsigned long long*)keys, packed, boxes, counts, K, H, W, camf, pw);
+        hipLaunchKernelGGL(prepare_kernel<PT>, dim3(F), dim3(1024), 0, st, points, labels, N, ws.P, ws.NCMAX, keys, packed, boxes, counts, 0, K, H, W,
+                           camf, (const int*)pw.flag);
+    }
     // DI2P_SOLVER_CFG=<waves per hypothesis><min waves/SIMD>, e.g. 43 (default); DI2P_SOLVER_NOCULL=1 classifies every
     // cluster per point (the sums are bit-identical by construction: tests compare the two)
     const int cfg = (int)di2p_opt(DI2P_OPT_SOLVER_CFG);
