@@ -51,6 +51,9 @@
 #ifndef DI2P_SOLVER_EXEC_APPEND
 #define DI2P_SOLVER_EXEC_APPEND 1 // 1: phase II stores a cluster's active ids under exec = its active mask (no per-lane bit test)
 #endif
+#ifndef DI2P_SOLVER_LMBATCH
+#define DI2P_SOLVER_LMBATCH 0     // 1: the LM stages fetch their state from LDS in one batch into registers (fewer serial LDS round trips on the critical lane)
+#endif
 #ifndef DI2P_SOLVER_LMROT
 #define DI2P_SOLVER_LMROT 0       // 1: the wave that advances the LM state rotates with the sweep number (spreads the single-lane code over the SIMDs)
 #endif
@@ -496,17 +499,18 @@ __global__ __launch_bounds__(1024) void prepare_kernel(const PT* __restrict__ po
 // MULTI-WORKGROUP frame preparation (round 6).  prepare_kernel runs one 1024-thread workgroup per frame: 32 of 256 compute units for 0.26 ms at
 // the head of every solve.  The same five steps as five launches, G workgroups per frame each (same keys, same total order, same records and
 // boxes, bit for bit -- tests compare the paths):
-//   prep_bounds_kernel   partial ground-plane bounds + label counts per slice; zeroes the frame's histogram / cursors / flag
-//   prep_hist_kernel     keys of the slice (stored), bucket histogram (LDS atomics, flushed with global atomics)
-//   prep_scatter_kernel  exclusive scan of the histogram (every workgroup, into LDS), keys scattered to their buckets (global cursors)
+//   prep_bounds_kernel   partial ground-plane bounds + label counts per slice; clears the frame's flag
+//   prep_hist_kernel     keys of the slice (stored), bucket counts of the slice (LDS atomics) -> [frame][slice][bucket]
+//   prep_scatter_kernel  bucket offsets = exclusive scan of the summed counts (every workgroup, into LDS); a slice's keys go to
+//                        offset[bucket] + (counts of the slices before it) + an LDS cursor: no global atomics
 //   prep_rank_kernel     one thread per key: rank inside its bucket by counting -> sorted keys
 //   prep_records_kernel  one wavefront per cluster: gathers its 64 records, writes them and reduces the box FROM ITS REGISTERS
 // A frame with a bucket above 4096 keys is flagged by the scatter step, skipped by the last two and prepared by prepare_kernel (launched
 // behind them with `only_flagged`).
 constexpr int PREP_NBK = 2048;        // buckets: the top 11 key bits (label + 32 x 32 grid of the Hilbert curve)
 constexpr int PREP_G = 8;             // workgroups per frame of the slice kernels (PREP_NBK % PREP_G == 0)
-constexpr int PREP_CPW = 16;          // clusters per wavefront of prep_records_kernel (parked in lanes 0..15, finished lane-parallel)
-struct PrepWs { float* partial; int* hist; int* cursor; int* bases; int* flag; };      // [F][G][8] | [F][NBK] | [F][NBK] | [F][NBK + 1] | [F]
+constexpr int PREP_CPW = 4;           // clusters per wavefront of prep_records_kernel (their keys, then their gathers, in flight together; parked in lanes 0..3, finished lane-parallel)
+struct PrepWs { float* partial; int* cntg; int* bases; int* flag; };      // [F][G][8] | [F][G][NBK] bucket counts per slice | [F][NBK + 1] | [F]
 
 // bounds, scale and label counts of a frame from its G partial results (same min / max / sums whatever the slicing: exact operations)
 struct PrepFrame { float mnx, mnz, scale; int n1, n0; };
@@ -536,10 +540,6 @@ __global__ __launch_bounds__(256) void prep_bounds_kernel(const PT* __restrict__
     const PT* px = points + (long long)f * 3 * N;
     const PT* pz = px + 2 * (long long)N;
     const int* lab = labels + (long long)f * N;
-    for (int i = tid; i < PREP_NBK / PREP_G; i += 256) {
-        w.hist[(long long)f * PREP_NBK + g * (PREP_NBK / PREP_G) + i] = 0;
-        w.cursor[(long long)f * PREP_NBK + g * (PREP_NBK / PREP_G) + i] = 0;
-    }
     if (g == 0 && tid == 0) w.flag[f] = 0;
     int lo, hi;
     prep_slice(N, g, lo, hi);
@@ -602,18 +602,24 @@ __global__ __launch_bounds__(256) void prep_hist_kernel(const PT* __restrict__ p
         if (k != ~0ull) atomicAdd(&cnt[(int)(k >> 42)], 1);
     }
     __syncthreads();
-    for (int i = tid; i < PREP_NBK; i += 256)
-        if (cnt[i]) atomicAdd(&w.hist[(long long)f * PREP_NBK + i], cnt[i]);
+    for (int i = tid; i < PREP_NBK; i += 256) w.cntg[((long long)f * PREP_G + g) * PREP_NBK + i] = cnt[i];
 }
 
 __global__ __launch_bounds__(1024) void prep_scatter_kernel(int N, int P, unsigned long long* __restrict__ keys_all, PrepWs w) {
-    __shared__ int basev[PREP_NBK + 1];
+    __shared__ int cur[PREP_NBK];           // where the slice's next key of a bucket goes
     __shared__ int s_w[16];
     const int f = blockIdx.x / PREP_G, g = blockIdx.x % PREP_G, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long* keys = keys_all + (long long)f * 2 * P;
     const unsigned long long* raw = keys + P;
-    {   // exclusive scan of the 2048 counts: two per thread, wave scan, 16 wave totals (prepare_kernel's scan)
-        const int a0 = w.hist[(long long)f * PREP_NBK + 2 * tid], a1 = w.hist[(long long)f * PREP_NBK + 2 * tid + 1];
+    {   // exclusive scan of the 2048 summed counts: two buckets per thread, wave scan, 16 wave totals (prepare_kernel's scan)
+        const int* cg = w.cntg + (long long)f * PREP_G * PREP_NBK;
+        int a0 = 0, a1 = 0, before0 = 0, before1 = 0;       // totals of the two buckets; the keys of the slices before this one
+#pragma unroll
+        for (int q = 0; q < PREP_G; ++q) {
+            const int c0 = cg[q * PREP_NBK + 2 * tid], c1 = cg[q * PREP_NBK + 2 * tid + 1];
+            a0 += c0; a1 += c1;
+            before0 += q < g ? c0 : 0; before1 += q < g ? c1 : 0;
+        }
         int v = a0 + a1;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o); if (lane >= o) v += u; }
@@ -622,18 +628,20 @@ __global__ __launch_bounds__(1024) void prep_scatter_kernel(int N, int P, unsign
         int woff = 0;
         for (int q = 0; q < wave; ++q) woff += s_w[q];
         const int excl = woff + v - (a0 + a1);
-        basev[2 * tid] = excl; basev[2 * tid + 1] = excl + a0;
-        if (tid == 1023) basev[PREP_NBK] = excl + a0 + a1;
+        cur[2 * tid] = excl + before0; cur[2 * tid + 1] = excl + a0 + before1;
+        if (g == 0) {
+            int* bases = w.bases + (long long)f * (PREP_NBK + 1);
+            bases[2 * tid] = excl; bases[2 * tid + 1] = excl + a0;
+            if (tid == 1023) bases[PREP_NBK] = excl + a0 + a1;
+        }
         if (a0 > 4096 || a1 > 4096) w.flag[f] = 1;            // a degenerate scene: the frame goes to prepare_kernel's bitonic network
     }
     __syncthreads();
-    if (g == 0)
-        for (int i = tid; i <= PREP_NBK; i += 1024) w.bases[(long long)f * (PREP_NBK + 1) + i] = basev[i];
     int lo, hi;
     prep_slice(N, g, lo, hi);
     for (int n = lo + tid; n < hi; n += 1024) {
         const unsigned long long k = raw[n];
-        if (k != ~0ull) { const int bk = (int)(k >> 42); keys[basev[bk] + atomicAdd(&w.cursor[(long long)f * PREP_NBK + bk], 1)] = k; }
+        if (k != ~0ull) keys[atomicAdd(&cur[(int)(k >> 42)], 1)] = k;
     }
 }
 
@@ -697,14 +705,25 @@ __global__ __launch_bounds__(256) void prep_records_kernel(const PT* __restrict_
     double mlo[3] = {0, 0, 0}, mhi[3] = {0, 0, 0};
     float mrxz = 0.0f, mr3 = 0.0f;
     bool mnan = false;
-    for (int tt = 0; tt < PREP_CPW && c_first + tt < nct; ++tt) {
+    // the PREP_CPW clusters' keys, then their gathers, are requested together (a cluster alone is a chain of two dependent round trips)
+    int nn_all[PREP_CPW];
+#pragma unroll
+    for (int tt = 0; tt < PREP_CPW; ++tt) {
+        const int c = min(c_first + tt, nct - 1);
+        const int i = c * CL + lane;
+        const int rank = c < nc1 ? min(i, n1 - 1) : n1 + min(i - nc1 * CL, n0 - 1);       // position in the sorted key list (padding: the block's last record)
+        nn_all[tt] = (int)(unsigned)(skeys[rank] & 0xffffffffull);
+    }
+    Rec<PT> r_all[PREP_CPW];
+#pragma unroll
+    for (int tt = 0; tt < PREP_CPW; ++tt) { r_all[tt].x = px[nn_all[tt]]; r_all[tt].y = py[nn_all[tt]]; r_all[tt].z = pz[nn_all[tt]]; r_all[tt].lab = lab[nn_all[tt]]; }
+#pragma unroll
+    for (int tt = 0; tt < PREP_CPW; ++tt) {
+        if (c_first + tt >= nct) break;          // wave-uniform
         const int c = c_first + tt;
         const int i = c * CL + lane;
         const bool first = c < nc1;
-        const int rank = first ? min(i, n1 - 1) : n1 + min(i - nc1 * CL, n0 - 1);       // position in the sorted key list (padding: the block's last record)
-        const int nn = (int)(unsigned)(skeys[rank] & 0xffffffffull);
-        Rec<PT> r;
-        r.x = px[nn]; r.y = py[nn]; r.z = pz[nn]; r.lab = lab[nn];
+        const Rec<PT> r = r_all[tt];
         out[i] = r;
         const int end = first ? n1 : nc1 * CL + n0;
         const bool valid = i < end;
@@ -2047,6 +2066,89 @@ struct LMState {
     int n_ls_extra, n_ls_late_accept, n_resweep;      // diagnostics: line-search trials beyond the first, accepted ones among them, re-sweeps
 };
 
+// DI2P_SOLVER_LMBATCH: the LM stages fetch the state they work on from LDS IN ONE BATCH into registers (pinned: every load is issued, then one
+// wait) instead of field by field between the arithmetic -- the update runs on one lane, so every LDS round trip it waits for (~100+ cycles
+// under load; the copy loops alone were 14 read -> wait -> write pairs) is a round trip the whole workgroup waits for.  Same operations on
+// the same values: bit-identical.
+template <int N> __device__ __forceinline__ void pin_regs(double* v) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
+}
+
+#if DI2P_SOLVER_LMBATCH
+template <int NP>
+__device__ __forceinline__ void lm_begin_iteration(LMState<NP>& st) {
+    constexpr int NT = Tri<NP>::N;
+    const double kMinDiag = 1e-6, kMaxDiag = 1e32, kMinRadius = 1e-32, kGradTol = 1e-10;
+    double S[NP], A[NT], g[NP], diag[NP], sc[3];
+#pragma unroll
+    for (int a = 0; a < NP; ++a) { S[a] = st.S[a]; g[a] = st.g[a]; diag[a] = st.diag[a]; }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) A[i] = st.A[i];
+    sc[0] = st.gmax; sc[1] = st.radius; sc[2] = st.decrease;
+    int iter = st.iter, reuse_diag = st.reuse_diag, invalid_run = st.invalid_run;
+    const int max_iter = st.max_iter;
+    pin_regs<NP>(S); pin_regs<NP>(g); pin_regs<NP>(diag); pin_regs<NT>(A); pin_regs<3>(sc);
+    const double gmax = sc[0];
+    double radius = sc[1], decrease = sc[2];
+    auto scaled_A = [&](int a, int b) { const int hi = a >= b ? a : b, lo = a >= b ? b : a; return S[hi] * A[hi * (hi + 1) / 2 + lo] * S[lo]; };
+    auto write_back = [&]() { st.iter = iter; st.radius = radius; st.decrease = decrease; st.reuse_diag = reuse_diag; st.invalid_run = invalid_run; };
+    for (;;) {
+        if (iter >= max_iter || gmax <= kGradTol || radius <= kMinRadius) { write_back(); st.done = 1; return; }
+        ++iter;
+        double M[NT], ds[NP];
+#pragma unroll
+        for (int a = 0; a < NP; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) M[a * (a + 1) / 2 + b] = scaled_A(a, b);
+        if (!reuse_diag) {
+#pragma unroll
+            for (int a = 0; a < NP; ++a) { diag[a] = fmin(fmax(M[a * (a + 1) / 2 + a], kMinDiag), kMaxDiag); st.diag[a] = diag[a]; }
+        }
+#pragma unroll
+        for (int a = 0; a < NP; ++a) { M[a * (a + 1) / 2 + a] += lm_div(diag[a], radius); ds[a] = -(S[a] * g[a]); }
+        bool valid = chol_solve_inplace<NP>(M, ds);
+        double model_change = 0.0;
+        if (valid) {
+            double q = 0.0, l = 0.0;
+#pragma unroll
+            for (int a = 0; a < NP; ++a) {
+                l += ds[a] * (S[a] * g[a]);
+#pragma unroll
+                for (int b = 0; b < NP; ++b) q += ds[a] * scaled_A(a, b) * ds[b];
+            }
+            model_change = -(l + 0.5 * q);
+            valid = model_change > 0.0;
+        }
+        if (!valid) {
+            if (++invalid_run >= 5) { write_back(); st.done = 1; return; }
+            radius /= decrease; decrease *= 2.0; reuse_diag = 1;
+            continue;
+        }
+        invalid_run = 0;
+        write_back();
+        st.model_change = model_change;
+        double x[NP], lb[NP], ub[NP], delta[NP];
+#pragma unroll
+        for (int a = 0; a < NP; ++a) { x[a] = st.x[a]; lb[a] = st.lb[a]; ub[a] = st.ub[a]; }
+        pin_regs<NP>(x); pin_regs<NP>(lb); pin_regs<NP>(ub);
+        double gd = 0.0, dmax = 0.0;
+#pragma unroll
+        for (int a = 0; a < NP; ++a) {
+            delta[a] = ds[a] * S[a];
+            gd += g[a] * delta[a];
+            dmax = fmax(dmax, fabs(delta[a]));
+        }
+        double xe[NP];
+        plus_proj<NP>(x, delta, 1.0, lb, ub, xe);
+#pragma unroll
+        for (int a = 0; a < NP; ++a) { st.delta[a] = delta[a]; st.xe[a] = xe[a]; }
+        st.gd = gd; st.dmax = dmax; st.t = 1.0; st.ls_it = 0;
+        st.phase = PH_TRIAL; st.want_j = 2; st.prev_vok = 0; st.prev_gok = 0;
+        return;   // needs a sweep at xe
+    }
+}
+#else
 template <int NP>
 __device__ __forceinline__ void lm_begin_iteration(LMState<NP>& st) {
     constexpr int NT = Tri<NP>::N;
@@ -2101,6 +2203,8 @@ __device__ __forceinline__ void lm_begin_iteration(LMState<NP>& st) {
     }
 }
 
+#endif
+
 // The LM update is a chain of STAGES, each instantiated exactly once in the kernel (lm_decide -> [wave-wide minimiser] ->
 // lm_trial_next_decide -> lm_apply = {lm_finish_iteration, lm_begin_iteration}); a stage hands the next one an action code.  (As
 // mutually calling inline functions the iteration start was instantiated five times: 13 k instructions, and the register allocator
@@ -2108,6 +2212,41 @@ __device__ __forceinline__ void lm_begin_iteration(LMState<NP>& st) {
 enum { ACT_NONE = 0, ACT_BEGIN = 1, ACT_FINISH_CUR = 2, ACT_FINISH_FIRST = 3, ACT_TRIAL_NEXT = 4, ACT_POLY = 5 };
 
 // candidate (xe, cand_cost, ge, Ae) against the current iterate: tolerance tests, accept / reject.  -> true: start the next iteration
+#if DI2P_SOLVER_LMBATCH
+template <int NP>
+__device__ __forceinline__ bool lm_finish_iteration(LMState<NP>& st, double cand_cost, const double* ge, const double* Ae) {
+    constexpr int NT = Tri<NP>::N;
+    const double kMaxRadius = 1e16, kMinRelDec = 1e-3, kFuncTol = 1e-6, kParamTol = 1e-8;
+    double xo[NP], xn[NP], gl[NP], Al[NT], lb[NP], ub[NP], sc[4];
+#pragma unroll
+    for (int a = 0; a < NP; ++a) { xo[a] = st.x[a]; xn[a] = st.xe[a]; gl[a] = ge[a]; lb[a] = st.lb[a]; ub[a] = st.ub[a]; }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) Al[i] = Ae[i];
+    sc[0] = st.cost; sc[1] = st.model_change; sc[2] = st.radius; sc[3] = st.decrease;
+    pin_regs<NP>(xo); pin_regs<NP>(xn); pin_regs<NP>(gl); pin_regs<NT>(Al); pin_regs<NP>(lb); pin_regs<NP>(ub); pin_regs<4>(sc);
+    double step_norm = 0.0, x_norm = 0.0;
+#pragma unroll
+    for (int a = 0; a < NP; ++a) { step_norm += (xo[a] - xn[a]) * (xo[a] - xn[a]); x_norm += xo[a] * xo[a]; }
+    step_norm = lm_sqrt(step_norm); x_norm = lm_sqrt(x_norm);
+    if (step_norm <= kParamTol * (x_norm + kParamTol)) { st.done = 1; return false; }
+    if (fabs(sc[0] - cand_cost) <= kFuncTol * sc[0]) { st.done = 1; return false; }
+    const double rel = lm_div(sc[0] - cand_cost, sc[1]);
+    if (rel > kMinRelDec) {
+#pragma unroll
+        for (int a = 0; a < NP; ++a) { st.x[a] = xn[a]; st.g[a] = gl[a]; }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) st.A[i] = Al[i];
+        st.cost = cand_cost;
+        st.gmax = grad_max_norm<NP>(xn, gl, lb, ub);
+        const double w = 2.0 * rel - 1.0;
+        st.radius = fmin(kMaxRadius, lm_div(sc[2], fmax(1.0 / 3.0, 1.0 - w * w * w)));
+        st.decrease = 2.0; st.reuse_diag = 0;
+    } else {
+        st.radius = sc[2] / sc[3]; st.decrease = sc[3] * 2.0; st.reuse_diag = 1;
+    }
+    return true;
+}
+#else
 template <int NP>
 __device__ __forceinline__ bool lm_finish_iteration(LMState<NP>& st, double cand_cost, const double* ge, const double* Ae) {
     const double kMaxRadius = 1e16, kMinRelDec = 1e-3, kFuncTol = 1e-6, kParamTol = 1e-8;
@@ -2133,6 +2272,8 @@ __device__ __forceinline__ bool lm_finish_iteration(LMState<NP>& st, double cand
     }
     return true;
 }
+
+#endif
 
 // Second half of a failed line-search trial: the next step size st.tn is known.  -> ACT_FINISH_FIRST when the search gives up
 // (the candidate is then the first trial point, whose sums were kept), ACT_NONE when the next sweep evaluates the new trial point.
@@ -2170,7 +2311,18 @@ __device__ __forceinline__ void lm_poly_wave(LMState<NP>& st) {
 
 // First stage, called by thread 0 after every sweep with the combined sums of the point just evaluated (st.xe).  -> action code
 template <int NP>
-__device__ __forceinline__ int lm_decide(LMState<NP>& st, bool ok, double fe, const double* ge, const double* Ae) {
+__device__ __forceinline__ int lm_decide(LMState<NP>& st, bool ok, double fe, const double* ge_in, const double* Ae_in) {
+#if DI2P_SOLVER_LMBATCH
+    double ge[NP], Ae[Tri<NP>::N];       // the combined sums, fetched in one batch (the copies below were read -> wait -> write pairs)
+#pragma unroll
+    for (int a = 0; a < NP; ++a) ge[a] = ge_in[a];
+#pragma unroll
+    for (int i = 0; i < Tri<NP>::N; ++i) Ae[i] = Ae_in[i];
+    pin_regs<NP>(ge); pin_regs<Tri<NP>::N>(Ae);
+#else
+    const double* ge = ge_in;
+    const double* Ae = Ae_in;
+#endif
     ++st.nsweep;
     if (st.phase == PH_INIT) {
         st.cost = fe;
@@ -2592,7 +2744,7 @@ __global__ __launch_bounds__(256) void residuals_kernel(const double* __restrict
 static long long* g_prof = nullptr;   // diagnostics hook, see di2p_solver_set_profile_buffer
 
 constexpr size_t kStateBytes = sizeof(LMState<6>) > sizeof(LMState<4>) ? sizeof(LMState<6>) : sizeof(LMState<4>);
-struct SolveWs { int P, NCMAX; size_t off_recs, off_boxes, off_keys, off_pending, off_state, off_cache, off_camf, off_partial, off_hist, off_cursor, off_bases, off_flag, bytes; };
+struct SolveWs { int P, NCMAX; size_t off_recs, off_boxes, off_keys, off_pending, off_state, off_cache, off_camf, off_partial, off_cntg, off_bases, off_flag, bytes; };
 static SolveWs solve_ws_layout(int F, int R, int N) {
     SolveWs w;
     w.P = 64;
@@ -2607,9 +2759,8 @@ static SolveWs solve_ws_layout(int F, int R, int N) {
     w.off_cache = up(w.off_state + (size_t)F * R * kStateBytes);
     w.off_camf = up(w.off_cache + (size_t)F * R * (w.NCMAX + CACHE_PAD) * sizeof(CacheEnt));
     w.off_partial = up(w.off_camf + (size_t)F * 8 * sizeof(float));
-    w.off_hist = up(w.off_partial + (size_t)F * PREP_G * 8 * sizeof(float));
-    w.off_cursor = up(w.off_hist + (size_t)F * PREP_NBK * sizeof(int));
-    w.off_bases = up(w.off_cursor + (size_t)F * PREP_NBK * sizeof(int));
+    w.off_cntg = up(w.off_partial + (size_t)F * PREP_G * 8 * sizeof(float));
+    w.off_bases = up(w.off_cntg + (size_t)F * PREP_G * PREP_NBK * sizeof(int));
     w.off_flag = up(w.off_bases + (size_t)F * (PREP_NBK + 1) * sizeof(int));
     w.bytes = up(w.off_flag + (size_t)F * sizeof(int)) + 256;
     return w;
@@ -2623,7 +2774,7 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
     for (int i = 0; i < 3; ++i) { b.lb[i] = lb[i]; b.ub[i] = ub[i]; }
     // workspace: counts i32[F][4] | records Rec[F][N] | cluster boxes [F][NCMAX] | sort keys u64[F][P] | pending i32[F][R] | parked LM states [F][R] |
     // classification cache [F][R][NCMAX + CACHE_PAD] | normalised plane coefficients f32[F][8] | multi-workgroup preparation: partial bounds
-    // f32[F][G][8], bucket histogram / cursors i32[F][2048] each, bucket offsets i32[F][2049], fallback flag i32[F]
+    // f32[F][G][8], bucket counts per slice i32[F][G][2048], bucket offsets i32[F][2049], fallback flag i32[F]
     const SolveWs ws = solve_ws_layout(F, R, N);
     char* base = (char*)workspace;
     int* counts = (int*)base;
@@ -2640,7 +2791,7 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
     } else {
         static_assert(PREP_NBK % PREP_G == 0 && PREP_NBK == 2048, "the slice kernels zero / scan the histogram in these shapes");
         PrepWs pw;
-        pw.partial = (float*)(base + ws.off_partial); pw.hist = (int*)(base + ws.off_hist); pw.cursor = (int*)(base + ws.off_cursor);
+        pw.partial = (float*)(base + ws.off_partial); pw.cntg = (int*)(base + ws.off_cntg);
         pw.bases = (int*)(base + ws.off_bases); pw.flag = (int*)(base + ws.off_flag);
         hipLaunchKernelGGL(prep_bounds_kernel<PT>, dim3(F * PREP_G), dim3(256), 0, st, points, labels, N, pw);
         hipLaunchKernelGGL(prep_hist_kernel<PT>, dim3(F * PREP_G), dim3(256), 0, st, points, labels, N, ws.P, keys, pw);

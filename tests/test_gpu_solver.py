@@ -338,7 +338,8 @@ def test_solver_matches_oracle_other_cameras(dev, seed, is_2d, N, HW, flip):
 @pytest.mark.parametrize("N", [777, 20480])
 def test_frame_preparation_sort_paths_agree(dev, scene, N):
     """Frame preparation sorts the records by (label, Hilbert cell, index).  The shipped path is a counting sort into (label, cell) buckets
-    followed by a ranking of every key inside its bucket, ONE THREAD PER KEY (solver.hip prepare_kernel step 3a); a frame with a bucket above
+    followed by a ranking of every key inside its bucket, ONE THREAD PER KEY -- round 6: as five launches of several workgroups per frame
+    (solver.hip prep_*_kernel), round 4: one workgroup per frame (prepare_kernel step 3a, knob solver_prep_single); a frame with a bucket above
     4096 keys goes to the bitonic network instead.  Either way the order must be the SAME as the bitonic network's (knob solver_prep_bitonic):
     params, costs, iteration and sweep counts bit-identical.  Scenes: a scan (small buckets), patchy (dense patches: large buckets), collapsed
     (a far outlier stretches the grid so that everything shares a few cells: the fallback), duplicates (equal coordinates, unique keys by
@@ -367,7 +368,10 @@ def test_frame_preparation_sort_paths_agree(dev, scene, N):
         sweeps = torch.zeros((1, R), dtype=torch.int32, device=dev)
         params, cost, iters = ops.solve_batched(*args, sweeps=sweeps)
         return [t.cpu().numpy().tobytes() for t in (params, cost, iters, sweeps)]
-    a = run()
+    a = run()                                    # round 6: five multi-workgroup launches (+ the single-workgroup kernel for flagged frames)
     with _lib.option("solver_prep_bitonic", 1):
         b = run()
     assert a == b
+    with _lib.option("solver_prep_single", 1):   # the round-4 single-workgroup kernel (counting sort + ranking)
+        c = run()
+    assert a == c
