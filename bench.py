@@ -468,7 +468,7 @@ def main():
     # HBM traffic per launch from the committed PMC passes of the same kernels on the same shapes (separate rocprofv3
     # --pmc FETCH_SIZE / WRITE_SIZE runs, corrected as MI355X_MICROARCH.md prescribes); None if absent
     pmc = {}
-    for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fn in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as fh:
                 pmc = json.load(fh)
@@ -484,7 +484,7 @@ def main():
     # 64 lanes x (2 FMA + ADD + MUL) wave-instructions per launch)
     try:
         sc = None
-        for fn in ("r05_solver_counters.json", "r04_solver_counters.json", "r03_solver_counters.json"):
+        for fn in ("r06_solver_counters.json", "r05_solver_counters.json", "r04_solver_counters.json", "r03_solver_counters.json"):
             path = os.path.join(ROOT, "profiles", fn)
             if os.path.exists(path):
                 with open(path) as fh:

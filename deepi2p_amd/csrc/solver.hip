@@ -39,33 +39,6 @@
 #ifndef DI2P_SOLVER_PFC
 #define DI2P_SOLVER_PFC 2         // clusters CLASSIFIED per straight-line batch (1, 2 or 4): ~2 per label block and round need it since the cache (round 6: 4 -> 2, -2 % vector instructions)
 #endif
-#ifndef DI2P_SOLVER_NOVALID
-#define DI2P_SOLVER_NOVALID 1     // 1: no per-lane validity masks in the walk (padding lanes are copies of valid records; the ballot is cut by a scalar mask)
-#endif
-#ifndef DI2P_SOLVER_CAMF
-#define DI2P_SOLVER_CAMF 1        // 1: the normalised plane coefficients come from a per-frame table (prepare_kernel) instead of being re-derived per wave and sweep
-#endif
-#ifndef DI2P_SOLVER_BOXMS
-#define DI2P_SOLVER_BOXMS 1       // 1: the per-point margin m S of the walk is the CLUSTER's (from its box: >= every point's), read from the lane that owns the cluster
-#endif
-#ifndef DI2P_SOLVER_EXEC_APPEND
-#define DI2P_SOLVER_EXEC_APPEND 1 // 1: phase II stores a cluster's active ids under exec = its active mask (no per-lane bit test)
-#endif
-#ifndef DI2P_SOLVER_LMBATCH
-#define DI2P_SOLVER_LMBATCH 0     // 1: the LM stages fetch their state from LDS in one batch into registers (fewer serial LDS round trips on the critical lane)
-#endif
-#ifndef DI2P_SOLVER_LMROT
-#define DI2P_SOLVER_LMROT 0       // 1: the wave that advances the LM state rotates with the sweep number (spreads the single-lane code over the SIMDs)
-#endif
-#ifndef DI2P_SOLVER_FLATROUND
-#define DI2P_SOLVER_FLATROUND 1   // 1: the cluster-test round (status decision table, cache look-up) as selects instead of nested divergent branches
-#endif
-#ifndef DI2P_SOLVER_GUARD_TBZ
-#define DI2P_SOLVER_GUARD_TBZ 1   // 1: guard-only clusters whose box clears the left / right planes by DI2P_GUARD_LR_MIN are guarded on the top / bottom / z planes only
-#endif
-#ifndef DI2P_SOLVER_WRITELANE
-#define DI2P_SOLVER_WRITELANE 0   // 1: a batch's results go into the owning lane by v_writelane (one instruction per value) instead of compare + select
-#endif
 
 namespace {
 
@@ -1044,7 +1017,8 @@ __device__ __forceinline__ void eval_active(const Rec<PT>& rc, const Rot<NP>& ro
 //   label 1: inactive iff all five are positive, else every point is active;
 //   label 0: active   iff all five are positive, else every point is inactive (and cannot raise `bad`).
 // NaN/inf anywhere fails every comparison and falls back to the per-point path.
-// Returns 0: skip, 1: classify per point, 2: all active, 3 (label 0 only): no point is active, guard against exact zeros only.
+// Returns 0: skip, 1: classify per point, 2: all active, 3 (label 0 only): no point is active, guard against exact zeros only, 5: the same
+// on the top / bottom / z planes only (below).
 struct Pre32;
 struct alignas(16) BoxAbs {        // per sweep: |n_i^T R|_j * (1 + 1e-5) of the five planes and |t|_1 (wave-uniform; 16 words, kept in LDS)
     float aL[3], aR[3], aT[3], aB[3], aZ[3], T1;
@@ -1065,43 +1039,32 @@ struct Pre32 {
     float aL, bL, aR, bR, aT, bT, aB, bB;      // f_L = aL p0 + bL p2, f_R = -aR p0 + bR p2, f_T = aT p1 + bT p2, f_B = -aB p1 + bB p2
 };
 template <int NP>
-__device__ __forceinline__ void make_pre32(const Rot<NP>& rot, double tx, double ty, double tz, const Cam& k, const float* camf, Pre32& q) {
+__device__ __forceinline__ void make_pre32(const Rot<NP>& rot, double tx, double ty, double tz, const float* camf, Pre32& q) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) q.R[i] = (float)rot.R[i];
     q.t[0] = (float)tx; q.t[1] = (float)ty; q.t[2] = (float)tz;
     q.T1 = (fabsf(q.t[0]) + fabsf(q.t[1]) + fabsf(q.t[2])) * 1.000001f;
-#if DI2P_SOLVER_CAMF
-    // the camera-only part comes from the frame's table (prepare_kernel: the same expressions, the same bits), through SCALAR loads: the table
-    // was written by an earlier kernel and is read through the constant address space (a uniform load from plain global memory becomes a
-    // per-lane vector load as soon as the kernel also stores to global memory)
+    // The camera-only part -- the eight normalised plane coefficients: six conversions, four divisions, eight products -- comes from the frame's
+    // table (written by the preparation kernels) through SCALAR loads: the table is read through the constant address space (a uniform
+    // load from plain global memory becomes a per-lane vector load as soon as the kernel also stores to global memory).  Round 6: -3 % of
+    // the kernel's vector instructions, at the head of every sweep where all four waves of a workgroup are in step.
     typedef const float __attribute__((address_space(4))) * ConstF;
     const ConstF cf = (ConstF)camf;
     q.aL = cf[0]; q.bL = cf[1]; q.aR = cf[2]; q.bR = cf[3]; q.aT = cf[4]; q.bT = cf[5]; q.aB = cf[6]; q.bB = cf[7];
-    {
-        float* f = reinterpret_cast<float*>(&q);
-#pragma unroll
-        for (int i = 0; i < 13; ++i) f[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, f[i])));      // R, t, T1
-    }
-    return;
-#endif
-    const float fx = (float)k.fx, cx = (float)k.cx, wcx = (float)(k.W1 - k.cx), fy = (float)k.fy, cy = (float)k.cy, hcy = (float)(k.H1 - k.cy);
-    const float iL = 1.0f / (fabsf(fx) + fabsf(cx)), iR = 1.0f / (fabsf(fx) + fabsf(wcx));
-    const float iT = 1.0f / (fabsf(fy) + fabsf(cy)), iB = 1.0f / (fabsf(fy) + fabsf(hcy));
-    q.aL = fx * iL; q.bL = cx * iL; q.aR = fx * iR; q.bR = wcx * iR;
-    q.aT = fy * iT; q.bT = cy * iT; q.aB = fy * iB; q.bB = hcy * iB;
-    // wave-uniform by construction: keep the whole table in SGPRs (it is live across the cluster loop)
+    // wave-uniform by construction: R, t, T1 are forced into SGPRs as well (the table is live across the cluster loop)
     float* f = reinterpret_cast<float*>(&q);
 #pragma unroll
-    for (int i = 0; i < (int)(sizeof(Pre32) / sizeof(float)); ++i) f[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, f[i])));
+    for (int i = 0; i < 13; ++i) f[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, f[i])));
 }
+// mS: the margin m S of the point -- round 6: the CLUSTER's, from its box (|x|_1 <= |c|_1 + |h|_1 for every point of it: never smaller than the
+// point's own, so more points fall to the exact test and none is certified wrongly), read from the lane that owns the cluster.
 // -> act, and the point's SLACK: how far (normalised plane units = metres of displacement of the point, |.|_inf) the point is, beyond the
 // margin, from changing its classification -- label 1: |min_i f_i| - m S (an inside point: the nearest plane; an outside point: its most
 // negative plane, which keeps it active whatever the others do); label 0: min_i |f_i| - m S (EVERY plane: an exact zero on any of them is an
 // evaluation failure in the reference).  slack > 0 <=> the point is certified (act is then the exact test's answer); NaN / inf anywhere
 // fails that comparison.
 template <int NP, int LAB>
-__device__ __forceinline__ void prefilter32(const Pre32& q, float X, float Y, float Z, bool& act, float& slack, float mS_given = -1.0f) {
-    const float mS = DI2P_SOLVER_BOXMS ? mS_given : kPreRel * ((fabsf(X) + fabsf(Y)) + (fabsf(Z) + q.T1));
+__device__ __forceinline__ void prefilter32(const Pre32& q, float X, float Y, float Z, float mS, bool& act, float& slack) {
     float p0, p1, p2;
     if (NP == 4) {
         p0 = fmaf(q.R[0], X, fmaf(q.R[2], Z, q.t[0])); p1 = Y + q.t[1]; p2 = fmaf(q.R[6], X, fmaf(q.R[8], Z, q.t[2]));
@@ -1125,8 +1088,7 @@ __device__ __forceinline__ void prefilter32(const Pre32& q, float X, float Y, fl
 
 // The guard of a status-5 cluster: slack towards the top / bottom / z planes only (8 instead of 16 instructions for the plane functions).
 template <int NP>
-__device__ __forceinline__ float guard32_tbz(const Pre32& q, float X, float Y, float Z, float mS_given = -1.0f) {
-    const float mS = DI2P_SOLVER_BOXMS ? mS_given : kPreRel * ((fabsf(X) + fabsf(Y)) + (fabsf(Z) + q.T1));
+__device__ __forceinline__ float guard32_tbz(const Pre32& q, float X, float Y, float Z, float mS) {
     float p1, p2;
     if (NP == 4) {
         p1 = Y + q.t[1]; p2 = fmaf(q.R[6], X, fmaf(q.R[8], Z, q.t[2]));
@@ -1151,7 +1113,7 @@ __device__ __forceinline__ void make_box_abs(const Pre32& p, BoxAbs& q) {
     }
     q.T1 = fabsf(p.t[0]) + fabsf(p.t[1]) + fabsf(p.t[2]);
 }
-// Status 5 (label 0, DI2P_SOLVER_GUARD_TBZ): a guard-only cluster whose box clears BOTH the left and the right plane by more than kGuardLrMin
+// Status 5 (label 0): a guard-only cluster whose box clears BOTH the left and the right plane by more than kGuardLrMin
 // (normalised plane units = metres).  No point of it can sit on those two planes, and the box's clearance *lr_slack is a lower bound of every
 // point's |f_L|, |f_R| minus its margin (the box margin contains the point margin: mS_box >= mS_point, support >= the point's offset): the
 // per-point guard evaluates the top / bottom / z planes only and the recorded slack is min(point slack on those three, *lr_slack).
@@ -1175,38 +1137,18 @@ __device__ __forceinline__ int cluster_status(const Box& bx, const Pre32& q, con
     const float lo = fminf(fminf(fminf(fL - tL, fR - tR), fminf(fT - tT, fB - tB)), p2 - tZ);
     const float cm = fminf(fminf(fminf(fabsf(fL) - tL, fabsf(fR) - tR), fminf(fabsf(fT) - tT, fabsf(fB) - tB)), fabsf(p2) - tZ);
     const bool inside = lo > 0.0f;
-#if DI2P_SOLVER_FLATROUND
-    {   // the same decision table without divergent branches (every lane of a round takes another path through the nested form: the wave runs
-        // all of them anyway, plus the register copies at their joins); a NaN fails every comparison -> 1, as below
-        const float hi_ = fminf(fminf(fminf(fL + tL, fR + tR), fminf(fT + tT, fB + tB)), p2 + tZ);
-        const bool decided = cm > 0.0f, neg = hi_ < 0.0f;
-        if (LAB == 1) return decided ? (inside ? 0 : 2) : (neg ? 2 : 1);
-        int g = 3;
-#if DI2P_SOLVER_GUARD_TBZ
-        const float lrs = fminf(fabsf(fL) - tL, fabsf(fR) - tR);
-        *lr_slack = lrs;
-        g = lrs > kGuardLrMin ? 5 : 3;
-#endif
-        return decided ? (inside ? 2 : 0) : (neg ? g : 1);
-    }
-#endif
-    if (cm > 0.0f) return (LAB == 1) ? (inside ? 0 : 2) : (inside ? 2 : 0);
-    // a decided-negative plane already decides every point: not inside.  Label 1: all active.  Label-0 points of such a
-    // cluster may still sit exactly on one of the undecided planes (dx, dy or p2 == 0 is an evaluation failure in the
-    // reference): status 3 = no point can be active, but every point is still checked against exact zeros (fp32 guard,
-    // exact test when the guard cannot certify) -- without the ballot / queue work of a real classification.
+    // The decision table as selects (as nested returns every lane of a round took another path: the wave ran all of them anyway, plus the
+    // register copies at their joins -- round 6: 157 -> 133 vector instructions per round).  A NaN fails every comparison -> 1.
+    // A decided-negative plane already decides every point: not inside.  Label 1: all active.  Label-0 points of such a cluster may still sit
+    // exactly on one of the undecided planes (dx, dy or p2 == 0 is an evaluation failure in the reference): status 3 / 5 = no point can be
+    // active, but every point is still checked against exact zeros (fp32 guard, exact test when the guard cannot certify) -- without the
+    // ballot / queue work of a real classification.
     const float hi = fminf(fminf(fminf(fL + tL, fR + tR), fminf(fT + tT, fB + tB)), p2 + tZ);
-    if (hi < 0.0f) {
-        if (LAB == 1) return 2;
-#if DI2P_SOLVER_GUARD_TBZ
-        const float lrs = fminf(fabsf(fL) - tL, fabsf(fR) - tR);
-        *lr_slack = lrs;
-        return lrs > kGuardLrMin ? 5 : 3;      // NaN -> 3
-#else
-        return 3;      // label 0: nothing is active, but an exact zero on an undecided plane must still be found
-#endif
-    }
-    return 1;
+    const bool decided = cm > 0.0f, neg = hi < 0.0f;
+    if (LAB == 1) return decided ? (inside ? 0 : 2) : (neg ? 2 : 1);
+    const float lrs = fminf(fabsf(fL) - tL, fabsf(fR) - tR);
+    *lr_slack = lrs;
+    return decided ? (inside ? 2 : 0) : (neg ? (lrs > kGuardLrMin ? 5 : 3) : 1);      // lrs NaN -> 3
 }
 
 // Wave-wide minima of FOUR non-negative floats (or +inf) at once, by DPP (no LDS round trip): four joins inside rows of 16 lanes, then
@@ -1263,16 +1205,6 @@ __device__ __forceinline__ void wave_min1_nonneg(float& a) {
                  : "+v"(a));
 #undef DI2P_MIN1
     a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
-}
-// old with lane `sel` (wave-uniform) replaced by the wave-uniform value `val`: one v_writelane_b32 per value (ignores the exec mask).  The lane
-// select travels in m0: gfx9 allows ONE scalar register per vector instruction, m0 next to it.
-__device__ __forceinline__ int di2p_writelane(int val, int sel, int old) {
-    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(sel) : "m0");
-    return old;
-}
-__device__ __forceinline__ void di2p_writelane3(int sel, int v0, int v1, int v2, int& o0, int& o1, int& o2) {
-    asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0"
-                 : "+v"(o0), "+v"(o1), "+v"(o2) : "s"(sel), "s"(v0), "s"(v1), "s"(v2) : "m0");
 }
 template <int N> __device__ __forceinline__ void wave_min_nonneg(float* v) {
     static_assert(N == 1 || N == 2 || N == 4, "batch sizes of the cluster walk");
@@ -1384,13 +1316,10 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
     CacheEnt* cache_w = cache + wave * ((nc + WPH - 1) / WPH);      // the wave's entries are consecutive: lane j <-> its j-th cluster
     constexpr int PF = DI2P_SOLVER_PF;
     auto take_bit = [](unsigned long long& m) { int b = -1; if (m) { b = (int)__builtin_ctzll(m); m &= m - 1; } return b; };
-    const unsigned bit_lo = lane < 32 ? 1u << lane : 0u, bit_hi = lane >= 32 ? 1u << (lane - 32) : 0u;
     const int nv_last = cnt - (nc - 1) * CL;                 // valid records of the block's last cluster (scalar), 1..CL
     const unsigned long long tail_mask = nv_last >= CL ? ~0ull : ((1ull << (nv_last & 63)) - 1ull);
     const unsigned tail_lo = (unsigned)tail_mask, tail_hi = (unsigned)(tail_mask >> 32);
-#if DI2P_SOLVER_EXEC_APPEND
     const unsigned queue_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int*)queue;      // LDS byte address of the wave's queue
-#endif
     for (int j0 = 0; j0 < mine; j0 += 64) {
         const long long ts0 = PROFILE ? clock64() : 0;
         const int j = j0 + lane;
@@ -1399,18 +1328,15 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
         float slack = 0.0f;               // min slack of the lane's cluster (phase I)
         float lr_slack = 0.0f;            // status 5: the box's clearance of the left / right planes
         bool cached_guard = false;
-        // DI2P_SOLVER_BOXMS: the margin m S of the per-point tests of the lane's cluster, from its box (|x|_1 <= |c|_1 + |h|_1 for every point of it: a
-        // margin that is never smaller than the point's own -- more points fall to the exact test, none is certified wrongly); +inf switches the
+        // the margin m S of the per-point tests of the lane's cluster, from its box (|x|_1 <= |c|_1 + |h|_1 for every point of it: a margin
+        // that is never smaller than the point's own -- more points fall to the exact test, none is certified wrongly); +inf switches the
         // fp32 tests off (solver_noprefilter), NaN (a poisoned box) certifies nothing
         float ms_box = 0.0f;
         if (j < mine) {
             const int c = j * WPH + wave;
             const Box bx = boxes[c];           // (solver_nocull needs it for the margin only)
-#if DI2P_SOLVER_BOXMS
             ms_box = use_pre ? kPreRel * (((fabsf(bx.cx) + fabsf(bx.cy)) + (fabsf(bx.cz) + pre.T1)) + ((bx.hx + bx.hy) + bx.hz)) : __builtin_inff();
-#endif
-#if DI2P_SOLVER_FLATROUND
-            {
+            {   // box test + cache look-up of every lane, as SELECTS (round 6: the nested divergent form ran every path anyway)
                 // the table is wave-uniform and only needed here (<= 2 rounds per label block): fetched from LDS per round instead of
                 // staying in VGPRs through the cluster walk
                 BoxAbs ab;
@@ -1454,58 +1380,9 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                     cache_w[j] = ne;
                 }
             }
-#else
-            if (nocull) {
-                status = 1;
-            } else {
-                // the table is wave-uniform and only needed here (<= 2 rounds per label block): fetched from LDS per round instead of
-                // staying in VGPRs through the cluster walk
-                BoxAbs ab;
-                asm volatile("" ::: "memory");
-                const float4* bt4 = reinterpret_cast<const float4*>(btest_lds);
-                float4* dst4 = reinterpret_cast<float4*>(&ab);
-#pragma unroll
-                for (int i = 0; i < (int)(sizeof(BoxAbs) / 16); ++i) dst4[i] = bt4[i];
-                CacheEnt e;                                     // fetched together with the box, whatever the box test will say
-                e.mlo = e.mhi = 0u; e.slack = 0.0f; e.stamp = 0u;
-                if (use_cache) e = cache_w[j];
-                status = cluster_status<NP, LAB>(bx, pre, ab, &lr_slack);
-                if (use_cache && (status == 1 || status == 3 || status == 5)) {
-                    const unsigned age = (unsigned)s_now + 1u - e.stamp;               // e.stamp <= s_now + 1
-                    const double* xr = ring + ((e.stamp - 1u) & (unsigned)(RING - 1)) * NP;
-                    float mu;
-                    if (NP == 4) {
-                        const double dth = fabs(x[0] - xr[0]);
-                        const double dt = fmax(fmax(fabs(x[1] - xr[1]), fabs(x[2] - xr[2])), fabs(x[3] - xr[3]));
-                        mu = fmaf((float)dth, bx.rxz, (float)dt);
-                    } else {
-                        const double dth = (fabs(x[0] - xr[0]) + fabs(x[1] - xr[1])) + fabs(x[2] - xr[2]);     // >= |d w|_2
-                        const double dt = fmax(fmax(fabs(x[3] - xr[3]), fabs(x[4] - xr[4])), fabs(x[5] - xr[5]));
-                        mu = fmaf((float)dth, bx.r3, (float)dt);
-                    }
-                    const float need = fmaf(1.0001f, mu, 1e-6f);
-                    if (e.stamp != 0u && age < (unsigned)RING && e.slack > need) {       // NaN fails
-                        cached_guard = status == 3 || status == 5;
-                        status = cached_guard ? 0 : 4;
-                        mlo = e.mlo; mhi = e.mhi;
-                        if (age >= (unsigned)(RING / 2)) {
-                            // still valid but about to leave the ring: re-record against THIS iterate with what is left of the slack
-                            CacheEnt ne;
-                            ne.mlo = e.mlo; ne.mhi = e.mhi; ne.slack = (e.slack - need) * 0.99999f; ne.stamp = (unsigned)s_now + 1u;
-                            cache_w[j] = ne;
-                        }
-                    }
-                }
-            }
-            if (status == 2) {       // all active: the cluster's valid records -- all 64 but for the block's last cluster (its mask is wave-uniform)
-                const bool last = c == nc - 1;
-                mlo = last ? tail_lo : ~0u;
-                mhi = last ? tail_hi : ~0u;
-            }
-#endif
         }
         const unsigned long long mA = __ballot(status == 1), mB = __ballot(status == 2), mC = __ballot(status == 3), mD = __ballot(status == 4);
-        const unsigned long long mE = DI2P_SOLVER_GUARD_TBZ ? __ballot(status == 5) : 0ull;
+        const unsigned long long mE = __ballot(status == 5);
         if (PROFILE) {
             n_active[1] += __popcll(mA); n_active[2] += __popcll(mB); n_active[3] += __popcll(mC | mE);
             n_active[4] += __popcll(mD); n_active[5] += __popcll(__ballot(cached_guard));
@@ -1532,60 +1409,35 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                 for (int u = 0; u < PF; ++u) {
                     cur[u] = ring_r[u];
                     nbp[u] = nb[u];
-#if !DI2P_SOLVER_NOVALID
-                    const bool valid = nb[u] >= 0 && ((j0 + nb[u]) * WPH + wave) * CL + lane < cnt;      // exhausted slots / padding lanes
-#endif
                     nb[u] = take_bit(mg);
                     ring_r[u] = load_rec((j0 + nb[u]) * WPH + wave);
                     float sl;
-#if DI2P_SOLVER_BOXMS
                     const float msu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ms_box), nbp[u]));
-#else
-                    const float msu = -1.0f;
-#endif
                     if (TBZ) {
                         sl = guard32_tbz<NP>(pre, (float)cur[u].x, (float)cur[u].y, (float)cur[u].z, msu);
                     } else {
                         bool a;
-                        prefilter32<NP, 0>(pre, (float)cur[u].x, (float)cur[u].y, (float)cur[u].z, a, sl, msu);
+                        prefilter32<NP, 0>(pre, (float)cur[u].x, (float)cur[u].y, (float)cur[u].z, msu, a, sl);
                     }
-#if DI2P_SOLVER_BOXMS
                     sl = __builtin_fmaxf(sl, 0.0f);                             // not certified (<= 0, or NaN: v_max returns the other operand) -> 0
-#else
-                    sl = (use_pre && sl > 0.0f) ? sl : 0.0f;                    // not certified (or NaN) -> 0
-#endif
-#if DI2P_SOLVER_NOVALID
                     // no lane mask: the padding lanes of a block's last cluster hold COPIES of its last record (prepare_kernel), so they change
                     // neither the minimum nor the verdict of the exact test; the value of an exhausted slot (nbp < 0) is never used
                     sm[u] = sl;
-#else
-                    sm[u] = valid ? sl : __builtin_inff();
-#endif
                 }
                 wave_min_nonneg<PF>(sm);
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
                     if (nbp[u] >= 0) {              // wave-uniform
-                        if (!(sm[u] > 0.0f)) {      // rare: some record the fp32 guard cannot certify -> exact test of this cluster
-#if DI2P_SOLVER_NOVALID
-                            (void)exact_active(cur[u], true);                      // sets `bad` on a zero
-#else
-                            const int c = (j0 + nbp[u]) * WPH + wave;
-                            (void)exact_active(cur[u], c * CL + lane < cnt);       // sets `bad` on a zero
-#endif
-                        }
-                        // into the lane that owns the cluster
-#if DI2P_SOLVER_WRITELANE
-                        slack = __builtin_bit_cast(float, di2p_writelane(__builtin_bit_cast(int, sm[u]), nbp[u], __builtin_bit_cast(int, slack)));
-#else
-                        slack = lane == nbp[u] ? sm[u] : slack;
-#endif
+                        if (!(sm[u] > 0.0f)) (void)exact_active(cur[u], true);      // rare: some record the fp32 guard cannot certify -> exact test of this cluster (sets `bad` on a zero)
+                        slack = lane == nbp[u] ? sm[u] : slack;                    // into the lane that owns the cluster
                     }
                 }
             }
         };
+        // Round 6: three of four guard-only clusters of the config-2 workload clear the left / right planes by their box (the band beside the
+        // camera, |p2| small): their guard needs the top / bottom / z planes only (28 instead of 36 vector instructions per cluster)
         if (LAB == 0 && mC) guard_walk(std::false_type(), mC);
-        if (DI2P_SOLVER_GUARD_TBZ && LAB == 0 && mE) {
+        if (LAB == 0 && mE) {
             guard_walk(std::true_type(), mE);
             if (status == 5) slack = fminf(slack, lr_slack);       // the box's clearance of the two planes the walk left out (lane-parallel)
         }
@@ -1603,16 +1455,10 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                 int nbp[PFC];
                 bool act[PFC];
                 float sm[PFC];
-#if !DI2P_SOLVER_NOVALID
-                bool valid[PFC];
-#endif
 #pragma unroll
                 for (int u = 0; u < PFC; ++u) {
                     cur[u] = ring_r[u];
                     nbp[u] = nb[u];
-#if !DI2P_SOLVER_NOVALID
-                    valid[u] = nb[u] >= 0 && ((j0 + nb[u]) * WPH + wave) * CL + lane < cnt;
-#endif
                     nb[u] = take_bit(mo);
                     ring_r[u] = load_rec((j0 + nb[u]) * WPH + wave);
                 }
@@ -1620,46 +1466,23 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                 for (int u = 0; u < PFC; ++u) {          // no short circuits: PFC independent, branch-free instruction streams
                     bool a;
                     float sl;
-#if DI2P_SOLVER_BOXMS
                     const float msu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ms_box), nbp[u]));
-                    prefilter32<NP, LAB>(pre, (float)cur[u].x, (float)cur[u].y, (float)cur[u].z, a, sl, msu);
+                    prefilter32<NP, LAB>(pre, (float)cur[u].x, (float)cur[u].y, (float)cur[u].z, msu, a, sl);
                     sl = __builtin_fmaxf(sl, 0.0f);
-#else
-                    prefilter32<NP, LAB>(pre, (float)cur[u].x, (float)cur[u].y, (float)cur[u].z, a, sl);
-                    sl = (use_pre && sl > 0.0f) ? sl : 0.0f;
-#endif
-#if DI2P_SOLVER_NOVALID
                     act[u] = a;           // the padding lanes (copies of the block's last record) are cut from the BALLOT by a scalar mask below
                     sm[u] = sl;
-#else
-                    act[u] = valid[u] & a;
-                    sm[u] = valid[u] ? sl : __builtin_inff();
-#endif
                 }
                 wave_min_nonneg<PFC>(sm);
 #pragma unroll
                 for (int u = 0; u < PFC; ++u) {
                     if (nbp[u] >= 0) {              // wave-uniform
-#if DI2P_SOLVER_NOVALID
                         if (!(sm[u] > 0.0f)) act[u] = exact_active(cur[u], true);        // rare: some record is not certified -> exact test for THAT cluster
                         const int nvr = cnt - ((j0 + nbp[u]) * WPH + wave) * CL;          // valid records of the cluster (scalar), >= 1
                         const unsigned long long bal = __ballot(act[u]) & (nvr >= CL ? ~0ull : ((1ull << nvr) - 1ull));
-#else
-                        if (!(sm[u] > 0.0f)) act[u] = exact_active(cur[u], valid[u]);        // rare: some record is not certified -> exact test for THAT cluster
-                        const unsigned long long bal = __ballot(act[u]);
-#endif
                         // into the lane that owns the cluster
-#if DI2P_SOLVER_WRITELANE
-                        {
-                            int o0 = (int)mlo, o1 = (int)mhi, o2 = __builtin_bit_cast(int, slack);
-                            di2p_writelane3(nbp[u], (int)(unsigned)bal, (int)(unsigned)(bal >> 32), __builtin_bit_cast(int, sm[u]), o0, o1, o2);
-                            mlo = (unsigned)o0; mhi = (unsigned)o1; slack = __builtin_bit_cast(float, o2);
-                        }
-#else
                         mlo = lane == nbp[u] ? (unsigned)bal : mlo;
                         mhi = lane == nbp[u] ? (unsigned)(bal >> 32) : mhi;
                         slack = lane == nbp[u] ? sm[u] : slack;
-#endif
                     }
                 }
             }
@@ -1677,8 +1500,8 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                 mo &= mo - 1;
                 if (qn > QCAP - 64) drain(false);      // queue nearly full: evaluate the full rounds, keep the remainder queued
                 const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)mlo, b), hi = (unsigned)__builtin_amdgcn_readlane((int)mhi, b);
-#if DI2P_SOLVER_EXEC_APPEND
-                {   // the store runs under exec = the cluster's active mask: mbcnt does not depend on exec, so no per-lane bit test is needed
+                {   // the store runs under exec = the cluster's active mask (mbcnt does not depend on exec): no per-lane bit test, the address and
+                    // the id are (scalar) + (lane term) -- 6 instead of 11 vector instructions per appended cluster
                     const unsigned rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
                     const unsigned addr = (queue_addr + 4u * (unsigned)qn) + 4u * rank;              // (scalar) + 4 * rank
                     const unsigned id = (unsigned)(((j0 + b) * WPH + wave) * CL) + (unsigned)lane;   // (scalar) + lane
@@ -1687,10 +1510,6 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                     asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
                                  : "=&s"(saved) : "s"(m64), "v"(addr), "v"(id) : "memory");
                 }
-#else
-                const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-                if (((lo & bit_lo) | (hi & bit_hi)) != 0u) queue[pos] = ((j0 + b) * WPH + wave) * CL + lane;
-#endif
                 qn += __builtin_popcount(lo) + __builtin_popcount(hi);
             }
         }
@@ -1739,7 +1558,7 @@ __device__ __forceinline__ void sweep(const Rec<PT>* __restrict__ recs, const Bo
         for (int i = 1; i < 1 + NP + Tri<NP>::N; ++i) acc[i][lane] = 0.0;
     }
     Pre32 pre;        // fp32 table of the iterate (SGPRs), shared by the cluster test and the per-point pre-filter of both label blocks
-    make_pre32<NP>(rot, x[TOFF], x[TOFF + 1], x[TOFF + 2], k, camf, pre);
+    make_pre32<NP>(rot, x[TOFF], x[TOFF + 1], x[TOFF + 2], camf, pre);
     if (!(nocull & 1)) {   // box-test table of this iterate: every lane computes the same values, lane 0 stores them
         BoxAbs ab;
         make_box_abs(pre, ab);
@@ -2066,16 +1885,15 @@ struct LMState {
     int n_ls_extra, n_ls_late_accept, n_resweep;      // diagnostics: line-search trials beyond the first, accepted ones among them, re-sweeps
 };
 
-// DI2P_SOLVER_LMBATCH: the LM stages fetch the state they work on from LDS IN ONE BATCH into registers (pinned: every load is issued, then one
-// wait) instead of field by field between the arithmetic -- the update runs on one lane, so every LDS round trip it waits for (~100+ cycles
-// under load; the copy loops alone were 14 read -> wait -> write pairs) is a round trip the whole workgroup waits for.  Same operations on
-// the same values: bit-identical.
+// Round 6: the LM stages fetch the state they work on from LDS IN ONE BATCH into registers (pinned: every load is issued, then one wait)
+// instead of field by field between the arithmetic -- the update runs on one lane, so every LDS round trip it waits for (the copy loops
+// alone were 14 read -> wait -> write pairs) is a round trip the whole workgroup waits for.  Same operations on the same values:
+// bit-identical; finish + begin 8.5 k -> 7.5 k cycles per iteration (profiles/r06_c6_prepare.txt), no more scratch.
 template <int N> __device__ __forceinline__ void pin_regs(double* v) {
 #pragma unroll
     for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
 }
 
-#if DI2P_SOLVER_LMBATCH
 template <int NP>
 __device__ __forceinline__ void lm_begin_iteration(LMState<NP>& st) {
     constexpr int NT = Tri<NP>::N;
@@ -2148,62 +1966,6 @@ __device__ __forceinline__ void lm_begin_iteration(LMState<NP>& st) {
         return;   // needs a sweep at xe
     }
 }
-#else
-template <int NP>
-__device__ __forceinline__ void lm_begin_iteration(LMState<NP>& st) {
-    constexpr int NT = Tri<NP>::N;
-    const double kMinDiag = 1e-6, kMaxDiag = 1e32, kMinRadius = 1e-32, kGradTol = 1e-10;
-    for (;;) {
-        if (st.iter >= st.max_iter || st.gmax <= kGradTol || st.radius <= kMinRadius) { st.done = 1; return; }
-        ++st.iter;
-        // scaled system (S A S + D^2) ds = -S g.  The scaled matrix S A S is needed twice (the system, the model change) and is
-        // RECOMPUTED from the LDS-resident A and S the second time (same expression, same bits) instead of being kept in registers.
-        double M[NT], ds[NP];
-        auto scaled_A = [&](int a, int b) { const int hi = a >= b ? a : b, lo = a >= b ? b : a; return st.S[hi] * st.A[hi * (hi + 1) / 2 + lo] * st.S[lo]; };
-#pragma unroll
-        for (int a = 0; a < NP; ++a)
-#pragma unroll
-            for (int b = 0; b <= a; ++b) M[a * (a + 1) / 2 + b] = scaled_A(a, b);
-        if (!st.reuse_diag)
-#pragma unroll
-            for (int a = 0; a < NP; ++a) st.diag[a] = fmin(fmax(M[a * (a + 1) / 2 + a], kMinDiag), kMaxDiag);
-#pragma unroll
-        for (int a = 0; a < NP; ++a) { M[a * (a + 1) / 2 + a] += lm_div(st.diag[a], st.radius); ds[a] = -(st.S[a] * st.g[a]); }
-        bool valid = chol_solve_inplace<NP>(M, ds);
-        double model_change = 0.0;
-        if (valid) {
-            double q = 0.0, l = 0.0;
-#pragma unroll
-            for (int a = 0; a < NP; ++a) {
-                l += ds[a] * (st.S[a] * st.g[a]);
-#pragma unroll
-                for (int b = 0; b < NP; ++b) q += ds[a] * scaled_A(a, b) * ds[b];
-            }
-            model_change = -(l + 0.5 * q);
-            valid = model_change > 0.0;
-        }
-        if (!valid) {
-            if (++st.invalid_run >= 5) { st.done = 1; return; }
-            st.radius /= st.decrease; st.decrease *= 2.0; st.reuse_diag = 1;
-            continue;
-        }
-        st.invalid_run = 0;
-        st.model_change = model_change;
-        double gd = 0.0, dmax = 0.0;
-#pragma unroll
-        for (int a = 0; a < NP; ++a) {
-            st.delta[a] = ds[a] * st.S[a];
-            gd += st.g[a] * st.delta[a];
-            dmax = fmax(dmax, fabs(st.delta[a]));
-        }
-        st.gd = gd; st.dmax = dmax; st.t = 1.0; st.ls_it = 0;
-        plus_proj<NP>(st.x, st.delta, 1.0, st.lb, st.ub, st.xe);
-        st.phase = PH_TRIAL; st.want_j = 2; st.prev_vok = 0; st.prev_gok = 0;
-        return;   // needs a sweep at xe
-    }
-}
-
-#endif
 
 // The LM update is a chain of STAGES, each instantiated exactly once in the kernel (lm_decide -> [wave-wide minimiser] ->
 // lm_trial_next_decide -> lm_apply = {lm_finish_iteration, lm_begin_iteration}); a stage hands the next one an action code.  (As
@@ -2212,7 +1974,6 @@ __device__ __forceinline__ void lm_begin_iteration(LMState<NP>& st) {
 enum { ACT_NONE = 0, ACT_BEGIN = 1, ACT_FINISH_CUR = 2, ACT_FINISH_FIRST = 3, ACT_TRIAL_NEXT = 4, ACT_POLY = 5 };
 
 // candidate (xe, cand_cost, ge, Ae) against the current iterate: tolerance tests, accept / reject.  -> true: start the next iteration
-#if DI2P_SOLVER_LMBATCH
 template <int NP>
 __device__ __forceinline__ bool lm_finish_iteration(LMState<NP>& st, double cand_cost, const double* ge, const double* Ae) {
     constexpr int NT = Tri<NP>::N;
@@ -2246,34 +2007,6 @@ __device__ __forceinline__ bool lm_finish_iteration(LMState<NP>& st, double cand
     }
     return true;
 }
-#else
-template <int NP>
-__device__ __forceinline__ bool lm_finish_iteration(LMState<NP>& st, double cand_cost, const double* ge, const double* Ae) {
-    const double kMaxRadius = 1e16, kMinRelDec = 1e-3, kFuncTol = 1e-6, kParamTol = 1e-8;
-    double step_norm = 0.0, x_norm = 0.0;
-#pragma unroll
-    for (int a = 0; a < NP; ++a) { step_norm += (st.x[a] - st.xe[a]) * (st.x[a] - st.xe[a]); x_norm += st.x[a] * st.x[a]; }
-    step_norm = lm_sqrt(step_norm); x_norm = lm_sqrt(x_norm);
-    if (step_norm <= kParamTol * (x_norm + kParamTol)) { st.done = 1; return false; }
-    if (fabs(st.cost - cand_cost) <= kFuncTol * st.cost) { st.done = 1; return false; }
-    const double rel = lm_div(st.cost - cand_cost, st.model_change);
-    if (rel > kMinRelDec) {
-#pragma unroll
-        for (int a = 0; a < NP; ++a) { st.x[a] = st.xe[a]; st.g[a] = ge[a]; }
-#pragma unroll
-        for (int i = 0; i < Tri<NP>::N; ++i) st.A[i] = Ae[i];
-        st.cost = cand_cost;
-        st.gmax = grad_max_norm<NP>(st.x, st.g, st.lb, st.ub);
-        const double w = 2.0 * rel - 1.0;
-        st.radius = fmin(kMaxRadius, lm_div(st.radius, fmax(1.0 / 3.0, 1.0 - w * w * w)));
-        st.decrease = 2.0; st.reuse_diag = 0;
-    } else {
-        st.radius /= st.decrease; st.decrease *= 2.0; st.reuse_diag = 1;
-    }
-    return true;
-}
-
-#endif
 
 // Second half of a failed line-search trial: the next step size st.tn is known.  -> ACT_FINISH_FIRST when the search gives up
 // (the candidate is then the first trial point, whose sums were kept), ACT_NONE when the next sweep evaluates the new trial point.
@@ -2312,17 +2045,12 @@ __device__ __forceinline__ void lm_poly_wave(LMState<NP>& st) {
 // First stage, called by thread 0 after every sweep with the combined sums of the point just evaluated (st.xe).  -> action code
 template <int NP>
 __device__ __forceinline__ int lm_decide(LMState<NP>& st, bool ok, double fe, const double* ge_in, const double* Ae_in) {
-#if DI2P_SOLVER_LMBATCH
-    double ge[NP], Ae[Tri<NP>::N];       // the combined sums, fetched in one batch (the copies below were read -> wait -> write pairs)
+    double ge[NP], Ae[Tri<NP>::N];       // the combined sums, fetched in one batch (copied field by field they were read -> wait -> write pairs)
 #pragma unroll
     for (int a = 0; a < NP; ++a) ge[a] = ge_in[a];
 #pragma unroll
     for (int i = 0; i < Tri<NP>::N; ++i) Ae[i] = Ae_in[i];
     pin_regs<NP>(ge); pin_regs<Tri<NP>::N>(Ae);
-#else
-    const double* ge = ge_in;
-    const double* Ae = Ae_in;
-#endif
     ++st.nsweep;
     if (st.phase == PH_INIT) {
         st.cost = fe;
@@ -2469,12 +2197,10 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
 #pragma unroll
         for (int i = 0; i < NP; ++i) xe[i] = st.xe[i];
         const int s_now = st.nsweep - s_base;
-        // The wave that advances the LM state after THIS sweep.  The waves of a workgroup are placed round-robin on the four SIMDs of a compute
-        // unit, so with four-wave workgroups wave 0 of every resident workgroup shares ONE SIMD: with the LM update always on wave 0 that SIMD
-        // carries all of the compute unit's single-lane LM code on top of its share of the sweeps while the other three idle at the barrier.
-        // Rotating the LM wave with the sweep number spreads it (the state lives in LDS: any wave can advance it; same operations, same bits).
-        const int lm_wave = (DI2P_SOLVER_LMROT && !PROFILE) ? (int)((unsigned)st.nsweep % (unsigned)WPH) : 0;
-        const bool lm_wave_here = (int)(threadIdx.x >> 6) == lm_wave;
+        // The LM state is advanced by wave 0.  (Round 6 measured rotating that wave with the sweep number -- the waves of a workgroup sit on
+        // the four SIMDs of a compute unit, so wave 0 of every resident workgroup shares one SIMD: bit-identical, and 1-1.5 % SLOWER both alone
+        // and in the pipeline, profiles/r06_c4 / c5: not adopted.)
+        const bool lm_wave_here = threadIdx.x < 64;
         const int lm_lane = (int)(threadIdx.x & 63);
         // the camera is re-read (scalar loads, cache hits) at the head of every sweep through a laundered pointer: hoisted out of the sweep
         // loop its twelve dwords were kept in VGPRs and SPILLED (nine scratch reloads per sweep)
