@@ -1925,7 +1925,13 @@ __device__ __forceinline__ void lm_begin_iteration(LMState<NP>& st) {
         }
 #pragma unroll
         for (int a = 0; a < NP; ++a) { M[a * (a + 1) / 2 + a] += lm_div(diag[a], radius); ds[a] = -(S[a] * g[a]); }
+#ifdef DI2P_SOLVER_LMPROF
+        const long long tc0 = clock64();
+#endif
         bool valid = chol_solve_inplace<NP>(M, ds);
+#ifdef DI2P_SOLVER_LMPROF
+        st.n_resweep += (int)(clock64() - tc0);
+#endif
         double model_change = 0.0;
         if (valid) {
             double q = 0.0, l = 0.0;
@@ -2173,7 +2179,7 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
         for (int i = 0; i < NP; ++i) { st.x[i] = fmin(fmax(st.x[i], st.lb[i]), st.ub[i]); st.xe[i] = st.x[i]; sh.ring[0][i] = st.x[i]; }
         st.radius = 1e4; st.decrease = 2.0; st.reuse_diag = 0; st.invalid_run = 0; st.iter = 0; st.nsweep = 0;
         st.phase = PH_INIT; st.done = 0; st.max_iter = a->max_iter; st.cost = 0.0; st.gmax = 0.0;
-        st.n_ls_extra = 0; st.n_ls_late_accept = 0; st.n_resweep = 0; st.want_j = 2; st.poly_req = 0;
+        st.n_ls_extra = 0; st.n_ls_late_accept = 0; st.n_resweep = 0; st.pad_ = 0; st.want_j = 2; st.poly_req = 0;
     }
     __syncthreads();
     long long c_sweep = 0, c_wait = 0, c_lm = 0, c_comb = 0;
@@ -2261,7 +2267,13 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
             double xn[NP];
 #pragma unroll
             for (int i = 0; i < NP; ++i) { xn[i] = st.xe[i]; sh.ring[slot][i] = xn[i]; }
+#ifdef DI2P_SOLVER_LMPROF
+            const long long tr0 = clock64();
+#endif
             if (NP == 4 && !st.done) { Rot<NP> r0; make_rot<NP>(xn, r0); sh.rot_cs[0] = r0.R[0]; sh.rot_cs[1] = r0.R[2]; }
+#ifdef DI2P_SOLVER_LMPROF
+            st.pad_ += (int)(clock64() - tr0);
+#endif
         }
         const long long t3 = PROFILE ? clock64() : 0;
         c_comb += t2b - t2; c_decide += t2c - t2b; c_poly += t2d - t2c; c_apply += t3 - t2d;
@@ -2285,7 +2297,7 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
         long long v[PROF_WORDS] = {c_sweep, c_wait, c_lm, n_act[0], n_act[1], n_act[2], c_comb,
                            (long long)st.n_ls_extra | ((long long)st.n_ls_late_accept << 20) | ((long long)st.n_resweep << 40),
                            c_decide, c_poly, c_apply, n_act[3], tp[0], tp[1], tp[2], tp[3], n_act[4], n_act[5],
-                           n_act[6], n_act[7], n_act[8], n_act[9], n_act[10], n_act[11], n_act[12], 0, 0, 0};
+                           n_act[6], n_act[7], n_act[8], n_act[9], n_act[10], n_act[11], n_act[12], (long long)st.pad_, 0, 0};
         for (int i = 0; i < PROF_WORDS; ++i) prof[i] = (a->resume && i != 7 ? prof[i] : 0) + v[i];
     }
     if (threadIdx.x == 0 && st.done) {

@@ -68,6 +68,8 @@ for name, lab_np in (("noisy-gt", np.stack([f["labels"] for f in frames])),):
         q = prof.cpu().numpy().reshape(-1, PW)[:, 7]
         print("  line search: extra trials %.1f / hyp, of which accepted %.1f, re-sweeps %.1f (iterations %.1f, sweeps %.1f)" % (
             (q & 0xfffff).mean(), ((q >> 20) & 0xfffff).mean(), (q >> 40).mean(), iters.float().mean().item(), sw.mean()))
+        if os.environ.get("LMPROF"):       # variant build -DDI2P_SOLVER_LMPROF: cycles of the Cholesky solves (packed where the re-sweep count was) and of the sincos
+            print("  LM detail (cycles per sweep): Cholesky solves %.0f  sincos of the next iterate %.0f" % (((q >> 40) / sw).mean(), (p[:, 25] / sw).mean()))
         X = np.stack([iters.cpu().numpy().reshape(-1).astype(float), (q & 0xfffff).astype(float), np.ones(sw.size)], axis=1)
         coef = np.linalg.lstsq(X, p[:, 2], rcond=None)[0]
         print("  LM cycles per hypothesis ~ %.0f x iterations + %.0f x extra line-search trials + %.0f" % tuple(coef))
