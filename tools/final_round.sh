@@ -6,7 +6,7 @@
 #                                         kernel-trace statistics;   then:  python tools/make_profiles.py <tag>
 # The bench line is produced AFTER the counter files it quotes.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 STAGE=${2:-bench}
 OUT=gpurun_out
 mkdir -p $OUT
@@ -30,12 +30,12 @@ timeout 200 python bench.py --mode train --steps 6 --warmup 2 > $OUT/${TAG}_trai
 timeout 100 python tools/bench_index_max.py > $OUT/${TAG}_index_max_cold.txt 2>&1
 timeout 300 python tools/bench_conv_x3.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_conv_layers.txt
 timeout 100 python tools/diag_conv_x3_accuracy.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_conv_x3_accuracy.txt
-tools/bin/probe_mfma_rounding > $OUT/${TAG}_mfma_rounding.txt 2>&1
+(/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/probe_mfma_rounding.hip -o /tmp/probe_mfma_rounding 2>/dev/null && /tmp/probe_mfma_rounding) > $OUT/${TAG}_mfma_rounding.txt 2>&1
 ROUNDS=3 REPS=50 timeout 200 python tools/bench_head_x3.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_head_x3.txt
 REPS=50 timeout 100 python tools/bench_stem_x3.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_stem_x3.txt
 timeout 100 python tools/probe_x3_ranges.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_x3_ranges.txt
 timeout 150 python tools/bench_winograd.py > $OUT/${TAG}_winograd_layers.txt 2>&1
-PROF=1 timeout 150 python tools/bench_solver.py > $OUT/${TAG}_solver_phases.txt 2>&1
+PROF=1 PFC=2 timeout 150 python tools/bench_solver.py > $OUT/${TAG}_solver_phases.txt 2>&1
 bash tools/profile_round.sh $TAG stats > $OUT/${TAG}_profile_round.log 2>&1
 timeout 200 python tools/call_times.py 15 > $OUT/${TAG}_call_times.txt 2>&1
 timeout 200 bash tools/sweep_streams2.sh > $OUT/${TAG}_sweep_streams.txt 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Hardware counters of the pose-solver kernel (GPU box; separate --pmc passes, kernel-trace only):  tools/prof_solver_counters.sh r03
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp

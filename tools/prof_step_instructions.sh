@@ -2,7 +2,7 @@
 # Wave-instruction counts of every kernel of one 32-frame step (GPU box; --pmc passes with kernel-trace only): how much VALU issue time
 # and how much matrix-pipe time a step needs in total, next to the measured 8-stream step time.   tools/prof_step_instructions.sh r03
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp

@@ -4,7 +4,7 @@
 # Writes gpurun_out/<tag>_*.csv (kernel-trace statistics of the bench command, default streams ("pipelined") and serial; separate --pmc passes
 # for the solver and index_max -- counters are never combined with other trace domains).  Copy what should be judged into profiles/.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 WHAT=${2:-all}          # stats | pmc | all
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
