@@ -109,6 +109,9 @@ if sc:
                  100 * sc["SQ_ACTIVE_INST_ANY"] / sc["SQ_WAVE_CYCLES"], sc["TCC_HIT_sum"] / (sc["TCC_HIT_sum"] + sc["TCC_MISS_sum"]), sc["FETCH_SIZE"] / 1024, sc["WRITE_SIZE"] / 1024))
 wino_counters_txt = ("* `%s_winograd_counters.txt` -- `tools/prof_winograd.sh`: SQ / TA / TCP / TCC counters of `wino_conv_kernel` on the stage-3 shape.\n" % TAG
                      if os.path.exists(P + TAG + "_winograd_counters.txt") else "")
+extra_txt = ""
+if os.path.exists(P + TAG + "_EXTRA.md"):        # the round's A/B calls (tools/oneoff/<tag>_call*.sh), described by hand
+    extra_txt = open(P + TAG + "_EXTRA.md").read().rstrip() + "\n"
 txt = f"""# Round-{RN} profiles (1x MI355X, ROCm 7.2)
 
 Everything here was produced by ONE gpurun call of `tools/final_round.sh {TAG}` (GPU tests, `bench.py`, `bench.py --mode train`, the
@@ -165,7 +168,7 @@ files listed in KEEP_OLD (if present) come from earlier calls of the round.
 ```
 {wino_counters_txt}* `{TAG}_solver_phases.txt` -- `PROF=1 python tools/bench_solver.py`: clock64() phase counters, cluster / line-search statistics, sweep-count
   percentiles.
-{sc_txt}* `{TAG}_call_times.txt` -- `tools/call_times.py`: HIP events around every C-ABI call of one serial step, with the contraction shapes.
+{sc_txt}{extra_txt}* `{TAG}_call_times.txt` -- `tools/call_times.py`: HIP events around every C-ABI call of one serial step, with the contraction shapes.
 * `{TAG}_sweep_streams.txt` -- the headline against streams / hardware queues.
 * `{TAG}_step_instructions.txt` -- `tools/prof_step_instructions.sh`: VALU / MFMA / SALU / LDS wave-instruction counters of every kernel of a step
   (what the 8-stream step time is bounded by: DESIGN.md section 4).
