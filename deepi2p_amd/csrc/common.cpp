@@ -38,7 +38,7 @@ const OptDef kOpts[DI2P_OPT_COUNT] = {
     {"head_reg", "DI2P_HEAD_REG", 0},               {"conv_s2scalar", "DI2P_CONV_S2SCALAR", 0},
     {"conv_x3", "DI2P_CONV_X3", 31},                 {"conv_x3_cfg", "DI2P_CONV_X3_CFG", -1},
     {"head_x3", "DI2P_HEAD_X3", 1},                 {"head_x3_tab", "DI2P_HEAD_X3_TAB", 1},
-    {"stem_x3", "DI2P_STEM_X3", 1},
+    {"stem_x3", "DI2P_STEM_X3", 1},                 {"bn_unfused", "DI2P_BN_UNFUSED", 0},
 };
 long long g_opt[DI2P_OPT_COUNT];
 std::once_flag g_opt_once;

@@ -438,6 +438,74 @@ __global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __r
     if (dres) dres[i] = g;
 }
 
+// Round 6: finalize + elementwise pass as ONE launch per direction (55 BatchNorm layers x 2 directions x a 64-thread finalize launch per step:
+// 0.5 ms of kernels and as much again in launch gaps).  Grid (C, S) like the reduction: block (c, s) first forms the channel's statistics from
+// the S fp64 partial pairs ON ONE THREAD IN THE FINALIZE KERNEL'S ORDER (the same sums, the same bits, whichever block forms them; block s == 0
+// also writes them out / updates the running buffers), then streams its chunk of row (b, c) with the elementwise kernel's expression.
+__global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ res, float* __restrict__ y, const double* __restrict__ partial,
+                                                                int S, double count, float eps, float momentum, float* __restrict__ save_mean,
+                                                                float* __restrict__ save_invstd, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                                int relu, int C, int N, int SN, int per) {
+    __shared__ float s_stat[2];
+    const int c = blockIdx.x, s = blockIdx.y, b = s / SN, ch = s - b * SN;
+    if (threadIdx.x == 0) {
+        double a0 = 0.0, a1 = 0.0;
+        for (int q = 0; q < S; ++q) { a0 += partial[((long long)c * S + q) * 2]; a1 += partial[((long long)c * S + q) * 2 + 1]; }
+        const double mu = a0 / count;
+        double var = a1 / count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float fm = (float)mu, fi = (float)(1.0 / sqrt(var + (double)eps));
+        s_stat[0] = fm; s_stat[1] = fi;
+        if (s == 0) {
+            save_mean[c] = fm;
+            save_invstd[c] = fi;
+            if (run_mean) {
+                const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+                run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mu);
+                run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unb);
+            }
+        }
+    }
+    __syncthreads();
+    const float mean = s_stat[0], invstd = s_stat[1], g = gamma[c], be = beta[c];
+    const long long row = ((long long)b * C + c) * N;
+    const int n0 = ch * per, n1 = min(N, n0 + per);
+    for (int n = n0 + threadIdx.x; n < n1; n += 256) {
+        float v = (x[row + n] - mean) * invstd * g + be;
+        if (res) v += res[row + n];
+        if (relu) v = fmaxf(v, 0.0f);
+        y[row + n] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_backward_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ mean_,
+                                                                   const float* __restrict__ invstd_, const double* __restrict__ partial, int S, double count,
+                                                                   int relu, float* __restrict__ dx, float* __restrict__ dres, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta, int C, int N, int SN, int per) {
+    __shared__ float s_sum[2];
+    const int c = blockIdx.x, s = blockIdx.y, b = s / SN, ch = s - b * SN;
+    if (threadIdx.x == 0) {
+        double a0 = 0.0, a1 = 0.0;
+        for (int q = 0; q < S; ++q) { a0 += partial[((long long)c * S + q) * 2]; a1 += partial[((long long)c * S + q) * 2 + 1]; }
+        s_sum[0] = (float)(a0 / count);
+        s_sum[1] = (float)(a1 / count);
+        if (s == 0) { dgamma[c] = (float)a1; dbeta[c] = (float)a0; }
+    }
+    __syncthreads();
+    const float m0 = s_sum[0], m1 = s_sum[1], mean = mean_[c], invstd = invstd_[c], gm = gamma[c];
+    const long long row = ((long long)b * C + c) * N;
+    const int n0 = ch * per, n1 = min(N, n0 + per);
+    for (int n = n0 + threadIdx.x; n < n1; n += 256) {
+        float g = dy[row + n];
+        if (relu && !(y[row + n] > 0.0f)) g = 0.0f;
+        const float xh = (x[row + n] - mean) * invstd;
+        dx[row + n] = gm * invstd * (g - m0 - xh * m1);
+        if (dres) dres[row + n] = g;
+    }
+}
+
 struct RedPlan { int SN, per, S; long long bytes; };
 RedPlan red_plan(int B, int C, int N) {
     RedPlan p;
@@ -541,11 +609,16 @@ extern "C" int di2p_bn_train_forward(const float* x, const float* gamma, const f
     double* part = (double*)workspace;
     hipLaunchKernelGGL((channel_reduce_kernel<0>), dim3(C, p.S), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, 0, C, N, p.SN, p.per, part);
-    hipLaunchKernelGGL((channel_finalize_kernel<0>), dim3(di2p_cdiv(C, 64)), dim3(64), 0, st, (const double*)part, p.S, C, (double)B * N, eps, momentum,
-                       save_mean, save_invstd, running_mean, running_var, (float*)nullptr);
-    const long long total = (long long)B * C * N;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(di2p_cdiv(total, 256)), dim3(256), 0, st, x, gamma, beta, (const float*)save_mean, (const float*)save_invstd,
-                       residual, y, relu, C, N, total);
+    if (di2p_opt(DI2P_OPT_BN_UNFUSED)) {          // rounds 2-5: finalize and the elementwise pass as two launches (same results)
+        hipLaunchKernelGGL((channel_finalize_kernel<0>), dim3(di2p_cdiv(C, 64)), dim3(64), 0, st, (const double*)part, p.S, C, (double)B * N, eps, momentum,
+                           save_mean, save_invstd, running_mean, running_var, (float*)nullptr);
+        const long long total = (long long)B * C * N;
+        hipLaunchKernelGGL(bn_apply_kernel, dim3(di2p_cdiv(total, 256)), dim3(256), 0, st, x, gamma, beta, (const float*)save_mean, (const float*)save_invstd,
+                           residual, y, relu, C, N, total);
+    } else {
+        hipLaunchKernelGGL(bn_finalize_apply_kernel, dim3(C, p.S), dim3(256), 0, st, x, gamma, beta, residual, y, (const double*)part, p.S, (double)B * N, eps,
+                           momentum, save_mean, save_invstd, running_mean, running_var, relu, C, N, p.SN, p.per);
+    }
     DI2P_RETURN_LAUNCH();
 }
 
@@ -560,11 +633,16 @@ extern "C" int di2p_bn_train_backward(const float* x, const float* y, const floa
     double* part = (double*)workspace;
     float* sums = (float*)((char*)workspace + (long long)C * p.S * 16);
     hipLaunchKernelGGL((channel_reduce_kernel<1>), dim3(C, p.S), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, relu, C, N, p.SN, p.per, part);
-    hipLaunchKernelGGL((channel_finalize_kernel<1>), dim3(di2p_cdiv(C, 64)), dim3(64), 0, st, (const double*)part, p.S, C, (double)B * N, 0.0f, 0.0f, dgamma,
-                       dbeta, (float*)nullptr, (float*)nullptr, sums);
-    const long long total = (long long)B * C * N;
-    hipLaunchKernelGGL(bn_backward_apply_kernel, dim3(di2p_cdiv(total, 256)), dim3(256), 0, st, x, dy, y, gamma, save_mean, save_invstd, (const float*)sums,
-                       relu, dx, dresidual, C, N, total);
+    if (di2p_opt(DI2P_OPT_BN_UNFUSED)) {
+        hipLaunchKernelGGL((channel_finalize_kernel<1>), dim3(di2p_cdiv(C, 64)), dim3(64), 0, st, (const double*)part, p.S, C, (double)B * N, 0.0f, 0.0f, dgamma,
+                           dbeta, (float*)nullptr, (float*)nullptr, sums);
+        const long long total = (long long)B * C * N;
+        hipLaunchKernelGGL(bn_backward_apply_kernel, dim3(di2p_cdiv(total, 256)), dim3(256), 0, st, x, dy, y, gamma, save_mean, save_invstd, (const float*)sums,
+                           relu, dx, dresidual, C, N, total);
+    } else {
+        hipLaunchKernelGGL(bn_finalize_backward_kernel, dim3(C, p.S), dim3(256), 0, st, x, dy, y, gamma, save_mean, save_invstd, (const double*)part, p.S,
+                           (double)B * N, relu, dx, dresidual, dgamma, dbeta, C, N, p.SN, p.per);
+    }
     DI2P_RETURN_LAUNCH();
 }
 
