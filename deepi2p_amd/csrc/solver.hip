@@ -1412,7 +1412,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                     nb[u] = take_bit(mg);
                     ring_r[u] = load_rec((j0 + nb[u]) * WPH + wave);
                     float sl;
-                    const float msu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ms_box), nbp[u]));
+                    const float msu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ms_box), nbp[u] & 63));
                     if (TBZ) {
                         sl = guard32_tbz<NP>(pre, (float)cur[u].x, (float)cur[u].y, (float)cur[u].z, msu);
                     } else {
@@ -1466,7 +1466,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                 for (int u = 0; u < PFC; ++u) {          // no short circuits: PFC independent, branch-free instruction streams
                     bool a;
                     float sl;
-                    const float msu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ms_box), nbp[u]));
+                    const float msu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ms_box), nbp[u] & 63));
                     prefilter32<NP, LAB>(pre, (float)cur[u].x, (float)cur[u].y, (float)cur[u].z, msu, a, sl);
                     sl = __builtin_fmaxf(sl, 0.0f);
                     act[u] = a;           // the padding lanes (copies of the block's last record) are cut from the BALLOT by a scalar mask below
@@ -2534,7 +2534,7 @@ int launch_solve(const PT* points, const int* labels, const double* K, const dou
         hipLaunchKernelGGL(prep_bounds_kernel<PT>, dim3(F * PREP_G), dim3(256), 0, st, points, labels, N, pw);
         hipLaunchKernelGGL(prep_hist_kernel<PT>, dim3(F * PREP_G), dim3(256), 0, st, points, labels, N, ws.P, keys, pw);
         hipLaunchKernelGGL(prep_scatter_kernel, dim3(F * PREP_G), dim3(1024), 0, st, N, ws.P, keys, pw);
-        hipLaunchKernelGGL(prep_rank_kernel, dim3((N + 255) / 256, F), dim3(256), 0, st, ws.P, keys, pw);
+        hipLaunchKernelGGL(prep_rank_kernel, dim3(N > 0 ? (N + 255) / 256 : 1, F), dim3(256), 0, st, ws.P, keys, pw);      // (an empty cloud still launches: a grid of 0 is an error)
         hipLaunchKernelGGL(prep_records_kernel<PT>, dim3((ws.NCMAX + 4 * PREP_CPW - 1) / (4 * PREP_CPW), F), dim3(256), 0, st, points, labels, N, ws.P,
                            ws.NCMAX, (const unsigned long long*)keys, packed, boxes, counts, K, H, W, camf, pw);
         hipLaunchKernelGGL(prepare_kernel<PT>, dim3(F), dim3(1024), 0, st, points, labels, N, ws.P, ws.NCMAX, keys, packed, boxes, counts, 0, K, H, W,
