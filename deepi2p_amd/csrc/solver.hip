@@ -1315,7 +1315,14 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
     const int mine = (nc - wave + WPH - 1) / WPH;        // clusters wave, wave+WPH, ... < nc
     CacheEnt* cache_w = cache + wave * ((nc + WPH - 1) / WPH);      // the wave's entries are consecutive: lane j <-> its j-th cluster
     constexpr int PF = DI2P_SOLVER_PF;
-    auto take_bit = [](unsigned long long& m) { int b = -1; if (m) { b = (int)__builtin_ctzll(m); m &= m - 1; } return b; };
+    // lowest set bit of a wave-uniform mask, cleared; -1 when the mask is empty.  s_ff1_i32_b64 returns -1 for an empty mask by itself and
+    // s_bitset0_b64 with index -1 clears bit 63 of an empty mask (a no-op): two scalar instructions instead of the seven of the portable form
+    // (add / addc / and for m & (m - 1), ff1, compare, select)
+    auto take_bit = [](unsigned long long& m) {
+        int b;
+        asm("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0" : "=&s"(b), "+s"(m));
+        return b;
+    };
     const int nv_last = cnt - (nc - 1) * CL;                 // valid records of the block's last cluster (scalar), 1..CL
     const unsigned long long tail_mask = nv_last >= CL ? ~0ull : ((1ull << (nv_last & 63)) - 1ull);
     const unsigned tail_lo = (unsigned)tail_mask, tail_hi = (unsigned)(tail_mask >> 32);
@@ -1323,6 +1330,13 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
     for (int j0 = 0; j0 < mine; j0 += 64) {
         const long long ts0 = PROFILE ? clock64() : 0;
         const int j = j0 + lane;
+        const int cbase = j0 * WPH + wave;       // cluster of the round's lane 0 (scalar): lane b's cluster is cbase + b * WPH
+        auto slot_cluster = [&](int b) {         // (one scalar instruction for four-wave workgroups: hipcc re-associates b * 4 + cbase into add, shift, add)
+            int c;
+            if (WPH == 4) asm("s_lshl2_add_u32 %0, %1, %2" : "=s"(c) : "s"(b), "s"(cbase) : "scc");
+            else c = b * WPH + cbase;
+            return c;
+        };
         int status = 0;
         unsigned mlo = 0u, mhi = 0u;      // active mask of the lane's cluster (status 4: cached, 2: its valid records, 1: filled in by phase I)
         float slack = 0.0f;               // min slack of the lane's cluster (phase I)
@@ -1399,7 +1413,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
             int nb[PF];
             Rec<PT> ring_r[PF];
 #pragma unroll
-            for (int u = 0; u < PF; ++u) { nb[u] = take_bit(mg); ring_r[u] = load_rec((j0 + nb[u]) * WPH + wave); }
+            for (int u = 0; u < PF; ++u) { nb[u] = take_bit(mg); ring_r[u] = load_rec(slot_cluster(nb[u])); }
             while (nb[0] >= 0) {
                 if (PROFILE) n_active[6] += 1;
                 float sm[PF];
@@ -1410,7 +1424,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                     cur[u] = ring_r[u];
                     nbp[u] = nb[u];
                     nb[u] = take_bit(mg);
-                    ring_r[u] = load_rec((j0 + nb[u]) * WPH + wave);
+                    ring_r[u] = load_rec(slot_cluster(nb[u]));
                     float sl;
                     const float msu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ms_box), nbp[u] & 63));
                     if (TBZ) {
@@ -1448,7 +1462,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
             int nb[PFC];
             Rec<PT> ring_r[PFC];
 #pragma unroll
-            for (int u = 0; u < PFC; ++u) { nb[u] = take_bit(mo); ring_r[u] = load_rec((j0 + nb[u]) * WPH + wave); }
+            for (int u = 0; u < PFC; ++u) { nb[u] = take_bit(mo); ring_r[u] = load_rec(slot_cluster(nb[u])); }
             while (nb[0] >= 0) {
                 if (PROFILE) n_active[7] += 1;
                 Rec<PT> cur[PFC];
@@ -1460,7 +1474,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                     cur[u] = ring_r[u];
                     nbp[u] = nb[u];
                     nb[u] = take_bit(mo);
-                    ring_r[u] = load_rec((j0 + nb[u]) * WPH + wave);
+                    ring_r[u] = load_rec(slot_cluster(nb[u]));
                 }
 #pragma unroll
                 for (int u = 0; u < PFC; ++u) {          // no short circuits: PFC independent, branch-free instruction streams
@@ -1496,8 +1510,7 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
         {
             unsigned long long mo = mA | mB | mD;
             while (mo) {
-                const int b = (int)__builtin_ctzll(mo);
-                mo &= mo - 1;
+                const int b = take_bit(mo);
                 if (qn > QCAP - 64) drain(false);      // queue nearly full: evaluate the full rounds, keep the remainder queued
                 const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)mlo, b), hi = (unsigned)__builtin_amdgcn_readlane((int)mhi, b);
                 {   // the store runs under exec = the cluster's active mask (mbcnt does not depend on exec): no per-lane bit test, the address and
