@@ -1491,8 +1491,12 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                 for (int u = 0; u < PFC; ++u) {
                     if (nbp[u] >= 0) {              // wave-uniform
                         if (!(sm[u] > 0.0f)) act[u] = exact_active(cur[u], true);        // rare: some record is not certified -> exact test for THAT cluster
-                        const int nvr = cnt - ((j0 + nbp[u]) * WPH + wave) * CL;          // valid records of the cluster (scalar), >= 1
-                        const unsigned long long bal = __ballot(act[u]) & (nvr >= CL ? ~0ull : ((1ull << nvr) - 1ull));
+                        // the padding lanes of the block's LAST cluster are cut from the ballot (its mask is the block's tail mask: scalar)
+                        unsigned long long bal = __ballot(act[u]);
+                        if (slot_cluster(nbp[u]) == nc - 1) {          // wave-uniform, once per block at most: the mask is re-derived here rather than kept live
+                            const int nvr = cnt - (nc - 1) * CL;
+                            bal &= nvr >= CL ? ~0ull : ((1ull << nvr) - 1ull);
+                        }
                         // into the lane that owns the cluster
                         mlo = lane == nbp[u] ? (unsigned)bal : mlo;
                         mhi = lane == nbp[u] ? (unsigned)(bal >> 32) : mhi;
@@ -1520,10 +1524,11 @@ __device__ __forceinline__ void sweep_clusters(const Rec<PT>* __restrict__ recs,
                     const unsigned id = (unsigned)(((j0 + b) * WPH + wave) * CL) + (unsigned)lane;   // (scalar) + lane
                     const unsigned long long m64 = ((unsigned long long)hi << 32) | lo;
                     unsigned long long saved;
-                    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
-                                 : "=&s"(saved) : "s"(m64), "v"(addr), "v"(id) : "memory");
+                    // (all lanes are active here, so exec & mask = mask: one s_and_saveexec instead of two moves)
+                    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
+                                 : "=&s"(saved) : "s"(m64), "v"(addr), "v"(id) : "memory", "scc");
+                    qn += __builtin_popcountll(m64);
                 }
-                qn += __builtin_popcount(lo) + __builtin_popcount(hi);
             }
         }
     }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6, call 16: take_bit as two scalar instructions (-14 % scalar instructions in the walk): bit-identity, counters, full-chip time, step time at 1 / 120 restarts
 set -u
-OUT=gpurun_out; mkdir -p $OUT; ROOT=$(pwd); LOG=$OUT/r06_c17_scalar_trims.txt; : > $LOG
+OUT=gpurun_out; mkdir -p $OUT; ROOT=$(pwd); LOG=$OUT/r06_c18_scalar_trims2.txt; : > $LOG
 V=${V:-tb}
 python tools/dump_solve.py /tmp/main.npz > /dev/null 2>&1
 DI2P_LIB=$ROOT/deepi2p_amd/lib/variants/$V/libdeepi2p_hip.so python tools/dump_solve.py /tmp/v.npz > /dev/null 2>&1
