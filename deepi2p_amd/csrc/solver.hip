@@ -762,7 +762,11 @@ __global__ __launch_bounds__(256) void prep_records_kernel(const PT* __restrict_
 //   reduction: xor-butterfly inside each wave, then the 4 wave partials are combined through LDS in a FIXED
 //     order by every thread, so all 256 threads hold bit-identical sums and the LM control flow that
 //     follows is workgroup-uniform.
-constexpr int PROF_WORDS = 28;      // int64 words per hypothesis of the diagnostics buffer (library version >= 6; 20 in versions 4-5)
+#ifdef DI2P_SOLVER_LMPROF
+constexpr int PROF_WORDS = 36;      // variant build: + 8 words of LM sub-stage clocks
+#else
+constexpr int PROF_WORDS = 28;
+#endif      // int64 words per hypothesis of the diagnostics buffer (library version >= 6; 20 in versions 4-5)
 constexpr int QCAP = DI2P_SOLVER_PF * 64 + 128;        // per-wave queue capacity (ids); phase B drains it when a batch of the cluster walk (PF clusters) may not fit
 
 constexpr int BOXTEST_WORDS = 16;   // sizeof(BoxAbs) / 4 (the table is fetched as 16-byte LDS reads)
@@ -1907,6 +1911,15 @@ struct LMState {
 // instead of field by field between the arithmetic -- the update runs on one lane, so every LDS round trip it waits for (the copy loops
 // alone were 14 read -> wait -> write pairs) is a round trip the whole workgroup waits for.  Same operations on the same values:
 // bit-identical; finish + begin 8.5 k -> 7.5 k cycles per iteration (profiles/r06_c6_prepare.txt), no more scratch.
+#ifdef DI2P_SOLVER_LMPROF
+// variant build: cycles of the LM lane's sub-stages, summed over a hypothesis' iterations (tools/bench_solver.py LMPROF=1 prints them)
+//   [0] finish_iteration  [1] begin: fetch + scaled matrix  [2] Cholesky solve  [3] model change  [4] begin: step, projection, stores
+//   [5] decide without the fit  [6] interpolating fit  [7] trial_next_decide
+__shared__ long long g_lmclk[8];
+#define DI2P_LMCLK(i, t0) g_lmclk[i] += clock64() - (t0)
+#else
+#define DI2P_LMCLK(i, t0) ((void)0)
+#endif
 template <int N> __device__ __forceinline__ void pin_regs(double* v) {
 #pragma unroll
     for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
@@ -1916,6 +1929,9 @@ template <int NP>
 __device__ __forceinline__ void lm_begin_iteration(LMState<NP>& st) {
     constexpr int NT = Tri<NP>::N;
     const double kMinDiag = 1e-6, kMaxDiag = 1e32, kMinRadius = 1e-32, kGradTol = 1e-10;
+#ifdef DI2P_SOLVER_LMPROF
+    long long tb0 = clock64();
+#endif
     double S[NP], A[NT], g[NP], diag[NP], sc[3];
 #pragma unroll
     for (int a = 0; a < NP; ++a) { S[a] = st.S[a]; g[a] = st.g[a]; diag[a] = st.diag[a]; }
@@ -1944,11 +1960,14 @@ __device__ __forceinline__ void lm_begin_iteration(LMState<NP>& st) {
 #pragma unroll
         for (int a = 0; a < NP; ++a) { M[a * (a + 1) / 2 + a] += lm_div(diag[a], radius); ds[a] = -(S[a] * g[a]); }
 #ifdef DI2P_SOLVER_LMPROF
+        DI2P_LMCLK(1, tb0);
         const long long tc0 = clock64();
 #endif
         bool valid = chol_solve_inplace<NP>(M, ds);
 #ifdef DI2P_SOLVER_LMPROF
         st.n_resweep += (int)(clock64() - tc0);
+        DI2P_LMCLK(2, tc0);
+        const long long tm0 = clock64();
 #endif
         double model_change = 0.0;
         if (valid) {
@@ -1962,9 +1981,16 @@ __device__ __forceinline__ void lm_begin_iteration(LMState<NP>& st) {
             model_change = -(l + 0.5 * q);
             valid = model_change > 0.0;
         }
+#ifdef DI2P_SOLVER_LMPROF
+        DI2P_LMCLK(3, tm0);
+        const long long tp0 = clock64();
+#endif
         if (!valid) {
             if (++invalid_run >= 5) { write_back(); st.done = 1; return; }
             radius /= decrease; decrease *= 2.0; reuse_diag = 1;
+#ifdef DI2P_SOLVER_LMPROF
+            tb0 = clock64();
+#endif
             continue;
         }
         invalid_run = 0;
@@ -1987,6 +2013,9 @@ __device__ __forceinline__ void lm_begin_iteration(LMState<NP>& st) {
         for (int a = 0; a < NP; ++a) { st.delta[a] = delta[a]; st.xe[a] = xe[a]; }
         st.gd = gd; st.dmax = dmax; st.t = 1.0; st.ls_it = 0;
         st.phase = PH_TRIAL; st.want_j = 2; st.prev_vok = 0; st.prev_gok = 0;
+#ifdef DI2P_SOLVER_LMPROF
+        DI2P_LMCLK(4, tp0);
+#endif
         return;   // needs a sweep at xe
     }
 }
@@ -2048,9 +2077,15 @@ template <int NP>
 __device__ __forceinline__ void lm_apply(LMState<NP>& st, int action, double fe, const double* ge, const double* Ae) {
     bool begin = action == ACT_BEGIN;
     if (action == ACT_FINISH_CUR || action == ACT_FINISH_FIRST) {
+#ifdef DI2P_SOLVER_LMPROF
+        const long long tf0 = clock64();
+#endif
         const bool first = action == ACT_FINISH_FIRST;
         if (first) plus_proj<NP>(st.x, st.delta, 1.0, st.lb, st.ub, st.xe);     // delta stays unscaled: back to the first trial point
         begin = lm_finish_iteration<NP>(st, first ? st.f1 : fe, first ? st.g1 : ge, first ? st.A1 : Ae);
+#ifdef DI2P_SOLVER_LMPROF
+        DI2P_LMCLK(0, tf0);
+#endif
     }
     if (begin) lm_begin_iteration<NP>(st);
 }
@@ -2114,7 +2149,14 @@ __device__ __forceinline__ int lm_decide(LMState<NP>& st, bool ok, double fe, co
     }
     st.prev_t = cur.x; st.prev_f = cur.value; st.prev_g = cur.gradient; st.prev_vok = cur.value_ok; st.prev_gok = cur.grad_ok;
     double p[6];
+#ifdef DI2P_SOLVER_LMPROF
+    const long long tfit0 = clock64();
+    const bool fitted = interpolating_fit(st.cost, st.gd, cur, prev, p);
+    DI2P_LMCLK(6, tfit0);
+    if (fitted) {
+#else
     if (interpolating_fit(st.cost, st.gd, cur, prev, p)) {
+#endif
         // the minimiser of the interpolant over [1e-3, 0.6] x t is found by the whole wavefront (lm_poly_wave), then lm_trial_next_decide
 #pragma unroll
         for (int j = 0; j < 6; ++j) st.poly[j] = p[j];
@@ -2198,6 +2240,9 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
         st.radius = 1e4; st.decrease = 2.0; st.reuse_diag = 0; st.invalid_run = 0; st.iter = 0; st.nsweep = 0;
         st.phase = PH_INIT; st.done = 0; st.max_iter = a->max_iter; st.cost = 0.0; st.gmax = 0.0;
         st.n_ls_extra = 0; st.n_ls_late_accept = 0; st.n_resweep = 0; st.pad_ = 0; st.want_j = 2; st.poly_req = 0;
+#ifdef DI2P_SOLVER_LMPROF
+        for (int i = 0; i < 8; ++i) g_lmclk[i] = 0;
+#endif
     }
     __syncthreads();
     long long c_sweep = 0, c_wait = 0, c_lm = 0, c_comb = 0;
@@ -2261,7 +2306,13 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
         int action = ACT_NONE;
         if (lm_wave_here && lm_lane == 0) {
             const bool ok = sh.comb[NV - 1] == 0.0 && isfinite(sh.comb[0]);
+#ifdef DI2P_SOLVER_LMPROF
+            const long long td0_ = clock64();
+#endif
             action = lm_decide<NP>(st, ok, sh.comb[0], sh.comb + 1, sh.comb + 1 + NP);
+#ifdef DI2P_SOLVER_LMPROF
+            DI2P_LMCLK(5, td0_);
+#endif
         }
         const long long t2c = PROFILE ? clock64() : 0;
         asm volatile("" ::: "memory");          // the interpolant is read back from LDS by all 64 lanes (not forwarded from lane 0's registers)
@@ -2278,7 +2329,13 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
         // loads with lm_decide's) they were spilled -- three scratch reloads with a full wait on the lane everybody waits for, four times per sweep
         asm volatile("" ::: "memory");
         if (lm_wave_here && lm_lane == 0) {
+#ifdef DI2P_SOLVER_LMPROF
+            const long long ttn0 = clock64();
+#endif
             if (action == ACT_TRIAL_NEXT) action = lm_trial_next_decide<NP>(st);
+#ifdef DI2P_SOLVER_LMPROF
+            DI2P_LMCLK(7, ttn0);
+#endif
             lm_apply<NP>(st, action, sh.comb[0], sh.comb + 1, sh.comb + 1 + NP);
             // the iterate of the NEXT sweep enters the ring of the classification cache (slot = its sweep number % RING)
             const int slot = (st.nsweep - s_base) & (RING - 1);
@@ -2316,6 +2373,9 @@ __global__ __launch_bounds__(WPH * 64, MINW) void solve_kernel(const SolveArgs<P
                            (long long)st.n_ls_extra | ((long long)st.n_ls_late_accept << 20) | ((long long)st.n_resweep << 40),
                            c_decide, c_poly, c_apply, n_act[3], tp[0], tp[1], tp[2], tp[3], n_act[4], n_act[5],
                            n_act[6], n_act[7], n_act[8], n_act[9], n_act[10], n_act[11], n_act[12], (long long)st.pad_, 0, 0};
+#ifdef DI2P_SOLVER_LMPROF
+        for (int i = 0; i < 8; ++i) v[28 + i] = g_lmclk[i];
+#endif
         for (int i = 0; i < PROF_WORDS; ++i) prof[i] = (a->resume && i != 7 ? prof[i] : 0) + v[i];
     }
     if (threadIdx.x == 0 && st.done) {

@@ -41,7 +41,7 @@ for name, lab_np in (("noisy-gt", np.stack([f["labels"] for f in frames])),):
     if os.environ.get("PROF"):
         from deepi2p_amd import _lib
         ver = _lib.load().di2p_version()
-        PW = 28 if ver >= 6 else (20 if ver >= 4 else (16 if ver >= 3 else 8))       # int64 words per hypothesis (version 3: finer phases, 4: classification-cache hits, 6: walk batches / rounds)
+        PW = (36 if os.environ.get("LMPROF") else 28) if ver >= 6 else (20 if ver >= 4 else (16 if ver >= 3 else 8))       # int64 words per hypothesis (version 3: finer phases, 4: classification-cache hits, 6: walk batches / rounds)
         prof = torch.zeros((F, R, PW), dtype=torch.int64, device=dev)
         _lib.load().di2p_solver_set_profile_buffer(prof.data_ptr())
         ops.solve_batched(pc, lab_front, K, restarts[0], restarts[1], H, W, pipe.lb, pipe.ub, 500, True, yaw0=yaw0, sweeps=sweeps)
@@ -70,6 +70,11 @@ for name, lab_np in (("noisy-gt", np.stack([f["labels"] for f in frames])),):
             (q & 0xfffff).mean(), ((q >> 20) & 0xfffff).mean(), (q >> 40).mean(), iters.float().mean().item(), sw.mean()))
         if os.environ.get("LMPROF"):       # variant build -DDI2P_SOLVER_LMPROF: cycles of the Cholesky solves (packed where the re-sweep count was) and of the sincos
             print("  LM detail (cycles per sweep): Cholesky solves %.0f  sincos of the next iterate %.0f" % (((q >> 40) / sw).mean(), (p[:, 25] / sw).mean()))
+            it_ = np.maximum(iters.cpu().numpy().reshape(-1).astype(float), 1.0); ex_ = np.maximum((q & 0xfffff).astype(float), 1.0)
+            print("  LM stages, cycles per ITERATION: finish %.0f  begin: fetch + scaled matrix %.0f  Cholesky solve %.0f  model change %.0f  step + projection + stores %.0f ; "
+                  "per SWEEP: decide without the fit %.0f ; per FAILED TRIAL: interpolating fit %.0f  trial-next %.0f" % (
+                      (p[:, 28] / it_).mean(), (p[:, 29] / it_).mean(), (p[:, 30] / it_).mean(), (p[:, 31] / it_).mean(), (p[:, 32] / it_).mean(),
+                      ((p[:, 33] - p[:, 34]) / sw).mean(), (p[:, 34] / ex_).mean(), (p[:, 35] / ex_).mean()))
         X = np.stack([iters.cpu().numpy().reshape(-1).astype(float), (q & 0xfffff).astype(float), np.ones(sw.size)], axis=1)
         coef = np.linalg.lstsq(X, p[:, 2], rcond=None)[0]
         print("  LM cycles per hypothesis ~ %.0f x iterations + %.0f x extra line-search trials + %.0f" % tuple(coef))
