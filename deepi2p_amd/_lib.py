@@ -91,6 +91,7 @@ _SIGS = {
     "di2p_stem_pack": [c_void_p, c_void_p, c_void_p],
     "di2p_conv7x7s2_stem": [c_void_p] * 5 + [c_int] * 4 + [c_void_p],
     "di2p_winograd_weight_transform": [c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "di2p_winograd_weight_transform_dgrad": [c_void_p, c_void_p, c_int, c_int, c_void_p],
     "di2p_conv3x3_winograd": [c_void_p] * 6 + [c_int] * 6 + [c_void_p],
     "di2p_conv3x3_x3": [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 5,
     "di2p_conv3x3_x3_supported": [c_int] * 6,

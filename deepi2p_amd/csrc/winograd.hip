@@ -34,15 +34,19 @@ struct WinoLds {
 };
 
 // U[xi][ci][co] = (G g G^T)[xi] of weight[co][ci][3][3];  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+// DGRAD: the filter of the input gradient of a stride-1 "same" convolution -- g'[co' = ci][ci' = co][ky][kx] = g[co][ci][2 - ky][2 - kx] -- read
+// straight from the forward filter w[Cin][Cout][3][3] (Cin / Cout are the TRANSFORMED filter's, i.e. the forward layer's Cout / Cin): the
+// training step used to flip, transpose and copy the filter with three launches before this one.
+template <bool DGRAD>
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cin, int Cout) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)Cin * Cout) return;
     const int co = (int)(i % Cout), ci = (int)(i / Cout);
-    const float* g = w + ((long long)co * Cin + ci) * 9;
+    const float* g = DGRAD ? w + ((long long)ci * Cout + co) * 9 : w + ((long long)co * Cin + ci) * 9;
     float t[4][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float g0 = g[c], g1 = g[3 + c], g2 = g[6 + c];
+        const float g0 = DGRAD ? g[8 - c] : g[c], g1 = DGRAD ? g[5 - c] : g[3 + c], g2 = DGRAD ? g[2 - c] : g[6 + c];
         t[0][c] = g0;
         t[1][c] = 0.5f * (g0 + g1 + g2);
         t[2][c] = 0.5f * (g0 - g1 + g2);
@@ -439,7 +443,15 @@ __global__ __launch_bounds__(NW * 64, 2) void wino_reg_kernel(const float* __res
 
 extern "C" int di2p_winograd_weight_transform(const float* weight, float* U, int Cin, int Cout, void* stream) {
     DI2P_CHECK_ARG(weight && U && Cin >= 1 && Cout >= 1, "bad args");
-    hipLaunchKernelGGL(wino_weight_kernel, dim3(di2p_cdiv((long long)Cin * Cout, 256)), dim3(256), 0, (hipStream_t)stream, weight, U, Cin, Cout);
+    hipLaunchKernelGGL(wino_weight_kernel<false>, dim3(di2p_cdiv((long long)Cin * Cout, 256)), dim3(256), 0, (hipStream_t)stream, weight, U, Cin, Cout);
+    DI2P_RETURN_LAUNCH();
+}
+
+// U f32[16, Cin_g, Cout_g] of the INPUT-GRADIENT filter of a stride-1 3x3 layer, from its forward filter weight f32[Cout_f = Cin_g, Cin_f = Cout_g, 3, 3]
+// (flipped taps, swapped channel roles -- one launch instead of flip + transpose + copy + transform).
+extern "C" int di2p_winograd_weight_transform_dgrad(const float* weight, float* U, int Cin_g, int Cout_g, void* stream) {
+    DI2P_CHECK_ARG(weight && U && Cin_g >= 1 && Cout_g >= 1, "bad args");
+    hipLaunchKernelGGL(wino_weight_kernel<true>, dim3(di2p_cdiv((long long)Cin_g * Cout_g, 256)), dim3(256), 0, (hipStream_t)stream, weight, U, Cin_g, Cout_g);
     DI2P_RETURN_LAUNCH();
 }
 

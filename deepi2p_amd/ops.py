@@ -570,6 +570,19 @@ def winograd_weights(weight):
     return U
 
 
+def winograd_weights_dgrad(weight):
+    """weight f32[Cout,Cin,3,3] of a stride-1 3x3 layer -> U f32[16,Cout,Cin]: the transformed filter of the layer's INPUT GRADIENT (the
+    convolution of dY with the flipped, channel-transposed filter), in one launch."""
+    Cout, Cin, KH, KW = weight.shape
+    if (KH, KW) != (3, 3) or weight.dtype != _f32:
+        raise RuntimeError("winograd_weights_dgrad needs an f32 3x3 filter bank")
+    w = weight.detach().contiguous()
+    require_cuda(w)
+    U = torch.empty((16, Cout, Cin), dtype=_f32, device=w.device)
+    call("di2p_winograd_weight_transform_dgrad", ptr(w), ptr(U), Cout, Cin, stream())
+    return U
+
+
 def conv3x3_winograd(x, U, scale, shift, relu, residual=None):
     """3x3 / stride 1 / pad 1 convolution via Winograd F(2x2,3x3): y = relu?(scale * conv(x) + shift + residual)."""
     require_cuda(x, U, scale, shift, residual)

@@ -154,7 +154,15 @@ class _Conv2d(Function):
             if stride == 1 and KH == KW and 2 * pad == KH - 1:
                 # a stride-1 "same" convolution's input gradient is the convolution of dY with the flipped, channel-transposed filter:
                 # the forward engine does it (the strided layers go through the generic gather-form kernel)
-                dx = _conv_forward(dy, W.flip(2, 3).transpose(0, 1), 1, pad)
+                one, zero = _unit_affine(Cin, dy.device)
+                if ((KH, pad) == (3, 1) and Cout % 16 == 0 and Cin % 32 == 0 and dy.shape[3] % 2 == 0 and dy.shape[3] >= 4
+                        and not (dy.shape[0] >= 16 and (_lib.get_option("conv_x3") & (1 << max(0, min(3, Cin.bit_length() - 7))))
+                                 and ops.conv3x3_x3_supported(dy.shape, Cin, 1))):
+                    # round 6: the Winograd kernel with the gradient filter transformed straight from W (one launch instead of flip + transpose +
+                    # copy + transform); the same U, the same kernel, the same bits as the path below
+                    dx = ops.conv3x3_winograd(dy, ops.winograd_weights_dgrad(W), one, zero, False)
+                else:
+                    dx = _conv_forward(dy, W.flip(2, 3).transpose(0, 1), 1, pad)
             else:
                 dx = torch.empty_like(x)
                 call("di2p_conv2d_dgrad", ptr(dy), ptr(_c(W)), ptr(dx), B, Cin, H, Wd, Cout, KH, KW, stride, pad, stream())

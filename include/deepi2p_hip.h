@@ -201,6 +201,10 @@ long long di2p_conv2d_workspace_bytes(int B, int Cin, int H, int W, int Cout, in
  *   di2p_winograd_weight_transform: weight f32[Cout,Cin,3,3] -> U f32[16,Cin,Cout] (= G g G^T), once per checkpoint load.
  *   di2p_conv3x3_winograd: y = relu?( scale * conv(x) + shift + residual ); needs Cin % 8 == 0 and Cout % 32 == 0. */
 int di2p_winograd_weight_transform(const float* weight, float* U, int Cin, int Cout, void* stream);
+/* round 6 (training path): the transformed filter of the INPUT GRADIENT of a stride-1 3x3 layer, U f32[16,Cin_g,Cout_g], straight from the layer's
+ * forward filter weight f32[Cout_f = Cin_g, Cin_f = Cout_g, 3, 3] (taps flipped, channel roles swapped).  Replaces torch's flip + transpose + copy
+ * in front of di2p_winograd_weight_transform (models/multimodal_classifier.py:213-218 reaches it through loss.backward()). */
+int di2p_winograd_weight_transform_dgrad(const float* weight, float* U, int Cin_g, int Cout_g, void* stream);
 int di2p_conv3x3_winograd(const float* x, const float* U, const float* scale, const float* shift, const float* residual, float* y, int B,
                           int Cin, int H, int W, int Cout, int relu, void* stream);
 /* The coarse per-point head (per_point_pn, models/networks_united.py:57-74 applied at :188-197: 736 -> 128 -> 128 -> P) in ONE launch on the bf16

@@ -79,6 +79,19 @@ def test_conv2d_backward(B, Cin, H, W, Cout, k, s, p):
     _run_pair(lambda x, W: tn._Conv2d.apply(x, W, s, p), lambda x, W: F.conv2d(x, W, None, stride=s, padding=p), [x, Wt], tol=3e-5)
 
 
+def test_winograd_dgrad_filter_transform_equals_flip_transpose_transform():
+    """Round 6: the transformed filter of a stride-1 3x3 layer's input gradient comes straight from the forward filter (one launch); it must be
+    the SAME tensor, bit for bit, as flipping, transposing and copying the filter and then transforming it (what the step did before) -- also
+    for a layer with different channel counts (the channel roles swap)."""
+    from deepi2p_amd import ops
+    dev = torch.device("cuda", 0)
+    for Cout, Cin in ((64, 64), (128, 64), (32, 96)):
+        W = torch.randn(Cout, Cin, 3, 3, generator=torch.Generator().manual_seed(Cout + Cin)).to(dev)
+        a = ops.winograd_weights_dgrad(W)
+        b = ops.winograd_weights(W.flip(2, 3).transpose(0, 1))
+        assert a.shape == b.shape == (16, Cout, Cin) and torch.equal(a, b)
+
+
 def test_maxpool_avgpool_backward():
     from deepi2p_amd import train_net as tn
     g = torch.Generator().manual_seed(3)
