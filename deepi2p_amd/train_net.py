@@ -212,13 +212,28 @@ class _BatchNorm(Function):
         return dx, (None if sunk else dgamma), (None if sunk else dbeta), None, None, None, None, dres
 
 
+# `num_batches_tracked += 1` is a one-element launch per BatchNorm layer (64 per step, 3 us each plus the gap around it).  Inside a whole
+# forward (keypoint_detector) the counters are collected and bumped by ONE multi-tensor launch at its end; a lone batch_norm call bumps at once.
+_NBT_PENDING = None
+
+
+def _flush_batch_counters():
+    global _NBT_PENDING
+    pending, _NBT_PENDING = _NBT_PENDING, None
+    if pending:
+        torch._foreach_add_(pending, 1)
+
+
 def batch_norm(P, key, x, relu, residual=None, momentum=0.1):
     """nn.BatchNorm{1,2}d of state-dict prefix `key` in train mode (+ fused residual add and ReLU)."""
     rm, rv = P.get(key + ".running_mean"), P.get(key + ".running_var")
     y = _BatchNorm.apply(x, P[key + ".weight"], P[key + ".bias"], rm, rv, momentum, relu, residual)
     nbt = P.get(key + ".num_batches_tracked")
     if nbt is not None:
-        nbt += 1
+        if _NBT_PENDING is not None:
+            _NBT_PENDING.append(nbt)
+        else:
+            nbt += 1
     return y
 
 
@@ -489,6 +504,15 @@ def keypoint_detector(P, opt, pc, intensity, sn, node_a, node_b, img, dropouts=N
     """KeypointDetector.forward (networks_united.py:105-210) in train mode -> scores f32[B, 2 (+L), N].
     dropouts: the two u8 keep-masks [B, C, N] of per_point_pn layers 0 and 1 (None: no dropout, i.e. p = 0).
     branch_streams: run the image branch on a second HIP stream (same results: no kernel changes its summation order)."""
+    global _NBT_PENDING
+    _NBT_PENDING = []                       # the BatchNorm counters of this forward: one launch at its end (the streams are joined by then)
+    try:
+        return _keypoint_detector(P, opt, pc, intensity, sn, node_a, node_b, img, dropouts, branch_streams)
+    finally:
+        _flush_batch_counters()
+
+
+def _keypoint_detector(P, opt, pc, intensity, sn, node_a, node_b, img, dropouts, branch_streams):
     B, N, Ma, Mb = pc.shape[0], pc.shape[2], node_a.shape[2], node_b.shape[2]
     if branch_streams and img.is_cuda:
         # The image branch and the point branch are independent up to the attention layers, and at the training batch (8 frames) neither

@@ -235,6 +235,9 @@ def test_trainer_optimises_and_eval_path_follows():
         losses.append(float(L["loss"]))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     assert float((tr.flat - before).abs().max()) > 0
+    # the BatchNorm step counters (round 6: bumped by one multi-tensor launch per forward instead of one launch per layer): 8 forwards = 8
+    nbt = [v for k, v in det.state_dict().items() if k.endswith("num_batches_tracked")]
+    assert len(nbt) > 40 and all(int(v) == 8 for v in nbt), sorted({int(v) for v in nbt})
     ev = tr.test_model(t["pc"], t["intensity"], t["sn"], t["node_a"], t["node_b"], t["img"], K, Pgt)
     assert np.isfinite(float(ev["loss"])) and 0.0 <= float(ev["coarse_accuracy"]) <= 1.0
     print("losses", ["%.3f" % v for v in losses], "eval loss %.3f coarse acc %.3f" % (float(ev["loss"]), float(ev["coarse_accuracy"])))
