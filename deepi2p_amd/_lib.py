@@ -28,7 +28,8 @@ class SrcT(ctypes.Structure):
 class EpilogueT(ctypes.Structure):
     _fields_ = [("scale", c_void_p), ("shift", c_void_p), ("batch_bias", c_void_p), ("relu", c_int),
                 ("group_max", c_int), ("g_table", c_void_p * 2), ("g_idx", c_void_p * 2), ("g_w", c_void_p * 2),
-                ("g_nodes", c_int * 2), ("g_k", c_int * 2), ("transpose_out", c_int), ("group_max_out", c_void_p)]
+                ("g_nodes", c_int * 2), ("g_k", c_int * 2), ("transpose_out", c_int), ("group_max_out", c_void_p),
+                ("planes_out", c_void_p)]
 
 
 class HeadX3T(ctypes.Structure):      # di2p_head_x3_t
@@ -55,6 +56,7 @@ _SIGS = {
                             ctypes.POINTER(EpilogueT), c_void_p],
     "di2p_pointwise_gemm_x3": [ctypes.POINTER(SrcT), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                ctypes.POINTER(EpilogueT), c_void_p],
+    "di2p_pointwise_gemm_x3p": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(EpilogueT), c_void_p],
     "di2p_bf16x3_pack": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "di2p_batch_gemv": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "di2p_batch_gemv2": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
@@ -121,6 +123,7 @@ _WS_SIGS = {        # <name>_workspace_bytes helpers returning long long
     "di2p_gather_backward_workspace_bytes": [c_int] * 4,
     "di2p_conv2d_wgrad_workspace_bytes": [c_int] * 9,
     "di2p_bf16x3_packed_bytes": [c_int] * 2,
+    "di2p_bf16x3_planes_bytes": [c_int] * 3,
     "di2p_head_x3_packed_bytes": [c_int],
     "di2p_stem_x3_packed_bytes": [],
 }

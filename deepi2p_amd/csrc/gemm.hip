@@ -131,6 +131,31 @@ struct LoaderConcat4 {
     __device__ __forceinline__ void fix(float4&, int, const Info&) const {}
 };
 
+#ifndef DI2P_X3P_B128
+#define DI2P_X3P_B128 0          // experiment: planes as [plane][K/8][N] x 16 bytes (one ds_read_b128 per fragment)
+#endif
+#ifndef DI2P_X3P_ORDER
+#define DI2P_X3P_ORDER 0         // experiment: 1 = the K-step's second weight-fragment request in FRONT of the next step's plane rows
+#endif
+// bf16x3 (see the section of that name below): the exact three-way split of fp32 values into truncated bf16 terms
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float x3_hi16(float x) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffff0000u); }
+// the bf16 (high halves) of two floats in one word: low half <- x0, high half <- x1
+__device__ __forceinline__ unsigned x3_pack_hi(float x0, float x1) {
+    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, x1), __builtin_bit_cast(unsigned, x0), 0x07060302u);
+}
+// four consecutive k of one column -> three planes of 4 x bf16
+__device__ __forceinline__ void x3_split4(float f0, float f1, float f2, float f3, u32x2_t& p1, u32x2_t& p2, u32x2_t& p3) {
+    const float r0 = f0 - x3_hi16(f0), r1 = f1 - x3_hi16(f1), r2 = f2 - x3_hi16(f2), r3 = f3 - x3_hi16(f3);
+    const float q0 = r0 - x3_hi16(r0), q1 = r1 - x3_hi16(r1), q2 = r2 - x3_hi16(r2), q3 = r3 - x3_hi16(r3);
+    p1 = u32x2_t{x3_pack_hi(f0, f1), x3_pack_hi(f2, f3)};
+    p2 = u32x2_t{x3_pack_hi(r0, r1), x3_pack_hi(r2, r3)};
+    p3 = u32x2_t{x3_pack_hi(q0, q1), x3_pack_hi(q2, q3)};
+}
+
 struct EpiDev {
     const float* scale;
     const float* shift;
@@ -145,6 +170,7 @@ struct EpiDev {
     int transpose_out;
     float* gmax_out;          // with group_max > 1: Y is stored in full AND the group maxima go here ([B,M,N/group_max])
     float* gmax_dst;          // where the group maxima go: gmax_out, or Y itself when only the maxima are stored (resolved on the host)
+    u32x2_t* planes;          // the full-size output as three bf16 planes [B][3][M/4][N] x 4 consecutive rows (kernels instantiated with PLANES only)
 };
 
 // The accumulator tile of a lane is 16 rows of ONE column: rows mrow0 + 8g + {0..3}, g = 0..3.  All per-row operands
@@ -153,7 +179,7 @@ struct EpiDev {
 // load -> wait -> store rounds.  Needs M % 4 == 0 whenever float4 operands are used (host-checked).
 // GK0 / GK1 >= 0: the neighbour counts of the two gathered tables are compile-time constants AND M % 32 == 0 (the fused head: 3 + 3 on 128 rows);
 // -1: run-time counts (any k, any M % 4 == 0).
-template <int GK0 = -1, int GK1 = -1>
+template <int GK0 = -1, int GK1 = -1, bool PLANES = false>
 struct EpiPointwiseT {
     EpiDev e;
     float* Y;
@@ -210,14 +236,27 @@ struct EpiPointwiseT {
     __device__ __forceinline__ void apply(int mrow0, int nc, const f32x16& acc, float (&v)[16]) const {
         apply_pre(mrow0, nc, acc, nullptr, v);
     }
+    // the per-row operand `row` (scale / shift / this frame's bias) on the 16 rows: ROWS4 (M % 4 == 0, the bf16x3 kernels) = one 16-byte load per
+    // row group instead of four clamped dword loads (rows >= M, never stored, then see other rows' values: the stored ones are the same)
+    template <bool ROWS4, class F>
+    __device__ __forceinline__ void row_operand(const float* row, int mrow0, float (&v)[16], F f) const {
+        if (ROWS4) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 q = *reinterpret_cast<const float4*>(row + min(mrow0 + 8 * g, M - 4));
+                v[4 * g] = f(v[4 * g], q.x); v[4 * g + 1] = f(v[4 * g + 1], q.y); v[4 * g + 2] = f(v[4 * g + 2], q.z); v[4 * g + 3] = f(v[4 * g + 3], q.w);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = f(v[r], row[min(mrow0 + (r & 3) + 8 * (r >> 2), M - 1)]);
+        }
+    }
     // pre != nullptr (compile-time tables only): the gathered sum of these rows, already computed by gather_sum
+    template <bool ROWS4 = false>
     __device__ __forceinline__ void apply_pre(int mrow0, int nc, const f32x16& acc, const float* pre, float (&v)[16]) const {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = acc[r];
-        if (e.batch_bias) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] += e.batch_bias[(long long)b * M + min(mrow0 + (r & 3) + 8 * (r >> 2), M - 1)];
-        }
+        if (e.batch_bias) row_operand<ROWS4>(e.batch_bias + (long long)b * M, mrow0, v, [](float a, float x) { return a + x; });
         // gathered add (per_point_pn layer 0): v[m] += sum_j w_j * G[b][idx_j][m]
         if (GK0 >= 0 && GK1 >= 0) {
             // The neighbours' products are summed FIRST, row group by row group, in fresh registers (t = sum_j w_j G_j: tables in order,
@@ -286,24 +325,47 @@ struct EpiPointwiseT {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] += t16[r];
         }
-        if (e.scale) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] *= e.scale[min(mrow0 + (r & 3) + 8 * (r >> 2), M - 1)];
-        }
-        if (e.shift) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] += e.shift[min(mrow0 + (r & 3) + 8 * (r >> 2), M - 1)];
-        }
+        if (e.scale) row_operand<ROWS4>(e.scale, mrow0, v, [](float a, float x) { return a * x; });
+        if (e.shift) row_operand<ROWS4>(e.shift, mrow0, v, [](float a, float x) { return a + x; });
         if (e.relu) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
         }
     }
+    // PLANES: the rows mrow0 + 8g + {0..3} of column n as three bf16 quads of 8 bytes each -- the k-quads of the layer that contracts over this
+    // layer's rows (pointwise_gemm_x3p_kernel stages them without touching them); M % 4 == 0 (host-checked)
+    __device__ __forceinline__ void store_planes(int mrow0, int n, const float (&v)[16]) const {
+        const long long ps = (long long)(M >> 2) * N;               // one plane of one frame, in quads
+#if DI2P_X3P_B128
+        u32x2_t* p = e.planes + (long long)b * 3 * ps + 2 * n;      // [plane][M/8][N] x 16 bytes: 8 consecutive rows of one column
+#else
+        u32x2_t* p = e.planes + (long long)b * 3 * ps + n;
+#endif
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int m = mrow0 + 8 * g;
+            if (m < M) {
+                u32x2_t p1, p2, p3;
+                x3_split4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], p1, p2, p3);
+#if DI2P_X3P_B128
+                u32x2_t* q = p + (long long)(m >> 3) * 2 * N + ((m >> 2) & 1);
+#else
+                u32x2_t* q = p + (long long)(m >> 2) * N;
+#endif
+                q[0] = p1; q[ps] = p2; q[2 * ps] = p3;
+            }
+        }
+    }
     __device__ __forceinline__ void tile(int mrow0, int n, const f32x16& acc) {
-        const bool col_ok = n < N;
-        const int nc = col_ok ? n : N - 1;
         float v[16];
-        apply(mrow0, nc, acc, v);
+        apply(mrow0, n < N ? n : N - 1, acc, v);
+        store(mrow0, n, v);
+    }
+    // the stores of tile(): v = what apply() returned for column min(n, N - 1).  Kernels whose epilogue loads should not queue behind the
+    // previous tile's stores call apply() for all their tiles first, then store() for all of them.
+    __device__ __forceinline__ void store(int mrow0, int n, float (&v)[16]) {
+        const bool col_ok = n < N;
+        if (PLANES && !lds_tile && col_ok) store_planes(mrow0, n, v);       // instead of every full-size store to Y below
         if (lds_tile) {          // columns past N hold clamped (finite) duplicates; they are never stored to memory
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -322,7 +384,7 @@ struct EpiPointwiseT {
             for (int r = 0; r < 16; ++r) {
                 const int m = mrow0 + (r & 3) + 8 * (r >> 2);
                 const bool ok = col_ok && m < M;
-                if (e.gmax_out && ok) Y[((long long)b * M + m) * N + n] = v[r];
+                if (!PLANES && e.gmax_out && ok) Y[((long long)b * M + m) * N + n] = v[r];
                 mx[r] = ok ? v[r] : -__builtin_inff();
                 nanbits |= (mx[r] != mx[r]) ? (1u << r) : 0u;
             }
@@ -354,7 +416,7 @@ struct EpiPointwiseT {
             for (int r = 0; r < 16; ++r) {
                 const int m = mrow0 + (r & 3) + 8 * (r >> 2);
                 const bool ok = col_ok && m < M;
-                if (e.gmax_out && ok) Y[((long long)b * M + m) * N + n] = v[r];
+                if (!PLANES && e.gmax_out && ok) Y[((long long)b * M + m) * N + n] = v[r];
                 float mx = ok ? v[r] : -__builtin_inff();
                 for (int o = 1; o < e.group_max; o <<= 1) {      // torch.max semantics: NaN propagates
                     const float ot = __shfl_xor(mx, o);
@@ -368,7 +430,7 @@ struct EpiPointwiseT {
                 const int m = mrow0 + 8 * g;
                 if (col_ok && m < M) *reinterpret_cast<float4*>(Y + ((long long)b * N + n) * M + m) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
             }
-        } else {
+        } else if (!PLANES) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mrow0 + (r & 3) + 8 * (r >> 2);
@@ -378,6 +440,7 @@ struct EpiPointwiseT {
     }
 };
 using EpiPointwise = EpiPointwiseT<-1, -1>;
+using EpiPointwisePlanes = EpiPointwiseT<-1, -1, true>;
 
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::THREADS) void pointwise_gemm_kernel(SrcDev srcs, const float* __restrict__ Wt, float* __restrict__ Y,
@@ -898,27 +961,9 @@ void launch_pw_vec(bool dense, const SrcDev& s, const float* Wt, float* Y, int B
 //            (5.5 vector instructions per value); LDS layout [plane][k-group of 8][k-half][column] x 8 bytes: a thread stores 32 contiguous
 //            bytes per plane (its 4 columns x 4 consecutive k), a fragment read is two conflict-free 8-byte reads.
 // Workgroup 128 x 128, 4 waves of 64 x 64 (2 x 2 MFMA tiles), K-step 32, 48 KB of LDS, two workgroups per CU.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ float x3_hi16(float x) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffff0000u); }
-// the bf16 (high halves) of two floats in one word: low half <- x0, high half <- x1
-__device__ __forceinline__ unsigned x3_pack_hi(float x0, float x1) {
-    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, x1), __builtin_bit_cast(unsigned, x0), 0x07060302u);
-}
-// four consecutive k of one column -> three planes of 4 x bf16
-__device__ __forceinline__ void x3_split4(float f0, float f1, float f2, float f3, u32x2_t& p1, u32x2_t& p2, u32x2_t& p3) {
-    const float r0 = f0 - x3_hi16(f0), r1 = f1 - x3_hi16(f1), r2 = f2 - x3_hi16(f2), r3 = f3 - x3_hi16(f3);
-    const float q0 = r0 - x3_hi16(r0), q1 = r1 - x3_hi16(r1), q2 = r2 - x3_hi16(r2), q3 = r3 - x3_hi16(r3);
-    p1 = u32x2_t{x3_pack_hi(f0, f1), x3_pack_hi(f2, f3)};
-    p2 = u32x2_t{x3_pack_hi(r0, r1), x3_pack_hi(r2, r3)};
-    p3 = u32x2_t{x3_pack_hi(q0, q1), x3_pack_hi(q2, q3)};
-}
-
 constexpr int X3_BM = 128, X3_BN = 128, X3_BK = 32, X3_KG = X3_BK / 8;
 
-template <bool DENSE>
+template <bool DENSE, bool PLANES = false>
 __global__ __launch_bounds__(256, 2) void pointwise_gemm_x3_kernel(SrcDev srcs, const u32x4_t* __restrict__ Wp, float* __restrict__ Y, int M, int K,
                                                                     int N, int Mp, EpiDev epi) {
     __shared__ __attribute__((aligned(16))) u32x2_t Bs[2][3][X3_KG][2][X3_BN];        // 2 x 24 KB
@@ -1006,11 +1051,138 @@ __global__ __launch_bounds__(256, 2) void pointwise_gemm_x3_kernel(SrcDev srcs, 
     }
     substep((T - 1) & 1, 0, (T - 1) * X3_KG + 2, true);
     substep((T - 1) & 1, 1, 0, false);
-    EpiPointwise ep{epi, Y, b, M, N};
+    // every tile's operand loads (gathered rows, scale, shift: 16 bytes each) and arithmetic first, then every tile's stores: loads that follow
+    // a store to memory the compiler cannot tell apart are not moved above it -- tile by tile, each tile's round trips came one after the other
+    EpiPointwiseT<-1, -1, PLANES> ep{epi, Y, b, M, N};
+    float v[2][2][16];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) ep.tile(m_blk + wm * 64 + i * 32 + 4 * half, n_blk + wn * 64 + j * 32 + l31, acc[i][j]);
+        for (int j = 0; j < 2; ++j)
+            ep.template apply_pre<true>(m_blk + wm * 64 + i * 32 + 4 * half, min(n_blk + wn * 64 + j * 32 + l31, N - 1), acc[i][j], nullptr, v[i][j]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ep.store(m_blk + wm * 64 + i * 32 + 4 * half, n_blk + wn * 64 + j * 32 + l31, v[i][j]);
+}
+
+// The same contraction with the activations given ALREADY SPLIT: three bf16 planes [B][3][K/4][N] x 8 bytes (4 consecutive k of one column),
+// what a PLANES epilogue of the producing layer wrote -- the LDS layout of the kernel above, row for row.  A K-step is 24 rows of 1 KB
+// (plane, k-quad): six per wave, one 16-byte load and one 16-byte LDS store per lane and row, no arithmetic on the way (the split costs the
+// fp32-source kernel 88 of its 225 vector instructions per K-step and wave, the generic concatenating loader's addressing about 80 more, and
+// every 128-row workgroup of a column tile repeats both).  Same A fragments, same products in the same order: bit-identical to the
+// fp32-source kernel on the same values.  Needs K % 32 == 0 and N % 128 == 0 (host-checked).
+template <bool PLANES>
+__global__ __launch_bounds__(256, 2) void pointwise_gemm_x3p_kernel(const u32x4_t* __restrict__ P, const u32x4_t* __restrict__ Wp, float* __restrict__ Y,
+                                                                     int M, int K, int N, int Mp, EpiDev epi) {
+    __shared__ __attribute__((aligned(16))) u32x2_t Bs[2][3][X3_KG][2][X3_BN];        // 2 x 24 KB: [buffer][24 rows of 1 KB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m_blk = blockIdx.y * X3_BM, n_blk = blockIdx.x * X3_BN, b = blockIdx.z;
+    const int T = K / X3_BK;
+    // staging role: rows wave * 6 .. + 5 of the 24 (row = plane * 8 + k-quad of the K-step), columns 2 * lane, 2 * lane + 1
+    const int kq = K >> 2, nh = N >> 1;                      // k-quads per plane; 16-byte elements per row
+    const u32x4_t* Pf = P + (long long)b * 3 * kq * nh + (n_blk >> 1) + lane;
+    int roff[6];
+#if DI2P_X3P_B128
+    // 12 rows of 2 KB (plane, k-oct): three per wave, two 16-byte columns (lane, lane + 64) per lane and row
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int row = wave * 3 + (i >> 1);
+        roff[i] = ((row >> 2) * (kq >> 1) + (row & 3)) * 2 * nh + (i & 1) * 64 + (n_blk >> 1);    // Pf already holds n_blk / 2 + lane
+    }
+#else
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int row = wave * 6 + i;
+        roff[i] = ((row >> 3) * kq + (row & 7)) * nh;
+    }
+#endif
+    u32x4_t st[6];
+    auto gload = [&](int t) {
+        const u32x4_t* pt = Pf + (long long)t * 8 * nh;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) st[i] = pt[roff[i]];
+    };
+    auto sstore = [&](int buf) {
+        u32x4_t* d = reinterpret_cast<u32x4_t*>(&Bs[buf][0][0][0][0]) + wave * 6 * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i * 64] = st[i];
+    };
+    u32x4_t af[2][2][3];                                     // [stage][tile i][plane]
+    auto aload = [&](int kg_global, int stg) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const u32x4_t* p = Wp + ((long long)(kg_global + half) * Mp + m_blk + wm * 64 + i * 32 + l31) * 3;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) af[stg][i][q] = p[q];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    auto substep = [&](int buf, int sub, int next_kg, bool has_next) __attribute__((always_inline)) {
+        if (has_next) aload(next_kg, sub ^ 1);
+        u32x4_t bf[2][3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int n = wn * 64 + j * 32 + l31;
+#if DI2P_X3P_B128
+                bf[j][q] = reinterpret_cast<const u32x4_t*>(&Bs[buf][0][0][0][0])[(q * 4 + 2 * sub + half) * X3_BN + n];
+#else
+                const u32x2_t lo = Bs[buf][q][2 * sub + half][0][n], hi = Bs[buf][q][2 * sub + half][1][n];
+                bf[j][q] = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+#endif
+            }
+        DI2P_MFMA_BEGIN();
+#define DI2P_X3_PROD(QA, QB)                                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                                      \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[sub][i][QA]), __builtin_bit_cast(bf16x8_t, bf[j][QB]), acc[i][j], 0, 0, 0);
+        DI2P_X3_PROD(2, 0) DI2P_X3_PROD(1, 1) DI2P_X3_PROD(0, 2)
+        DI2P_X3_PROD(1, 0) DI2P_X3_PROD(0, 1)
+        DI2P_X3_PROD(0, 0)
+#undef DI2P_X3_PROD
+        DI2P_MFMA_END();
+    };
+    gload(0);
+    sstore(0);
+    aload(0, 0);
+    __syncthreads();
+    for (int t = 0; t + 1 < T; ++t) {
+        const int buf = t & 1;
+#if DI2P_X3P_ORDER
+        aload(t * X3_KG + 2, 1);          // memory returns a wave's loads in order: the fragments of sub-step 1 must not queue behind the plane rows
+        gload(t + 1);
+        substep(buf, 0, 0, false);
+#else
+        gload(t + 1);
+        substep(buf, 0, t * X3_KG + 2, true);
+#endif
+        substep(buf, 1, t * X3_KG + 4, true);
+        sstore(buf ^ 1);
+        __syncthreads();
+    }
+    substep((T - 1) & 1, 0, (T - 1) * X3_KG + 2, true);
+    substep((T - 1) & 1, 1, 0, false);
+    // every tile's operand loads (gathered rows, scale, shift: 16 bytes each) and arithmetic first, then every tile's stores: loads that follow
+    // a store to memory the compiler cannot tell apart are not moved above it -- tile by tile, each tile's round trips came one after the other
+    EpiPointwiseT<-1, -1, PLANES> ep{epi, Y, b, M, N};
+    float v[2][2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            ep.template apply_pre<true>(m_blk + wm * 64 + i * 32 + 4 * half, min(n_blk + wn * 64 + j * 32 + l31, N - 1), acc[i][j], nullptr, v[i][j]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ep.store(m_blk + wm * 64 + i * 32 + 4 * half, n_blk + wn * 64 + j * 32 + l31, v[i][j]);
 }
 
 // Wt f32 [K][M] (k-major, what the fp32 kernels read) -> [Kp/8][Mp][3][8] bf16, zero filled outside K x M.  One thread per (k-group, m).
@@ -1098,6 +1270,7 @@ extern "C" int di2p_pointwise_gemm(const di2p_src_t* srcs, int n_src, const floa
         }
         DI2P_CHECK_ARG(!(e.g_table[0] || e.g_table[1]) || (M % 4 == 0 && M >= 4), "gathered tables need M % 4 == 0");
         DI2P_CHECK_ARG(!e.transpose_out || (M % 4 == 0 && e.group_max == 1), "transpose_out needs M % 4 == 0 and no group_max");
+        DI2P_CHECK_ARG(!epi->planes_out, "planes_out: only the bf16x3 entry points write split planes");
     }
     if (e.group_max > 1) {
         const int g = e.group_max;
@@ -1147,12 +1320,44 @@ extern "C" int di2p_bf16x3_pack(const float* Wt, int K, int M, void* Wp, void* s
     DI2P_RETURN_LAUNCH();
 }
 
+// the epilogue of the two bf16x3 entry points (host struct -> device struct, argument checks)
+static int x3_epilogue(const char* who, const di2p_epilogue_t* epi, float* Y, int M, int N, EpiDev& e) {
+#define X3_EPI_CHECK(cond, msg) do { if (!(cond)) { di2p_set_error("%s: %s", who, msg); return -1; } } while (0)
+    e = EpiDev{};
+    e.group_max = 1;
+    if (epi) {
+        e.scale = epi->scale; e.shift = epi->shift; e.batch_bias = epi->batch_bias; e.relu = epi->relu;
+        e.group_max = epi->group_max > 1 ? epi->group_max : 1;
+        for (int t = 0; t < 2; ++t) { e.g_table[t] = epi->g_table[t]; e.g_idx[t] = epi->g_idx[t]; e.g_w[t] = epi->g_w[t]; e.g_nodes[t] = epi->g_nodes[t]; }
+        e.transpose_out = epi->transpose_out;
+        e.planes = (u32x2_t*)epi->planes_out;
+        // the full-size output goes to Y, or to the planes; the group maxima to group_max_out when given, else to Y (which then holds nothing else)
+        e.gmax_out = epi->group_max > 1 ? epi->group_max_out : nullptr;
+        e.gmax_dst = e.gmax_out ? e.gmax_out : Y;
+        for (int t = 0; t < 2; ++t) {
+            e.g_k[t] = e.g_table[t] ? epi->g_k[t] : 0;
+            X3_EPI_CHECK(e.g_k[t] >= 0 && e.g_k[t] <= DI2P_MAX_GK, "g_k must be in [0, DI2P_MAX_GK]");
+            X3_EPI_CHECK(!e.g_table[t] || (e.g_idx[t] && e.g_k[t] >= 1 && e.g_nodes[t] >= 1), "gathered table without index / k / nodes");
+        }
+        X3_EPI_CHECK(!e.transpose_out || e.group_max == 1, "transpose_out excludes group_max");
+        X3_EPI_CHECK(!e.planes || (!e.transpose_out && ((uintptr_t)e.planes & 15) == 0), "planes_out excludes transpose_out and must be 16-byte aligned");
+        X3_EPI_CHECK(!e.planes || (long long)3 * M * N * 2 < (1ll << 31), "planes_out: a frame's planes must fit 31 bits");
+    }
+    X3_EPI_CHECK(Y || (e.planes && (e.group_max == 1 || e.gmax_out)), "Y may be NULL only when planes_out takes the full-size output");
+    if (e.group_max > 1) {
+        const int g = e.group_max;
+        X3_EPI_CHECK((g & (g - 1)) == 0 && g <= 32 && N % g == 0, "group_max must be a power of two <= 32 dividing N");
+    }
+    return 0;
+#undef X3_EPI_CHECK
+}
+
 // Same contract as di2p_pointwise_gemm with the weights given as di2p_bf16x3_pack's output (of the SAME [K][M] matrix).  Needs N % 4 == 0;
-// every epilogue of the fp32 entry point is available.
+// every epilogue of the fp32 entry point is available, and planes_out.
 extern "C" int di2p_pointwise_gemm_x3(const di2p_src_t* srcs, int n_src, const void* Wp, float* Y, int B, int M, int K, int N,
                                       const di2p_epilogue_t* epi, void* stream) {
     DI2P_CHECK_ARG(srcs && n_src >= 1 && n_src <= DI2P_MAX_SRC, "1..3 sources");
-    DI2P_CHECK_ARG(Wp && Y && aligned16(Wp), "null / misaligned pointer");
+    DI2P_CHECK_ARG(Wp && aligned16(Wp), "null / misaligned pointer");
     DI2P_CHECK_ARG(B >= 0 && M >= 4 && M % 4 == 0 && K >= 1 && N >= 4 && N % 4 == 0, "needs M % 4 == 0 and N % 4 == 0");
     if (B == 0) return 0;
     SrcDev s{};
@@ -1172,33 +1377,43 @@ extern "C" int di2p_pointwise_gemm_x3(const di2p_src_t* srcs, int n_src, const v
     s.n_src = n_src;
     alias_absent_sources(s, n_src);
     DI2P_CHECK_ARG(ctot == K, "source channels do not sum to K");
-    EpiDev e{};
-    e.group_max = 1;
-    if (epi) {
-        e.scale = epi->scale; e.shift = epi->shift; e.batch_bias = epi->batch_bias; e.relu = epi->relu;
-        e.group_max = epi->group_max > 1 ? epi->group_max : 1;
-        for (int t = 0; t < 2; ++t) { e.g_table[t] = epi->g_table[t]; e.g_idx[t] = epi->g_idx[t]; e.g_w[t] = epi->g_w[t]; e.g_nodes[t] = epi->g_nodes[t]; }
-        e.transpose_out = epi->transpose_out;
-        e.gmax_out = epi->group_max > 1 ? epi->group_max_out : nullptr;
-        e.gmax_dst = e.gmax_out ? e.gmax_out : Y;
-        for (int t = 0; t < 2; ++t) {
-            e.g_k[t] = e.g_table[t] ? epi->g_k[t] : 0;
-            DI2P_CHECK_ARG(e.g_k[t] >= 0 && e.g_k[t] <= DI2P_MAX_GK, "g_k must be in [0, DI2P_MAX_GK]");
-            DI2P_CHECK_ARG(!e.g_table[t] || (e.g_idx[t] && e.g_k[t] >= 1 && e.g_nodes[t] >= 1), "gathered table without index / k / nodes");
-        }
-        DI2P_CHECK_ARG(!e.transpose_out || e.group_max == 1, "transpose_out excludes group_max");
-    }
-    if (e.group_max > 1) {
-        const int g = e.group_max;
-        DI2P_CHECK_ARG((g & (g - 1)) == 0 && g <= 32 && N % g == 0, "group_max must be a power of two <= 32 dividing N");
-    }
+    EpiDev e;
+    if (x3_epilogue(__func__, epi, Y, M, N, e)) return -1;
     bool dense = true;
     for (int i = 0; i < n_src; ++i)
         dense = dense && srcs[i].mode == DI2P_SRC_DENSE && srcs[i].row_stride % 4 == 0 && srcs[i].batch_stride % 4 == 0 && aligned16(srcs[i].ptr);
     const int Mp = di2p_cdiv(M, X3_BM) * X3_BM;
     const dim3 grid(di2p_cdiv(N, X3_BN), di2p_cdiv(M, X3_BM), B);
-    if (dense) hipLaunchKernelGGL(pointwise_gemm_x3_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, s, (const u32x4_t*)Wp, Y, M, K, N, Mp, e);
-    else hipLaunchKernelGGL(pointwise_gemm_x3_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, s, (const u32x4_t*)Wp, Y, M, K, N, Mp, e);
+    const hipStream_t st = (hipStream_t)stream;
+    const u32x4_t* W = (const u32x4_t*)Wp;
+    if (dense && e.planes) hipLaunchKernelGGL((pointwise_gemm_x3_kernel<true, true>), grid, dim3(256), 0, st, s, W, Y, M, K, N, Mp, e);
+    else if (dense) hipLaunchKernelGGL((pointwise_gemm_x3_kernel<true, false>), grid, dim3(256), 0, st, s, W, Y, M, K, N, Mp, e);
+    else if (e.planes) hipLaunchKernelGGL((pointwise_gemm_x3_kernel<false, true>), grid, dim3(256), 0, st, s, W, Y, M, K, N, Mp, e);
+    else hipLaunchKernelGGL((pointwise_gemm_x3_kernel<false, false>), grid, dim3(256), 0, st, s, W, Y, M, K, N, Mp, e);
+    DI2P_RETURN_LAUNCH();
+}
+
+extern "C" long long di2p_bf16x3_planes_bytes(int B, int C, int N) {
+    if (B < 0 || C < 4 || C % 4 || N < 1) return 0;
+    return (long long)B * 3 * C * N * 2;
+}
+
+// di2p_pointwise_gemm_x3 for ONE dense source given as the split planes a planes_out epilogue wrote (of a layer with M = this K rows and the
+// same N): u16[B][3][K/4][N][4].  K % 32 == 0, N % 128 == 0; same epilogues; the same bits as the fp32-source entry point on the same values.
+extern "C" int di2p_pointwise_gemm_x3p(const void* planes, const void* Wp, float* Y, int B, int M, int K, int N,
+                                       const di2p_epilogue_t* epi, void* stream) {
+    DI2P_CHECK_ARG(planes && Wp && aligned16(planes) && aligned16(Wp), "null / misaligned pointer");
+    DI2P_CHECK_ARG(B >= 0 && M >= 4 && M % 4 == 0, "needs M % 4 == 0");
+    DI2P_CHECK_ARG(K >= X3_BK && K % X3_BK == 0 && N >= X3_BN && N % X3_BN == 0, "planes source: K % 32 == 0 and N % 128 == 0");
+    DI2P_CHECK_ARG((long long)3 * K * N * 2 < (1ll << 31), "a frame's planes must fit 31 bits");
+    if (B == 0) return 0;
+    EpiDev e;
+    if (x3_epilogue(__func__, epi, Y, M, N, e)) return -1;
+    const int Mp = di2p_cdiv(M, X3_BM) * X3_BM;
+    const dim3 grid(N / X3_BN, di2p_cdiv(M, X3_BM), B);
+    const hipStream_t st = (hipStream_t)stream;
+    if (e.planes) hipLaunchKernelGGL(pointwise_gemm_x3p_kernel<true>, grid, dim3(256), 0, st, (const u32x4_t*)planes, (const u32x4_t*)Wp, Y, M, K, N, Mp, e);
+    else hipLaunchKernelGGL(pointwise_gemm_x3p_kernel<false>, grid, dim3(256), 0, st, (const u32x4_t*)planes, (const u32x4_t*)Wp, Y, M, K, N, Mp, e);
     DI2P_RETURN_LAUNCH();
 }
 
@@ -1209,7 +1424,7 @@ extern "C" int di2p_point_head(const di2p_src_t* srcs, int n_src, const float* W
     DI2P_CHECK_ARG(srcs && n_src >= 1 && n_src <= DI2P_MAX_SRC && W0t && W1t && W2t && out && epi0, "null pointer");
     DI2P_CHECK_ARG(M == HEAD_M && P >= 1 && P <= 4, "fused head: hidden width 128, at most 4 outputs (use the separate layers otherwise)");
     DI2P_CHECK_ARG(B >= 0 && N >= 4 && N % 4 == 0 && K0 >= 1, "bad size");
-    DI2P_CHECK_ARG(epi0->group_max <= 1 && !epi0->transpose_out, "fused head: layer 0 takes scale/shift/relu/bias/gathered only");
+    DI2P_CHECK_ARG(epi0->group_max <= 1 && !epi0->transpose_out && !epi0->planes_out, "fused head: layer 0 takes scale/shift/relu/bias/gathered only");
     if (B == 0) return 0;
     SrcDev s{};
     int ctot = 0;
@@ -1276,7 +1491,7 @@ extern "C" int di2p_point_chain(const di2p_src_t* srcs, int n_src, const float* 
     DI2P_CHECK_ARG(M == 32 || M == 64, "fused chain: width 32 or 64 (use the separate layers otherwise)");
     DI2P_CHECK_ARG(K0 <= M, "fused chain: at most M input channels");
     DI2P_CHECK_ARG(B >= 0 && N >= 1 && K0 >= 1, "bad size");
-    DI2P_CHECK_ARG(epi0->group_max <= 1 && !epi0->transpose_out, "fused chain: layer 0 takes scale/shift/relu/bias/gathered only");
+    DI2P_CHECK_ARG(epi0->group_max <= 1 && !epi0->transpose_out && !epi0->planes_out, "fused chain: layer 0 takes scale/shift/relu/bias/gathered only");
     if (B == 0) return 0;          // an empty batch has no output buffer to check
     DI2P_CHECK_ARG(Y && srcs[0].ptr && srcs[0].channels == K0 && srcs[0].mode == DI2P_SRC_DENSE, "fused chain: one dense source of K0 channels");
     DI2P_CHECK_ARG((long long)srcs[0].channels * srcs[0].row_stride < (1ll << 31), "per-frame source extent must fit 31 bits");

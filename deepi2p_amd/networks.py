@@ -256,16 +256,22 @@ class PCEncoder(_PackedModule):
         coord = ops.gather_neighbors(cluster_mean, node_b, knn_I)
         y = _run_split_layer([Src(coord)], (0, 3), node_a_features, (3, 3 + node_a_features.shape[1]), knn_I.view(B, Mb * K),
                              p["layers_before.0"], Mb * K)
-        if K & (K - 1) == 0 and K <= 32:      # the max over the K neighbours comes out of the same launch as y itself
-            y, fmax = _run_layer([Src(y)], p["layers_before.1"], Mb * K, group_max=K, also_full=True)
+        # consecutive bf16x3 layers hand their activations on already split (ops.X3Planes: the same bits, the split out of the consumers' K loops)
+        pow2 = K & (K - 1) == 0 and K <= 32
+        Cb1 = p["layers_before.1"][0].shape[1]
+        pl = [pow2 and ops.x3_planes_link(p["layers_before.1"], p["layers_after.0"][0][Cb1:2 * Cb1], B, Mb * K),
+              pow2 and ops.x3_planes_link(p["layers_after.0"], p["layers_after.1"][0], B, Mb * K)]
+        if pow2:                              # the max over the K neighbours comes out of the same launch as y itself
+            y, fmax = _run_layer([Src(y)], p["layers_before.1"], Mb * K, group_max=K, also_full=True, planes_out=pl[0])
             Cb = y.shape[1]
         else:
             y = _run_layer([Src(y)], p["layers_before.1"], Mb * K)
             Cb = y.shape[1]
             fmax = ops.channel_max(y.view(B, Cb * Mb, K)).view(B, Cb, Mb)
-        y = _run_split_layer([Src(y)], (Cb, 2 * Cb), fmax, (0, Cb), self._group_index(B, Mb, K, pc.device), p["layers_after.0"], Mb * K)
-        if K & (K - 1) == 0 and K <= 32:
-            node_b_features = _run_layer([Src(y)], p["layers_after.1"], Mb * K, group_max=K)
+        y = _run_split_layer([y if pl[0] else Src(y)], (Cb, 2 * Cb), fmax, (0, Cb), self._group_index(B, Mb, K, pc.device), p["layers_after.0"], Mb * K,
+                             planes_out=pl[1])
+        if pow2:
+            node_b_features = _run_layer([y if pl[1] else Src(y)], p["layers_after.1"], Mb * K, group_max=K)
         else:
             y = _run_layer([Src(y)], p["layers_after.1"], Mb * K)
             node_b_features = ops.channel_max(y.view(B, y.shape[1] * Mb, K)).view(B, y.shape[1], Mb)

@@ -132,6 +132,27 @@ class Src:
         self.t, self.mode, self.gidx, self.group = t, mode, gidx, group
 
 
+class X3Planes:
+    """An activation f32[B,C,N] held ALREADY SPLIT for the bf16x3 kernel that contracts over its channels: u16[B,3,C/4,N,4], the three exact bf16
+    terms of every value, four consecutive channels of one column per 8 bytes (di2p_epilogue_t.planes_out; include/deepi2p_hip.h).  Written
+    by pointwise_gemm(..., planes_out=True), read by pointwise_gemm([X3Planes], ...); float() gives the fp32 values back (tests)."""
+
+    def __init__(self, t, C, N):
+        self.t, self.C, self.N = t, C, N
+        self.shape = (t.shape[0], C, N)
+
+    @staticmethod
+    def ok(C, N):
+        """Can a layer with C output rows and N columns hand its output on as planes (to a consumer with K = C)?"""
+        return C % 32 == 0 and N % 128 == 0 and 3 * C * N * 2 < (1 << 31)
+
+    def float(self):
+        B = self.t.shape[0]
+        w = self.t.view(torch.int16).view(B, 3, self.C // 4, self.N, 4).to(torch.int32) << 16
+        f = w.view(torch.float32)
+        return ((f[:, 2] + f[:, 1]) + f[:, 0]).permute(0, 1, 3, 2).reshape(B, self.C, self.N)
+
+
 def _fill_srcs(srcs):
     arr = (SrcT * len(srcs))()
     for i, s in enumerate(srcs):
@@ -264,17 +285,44 @@ def _x3_operand(Wt, B, M, N, x3):
     return Wp
 
 
+def x3_planes_link(producer, consumer_Wt, B, N):
+    """Should `producer` (a (Wt, scale, shift, act) layer) hand its [B, M, N] output to the layer with weights consumer_Wt [K = M, M2] as
+    split planes?  Both must run on the bf16x3 kernel by the automatic rule, the shapes must fit X3Planes, and the knob `pw_x3_planes` be on."""
+    Wt = producer[0]
+    M = Wt.shape[1]
+    if _lib.get_option("pw_x3_planes") == 0 or consumer_Wt.shape[0] != M or not X3Planes.ok(M, N):
+        return False
+
+    def auto(W):
+        Kc, Mc = W.shape
+        return (Kc >= X3_MIN_K and Mc % 128 == 0 and N % 4 == 0 and ((N + 127) // 128) * (Mc // 128) >= 8 and not W.requires_grad
+                and _lib.get_option("pw_x3") != 0 and W.is_contiguous())
+
+    return auto(Wt) and auto(consumer_Wt)
+
+
 def pointwise_gemm(srcs, Wt, M, N, scale=None, shift=None, batch_bias=None, relu=False, group_max=1, gathered=None,
-                   transpose_out=False, also_full=False, x3=None):
+                   transpose_out=False, also_full=False, x3=None, planes_out=False):
     """Y[b] = epi(Wt^T @ concat(srcs)[b]).  srcs: list of Src; Wt f32[K,M].  gathered: optional list of up
     to two (table f32[B,nodes,M] node-major, idx i32[B,N,k], w f32[B,N,k]).  transpose_out: Y is f32[B,N,M].
     group_max > 1 returns the group maxima; with also_full=True it returns (full Y, maxima) from the same launch.
     x3: run the contraction on the bf16x3 kernel (exact three-way bf16 split of both operands, fp32 accumulation; None = for the GEMM-shaped
-    layers, K >= 128 and M % 128 == 0, unless the knob `pw_x3` is 0)."""
+    layers, K >= 128 and M % 128 == 0, unless the knob `pw_x3` is 0).
+    planes_out (bf16x3 layers only): the full-size output comes back as X3Planes -- already split for the bf16x3 layer that consumes it as
+    `srcs=[planes]` (bit-identical to handing the fp32 output on; the split leaves the consumer's K loop)."""
     B = srcs[0].t.shape[0]
     K = Wt.shape[0]
+    from_planes = isinstance(srcs[0], X3Planes)
+    if from_planes:
+        if len(srcs) != 1 or srcs[0].C != K or srcs[0].N != N or srcs[0].t.device != Wt.device:
+            raise RuntimeError("a split-planes source must be the only source, with K channels and N columns, on the weights' device")
+        x3 = True
+    if planes_out and (transpose_out or not X3Planes.ok(M, N)):
+        raise RuntimeError("planes_out needs M % 32 == 0, N % 128 == 0 and no transpose_out")
     Wp = _x3_operand(Wt, B, M, N, x3)
-    arr = _fill_srcs(srcs)
+    if planes_out and Wp is None:
+        raise RuntimeError("planes_out: only the bf16x3 kernels write split planes")
+    arr = None if from_planes else _fill_srcs(srcs)
     e = EpilogueT()
     e.scale, e.shift, e.batch_bias = ptr(scale), ptr(shift), ptr(batch_bias)
     e.relu, e.group_max = int(bool(relu)), int(group_max)
@@ -282,16 +330,32 @@ def pointwise_gemm(srcs, Wt, M, N, scale=None, shift=None, batch_bias=None, relu
     e.transpose_out = int(bool(transpose_out))
     Nout = N // group_max if group_max > 1 else N
     Ymax = None
-    if also_full and group_max > 1:
+    if planes_out:
+        # the full-size output as split planes; with group_max > 1 the maxima come out of the same launch (also_full or not: there is no
+        # maxima-only planes output)
+        if group_max > 1 and not also_full:
+            raise RuntimeError("planes_out with group_max > 1 returns (planes, maxima): pass also_full=True")
+        Y = X3Planes(torch.empty((_lib.load().di2p_bf16x3_planes_bytes(B, M, N),), dtype=torch.uint8, device=Wt.device).view(B, -1), M, N)
+        e.planes_out = ptr(Y.t)
+        if group_max > 1:
+            Ymax = torch.empty((B, M, Nout), dtype=_f32, device=Wt.device)
+            e.group_max_out = ptr(Ymax)
+        y_ptr = None
+    elif also_full and group_max > 1:
         Y = torch.empty((B, M, N), dtype=_f32, device=Wt.device)
         Ymax = torch.empty((B, M, Nout), dtype=_f32, device=Wt.device)
         e.group_max_out = ptr(Ymax)
+        y_ptr = ptr(Y)
     else:
         Y = torch.empty((B, Nout, M) if transpose_out else (B, M, Nout), dtype=_f32, device=Wt.device)
+        y_ptr = ptr(Y)
     if Wp is not None:
         if _lib.WORK is not None:
             _lib.WORK["di2p_pointwise_gemm_x3"] = _lib.WORK.get("di2p_pointwise_gemm_x3", 0) + B * M * K * N
-        call("di2p_pointwise_gemm_x3", arr, len(srcs), ptr(Wp), ptr(Y), B, M, K, N, ctypes.byref(e), stream())
+        if from_planes:
+            call("di2p_pointwise_gemm_x3p", ptr(srcs[0].t), ptr(Wp), y_ptr, B, M, K, N, ctypes.byref(e), stream())
+        else:
+            call("di2p_pointwise_gemm_x3", arr, len(srcs), ptr(Wp), y_ptr, B, M, K, N, ctypes.byref(e), stream())
         return (Y, Ymax) if Ymax is not None else Y
     if _lib.WORK is not None:
         _lib.WORK["di2p_pointwise_gemm"] = _lib.WORK.get("di2p_pointwise_gemm", 0) + B * M * K * N

@@ -130,6 +130,12 @@ typedef struct {
     int transpose_out;         /* 1: Y is written f32[B,N,M] (needs M % 4 == 0, group_max == 1) */
     float* group_max_out;      /* with group_max > 1: NULL -> Y holds the maxima [B,M,N/group_max]; else Y is written in full
                                   [B,M,N] and the maxima go here (layers_pc.py:809-813 needs both) */
+    void* planes_out;          /* (ABI 6; the bf16x3 entry points only, NULL elsewhere) not NULL: the full-size output [B,M,N] is written
+                                  HERE, already split for the layer that contracts over it, instead of to Y as fp32:
+                                  u16[B][3][M/4][N][4] = three bf16 planes (x = x1 + x2 + x3, exact), four consecutive rows of one
+                                  column per 8 bytes; di2p_bf16x3_planes_bytes(B, M, N) bytes, 16-byte aligned, M % 4 == 0, no
+                                  transpose_out.  Y then only receives the group maxima (group_max > 1 and group_max_out == NULL) and
+                                  may be NULL otherwise. */
 } di2p_epilogue_t;
 
 int di2p_pointwise_gemm(const di2p_src_t* srcs_host, int n_src, const float* Wt, float* Y,
@@ -143,6 +149,14 @@ long long di2p_bf16x3_packed_bytes(int K, int M);
 int di2p_bf16x3_pack(const float* Wt, int K, int M, void* Wp, void* stream);
 int di2p_pointwise_gemm_x3(const di2p_src_t* srcs_host, int n_src, const void* Wp, float* Y,
                            int B, int M, int K, int N, const di2p_epilogue_t* epi_host, void* stream);
+/* A chain of such layers (GeneralKNNFusionModule's layers_before.1 -> layers_after.0 -> layers_after.1, models/layers_pc.py:779-818) hands
+ * its activations on ALREADY SPLIT: the producer's epilogue writes planes_out (6 bytes per value instead of 4), the consumer stages them into
+ * LDS without arithmetic -- the split leaves the K loop and is done once per value instead of once per 128-row block of every consumer.
+ * `planes` = a planes_out of a layer with K rows and the same N; K % 32 == 0, N % 128 == 0.  Same epilogues (planes_out included) and, on the
+ * same values, the same bits as di2p_pointwise_gemm_x3 with that layer's fp32 output as its one dense source. */
+long long di2p_bf16x3_planes_bytes(int B, int C, int N);
+int di2p_pointwise_gemm_x3p(const void* planes, const void* Wp, float* Y,
+                            int B, int M, int K, int N, const di2p_epilogue_t* epi_host, void* stream);
 
 /* Y[b,m] = sum_k Wt[k0+k, m] * v[b,k]  (the broadcast part of a concatenated input, folded into
  * batch_bias: networks_united.py:139-155,170-187 expand()s).  v f32[B,Kv]. */

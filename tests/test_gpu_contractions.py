@@ -1,6 +1,8 @@
 """GPU parity of the fp32-MFMA contractions (pointwise GEMM with its virtual-concat loader and fused
 epilogues, implicit-GEMM conv, pooling) vs plain PyTorch fp32 on CPU.  Tolerance: fp32 round-off of a
 K-term dot product, |err| <= 2e-6 * K^0.5 * max|out| + 1e-6 (stated per test)."""
+import ctypes
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -341,3 +343,73 @@ def test_bf16x3_cache_entries_live_and_die_with_their_operand(dev):
     del Wt, y
     gc.collect()
     assert not ops._X3_CACHE                              # expired with the operand
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N", [(2, 256), (3, 2048)])
+def test_bf16x3_split_planes_chain_is_bit_identical_to_fp32_handover(dev, B, N):
+    """A chain of bf16x3 layers (GeneralKNNFusionModule, layers_pc.py:779-818: 256 -> 256 (+ max over the 16 neighbours) -> 512 (+ gathered table)
+    -> 256 (max only)) may hand its activations on ALREADY SPLIT (di2p_epilogue_t.planes_out -> di2p_pointwise_gemm_x3p): the planes must hold
+    exactly the fp32 values the fp32 hand-over stores, and every consumer must produce the same bits from them."""
+    from deepi2p_amd import ops
+    g = torch.Generator().manual_seed(77 + N)
+    x = (torch.randn(B, 256, N, generator=g) * (1.0 + 3.0 * torch.rand(1, 256, 1, generator=g))).to(dev)
+
+    def layer(K, M):
+        W = (torch.randn(K, M, generator=g) / K ** 0.5).to(dev)
+        return W, (torch.rand(M, generator=g) + 0.5).to(dev), torch.randn(M, generator=g).to(dev)
+
+    (W1, s1, h1), (W2, s2, h2), (W3, s3, h3) = layer(256, 256), layer(256, 512), layer(512, 256)
+    tab = torch.randn(B, N // 16, 512, generator=g).to(dev)
+    gidx = (torch.arange(N, dtype=torch.int32) // 16).unsqueeze(0).expand(B, -1).contiguous().to(dev)
+    gat = [(tab, gidx.reshape(B, N, 1), None)]
+
+    def chain(planes):
+        y1, m1 = ops.pointwise_gemm([ops.Src(x)], W1, 256, N, scale=s1, shift=h1, relu=True, group_max=16, also_full=True, x3=True, planes_out=planes)
+        y2 = ops.pointwise_gemm([y1 if planes else ops.Src(y1)], W2, 512, N, scale=s2, shift=h2, relu=True, gathered=gat, x3=True, planes_out=planes)
+        y3 = ops.pointwise_gemm([y2 if planes else ops.Src(y2)], W3, 256, N, scale=s3, shift=h3, relu=False, group_max=16, x3=True)
+        return y1, m1, y2, y3
+
+    a1, am, a2, a3 = chain(False)
+    p1, pm, p2, p3 = chain(True)
+    assert isinstance(p1, ops.X3Planes) and isinstance(p2, ops.X3Planes) and p1.shape == (B, 256, N) and p2.shape == (B, 512, N)
+    assert torch.equal(p1.float(), a1) and torch.equal(pm, am)
+    assert torch.equal(p2.float(), a2)
+    assert torch.equal(p3, a3)
+    # a plain (no epilogue extras) planes consumer with a full-size fp32 output, too
+    yp = ops.pointwise_gemm([p2], W3, 256, N)
+    yf = ops.pointwise_gemm([ops.Src(a2)], W3, 256, N, x3=True)
+    assert torch.equal(yp, yf)
+
+
+@pytest.mark.gpu
+def test_bf16x3_split_planes_argument_checks(dev):
+    from deepi2p_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 256, 256, generator=g).to(dev)
+    W = torch.randn(256, 256, generator=g).to(dev)
+    with pytest.raises(RuntimeError):                                # N % 128 != 0
+        ops.pointwise_gemm([ops.Src(x[:, :, :192].contiguous())], W, 256, 192, x3=True, planes_out=True)
+    with pytest.raises(RuntimeError):                                # the fp32 kernel does not write planes
+        ops.pointwise_gemm([ops.Src(x)], W, 256, 256, x3=False, planes_out=True)
+    with pytest.raises(RuntimeError):                                # no transposed planes
+        ops.pointwise_gemm([ops.Src(x)], W, 256, 256, x3=True, planes_out=True, transpose_out=True)
+    pl = ops.pointwise_gemm([ops.Src(x)], W, 256, 256, x3=True, planes_out=True)
+    with pytest.raises(RuntimeError):                                # planes are the ONLY source, with matching K and N
+        ops.pointwise_gemm([pl, ops.Src(x)], torch.randn(512, 256).to(dev), 256, 256)
+    with pytest.raises(RuntimeError):
+        ops.pointwise_gemm([pl], torch.randn(128, 256).to(dev), 256, 256)
+    # the C entry points refuse what the host layer would never send
+    e = _lib.EpilogueT()
+    e.group_max = 1
+    e.planes_out = pl.t.data_ptr()
+    y = torch.empty(1, 256, 256, device=dev)
+    arr = ops._fill_srcs([ops.Src(x)])
+    with pytest.raises(_lib.DeepI2PHipError):                        # fp32 entry point + planes_out
+        _lib.call("di2p_pointwise_gemm", arr, 1, W.data_ptr(), y.data_ptr(), 1, 256, 256, 256, ctypes.byref(e), _lib.stream())
+    Wp = ops.bf16x3_pack(W)
+    with pytest.raises(_lib.DeepI2PHipError):                        # K % 32 != 0
+        _lib.call("di2p_pointwise_gemm_x3p", pl.t.data_ptr(), Wp.data_ptr(), y.data_ptr(), 1, 256, 200, 256, None, _lib.stream())
+    with pytest.raises(_lib.DeepI2PHipError):                        # Y == NULL without planes_out
+        _lib.call("di2p_pointwise_gemm_x3p", pl.t.data_ptr(), Wp.data_ptr(), None, 1, 256, 256, 256, None, _lib.stream())
+    assert _lib.load().di2p_bf16x3_planes_bytes(2, 256, 2048) == 2 * 3 * 256 * 2048 * 2

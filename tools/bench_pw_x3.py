@@ -1,5 +1,6 @@
 """Where the time of the bf16x3 pointwise kernel goes: K sweep (slope = K loop, intercept = prologue + epilogue + launch rounds) per epilogue
-variant, at the column counts of the kNN-fusion layers (32 frames x 2048 columns).  REPS=20 python tools/bench_pw_x3.py"""
+variant, at the column counts of the kNN-fusion layers (32 frames x 2048 columns).  REPS=20 [PLANES=1] python tools/bench_pw_x3.py
+(PLANES=1: the source handed over as split bf16 planes, di2p_pointwise_gemm_x3p)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -34,6 +35,9 @@ for M in (256, 512):
         for K in (32, 128, 256, 512):
             x = torch.randn(B, K, N, device=dev)
             Wt = torch.randn(K, M, device=dev) / K ** 0.5
-            t = timed(lambda: ops.pointwise_gemm([ops.Src(x)], Wt, M, N, x3=True, **kw))
+            src = ops.Src(x)
+            if os.environ.get("PLANES"):     # the activation handed over as split planes (made by a layer of K output rows)
+                src = ops.pointwise_gemm([ops.Src(x)], torch.randn(K, K, device=dev), K, N, x3=True, planes_out=True)
+            t = timed(lambda: ops.pointwise_gemm([src], Wt, M, N, x3=True, **kw))
             row.append("K=%3d %6.1f us (%5.1f TF)" % (K, t, 2.0 * B * M * K * N / t / 1e6))
         print("M=%d %-18s %s" % (M, name, "  ".join(row)), flush=True)
