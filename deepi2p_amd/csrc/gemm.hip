@@ -131,12 +131,6 @@ struct LoaderConcat4 {
     __device__ __forceinline__ void fix(float4&, int, const Info&) const {}
 };
 
-#ifndef DI2P_X3P_B128
-#define DI2P_X3P_B128 0          // experiment: planes as [plane][K/8][N] x 16 bytes (one ds_read_b128 per fragment)
-#endif
-#ifndef DI2P_X3P_ORDER
-#define DI2P_X3P_ORDER 0         // experiment: 1 = the K-step's second weight-fragment request in FRONT of the next step's plane rows
-#endif
 // bf16x3 (see the section of that name below): the exact three-way split of fp32 values into truncated bf16 terms
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -336,22 +330,14 @@ struct EpiPointwiseT {
     // layer's rows (pointwise_gemm_x3p_kernel stages them without touching them); M % 4 == 0 (host-checked)
     __device__ __forceinline__ void store_planes(int mrow0, int n, const float (&v)[16]) const {
         const long long ps = (long long)(M >> 2) * N;               // one plane of one frame, in quads
-#if DI2P_X3P_B128
-        u32x2_t* p = e.planes + (long long)b * 3 * ps + 2 * n;      // [plane][M/8][N] x 16 bytes: 8 consecutive rows of one column
-#else
         u32x2_t* p = e.planes + (long long)b * 3 * ps + n;
-#endif
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int m = mrow0 + 8 * g;
             if (m < M) {
                 u32x2_t p1, p2, p3;
                 x3_split4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], p1, p2, p3);
-#if DI2P_X3P_B128
-                u32x2_t* q = p + (long long)(m >> 3) * 2 * N + ((m >> 2) & 1);
-#else
                 u32x2_t* q = p + (long long)(m >> 2) * N;
-#endif
                 q[0] = p1; q[ps] = p2; q[2 * ps] = p3;
             }
         }
@@ -1070,8 +1056,15 @@ __global__ __launch_bounds__(256, 2) void pointwise_gemm_x3_kernel(SrcDev srcs, 
 // what a PLANES epilogue of the producing layer wrote -- the LDS layout of the kernel above, row for row.  A K-step is 24 rows of 1 KB
 // (plane, k-quad): six per wave, one 16-byte load and one 16-byte LDS store per lane and row, no arithmetic on the way (the split costs the
 // fp32-source kernel 88 of its 225 vector instructions per K-step and wave, the generic concatenating loader's addressing about 80 more, and
-// every 128-row workgroup of a column tile repeats both).  Same A fragments, same products in the same order: bit-identical to the
-// fp32-source kernel on the same values.  Needs K % 32 == 0 and N % 128 == 0 (host-checked).
+// every 128-row workgroup of a column tile repeats both: 52 are left here).  Same A fragments, same products in the same order: bit-identical
+// to the fp32-source kernel on the same values.  Needs K % 32 == 0 and N % 128 == 0 (host-checked).
+// What the K loop is bound by (round 6, profiles/r06_c25...c29: K sweeps of this kernel with parts of the loop removed): NOT the vector
+// instructions (this kernel's loop runs at the fp32-source kernel's rate), not the barrier (removed: no change), not the request order or
+// distance (weight fragments in front of the plane rows, or a whole K-step ahead in a second register set: no change), not the fragments'
+// 48-byte interleave (plane-major weights: no change), not ds_read2_b64 against ds_read_b128 fragments (a 16-byte plane layout: no change);
+// it is the vector-memory path itself: without the weight-fragment requests the loop is 24 % faster, without the plane rows 13 %, without both
+// 2.4x (1.65 PFLOP/s of bf16 products), with the fragments coming from an L1-resident range 13 %: 144 KB per K-step and compute unit (the
+// three planes make every operand byte count three times) against 3072 matrix cycles per SIMD.
 template <bool PLANES>
 __global__ __launch_bounds__(256, 2) void pointwise_gemm_x3p_kernel(const u32x4_t* __restrict__ P, const u32x4_t* __restrict__ Wp, float* __restrict__ Y,
                                                                      int M, int K, int N, int Mp, EpiDev epi) {
@@ -1084,20 +1077,11 @@ __global__ __launch_bounds__(256, 2) void pointwise_gemm_x3p_kernel(const u32x4_
     const int kq = K >> 2, nh = N >> 1;                      // k-quads per plane; 16-byte elements per row
     const u32x4_t* Pf = P + (long long)b * 3 * kq * nh + (n_blk >> 1) + lane;
     int roff[6];
-#if DI2P_X3P_B128
-    // 12 rows of 2 KB (plane, k-oct): three per wave, two 16-byte columns (lane, lane + 64) per lane and row
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int row = wave * 3 + (i >> 1);
-        roff[i] = ((row >> 2) * (kq >> 1) + (row & 3)) * 2 * nh + (i & 1) * 64 + (n_blk >> 1);    // Pf already holds n_blk / 2 + lane
-    }
-#else
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int row = wave * 6 + i;
         roff[i] = ((row >> 3) * kq + (row & 7)) * nh;
     }
-#endif
     u32x4_t st[6];
     auto gload = [&](int t) {
         const u32x4_t* pt = Pf + (long long)t * 8 * nh;
@@ -1133,12 +1117,8 @@ __global__ __launch_bounds__(256, 2) void pointwise_gemm_x3p_kernel(const u32x4_
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int n = wn * 64 + j * 32 + l31;
-#if DI2P_X3P_B128
-                bf[j][q] = reinterpret_cast<const u32x4_t*>(&Bs[buf][0][0][0][0])[(q * 4 + 2 * sub + half) * X3_BN + n];
-#else
                 const u32x2_t lo = Bs[buf][q][2 * sub + half][0][n], hi = Bs[buf][q][2 * sub + half][1][n];
                 bf[j][q] = u32x4_t{lo.x, lo.y, hi.x, hi.y};
-#endif
             }
         DI2P_MFMA_BEGIN();
 #define DI2P_X3_PROD(QA, QB)                                                                                                          \
@@ -1156,14 +1136,8 @@ __global__ __launch_bounds__(256, 2) void pointwise_gemm_x3p_kernel(const u32x4_
     __syncthreads();
     for (int t = 0; t + 1 < T; ++t) {
         const int buf = t & 1;
-#if DI2P_X3P_ORDER
-        aload(t * X3_KG + 2, 1);          // memory returns a wave's loads in order: the fragments of sub-step 1 must not queue behind the plane rows
-        gload(t + 1);
-        substep(buf, 0, 0, false);
-#else
         gload(t + 1);
         substep(buf, 0, t * X3_KG + 2, true);
-#endif
         substep(buf, 1, t * X3_KG + 4, true);
         sstore(buf ^ 1);
         __syncthreads();
@@ -1191,14 +1165,15 @@ __global__ __launch_bounds__(256) void bf16x3_pack_kernel(const float* __restric
     if (t >= (long long)(Kp / 8) * Mp) return;
     const int kg = (int)(t / Mp), m = (int)(t - (long long)kg * Mp);
     unsigned short* d = Wp + t * 24;
+    const long long ps = 8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int k = kg * 8 + i;
         const float a = (k < K && m < M) ? Wt[(long long)k * M + m] : 0.0f;
         const float a1 = x3_hi16(a), r1 = a - a1, a2 = x3_hi16(r1), r2 = r1 - a2;
-        d[0 * 8 + i] = (unsigned short)(__builtin_bit_cast(unsigned, a1) >> 16);
-        d[1 * 8 + i] = (unsigned short)(__builtin_bit_cast(unsigned, a2) >> 16);
-        d[2 * 8 + i] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+        d[0 * ps + i] = (unsigned short)(__builtin_bit_cast(unsigned, a1) >> 16);
+        d[1 * ps + i] = (unsigned short)(__builtin_bit_cast(unsigned, a2) >> 16);
+        d[2 * ps + i] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
     }
 }
 

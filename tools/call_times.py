@@ -24,9 +24,9 @@ _pg = ops.pointwise_gemm
 
 
 def tagged(srcs, Wt, M, Nn, **kw):
-    _lib.TIMED_TAG = "M=%d K=%d N=%d srcs=%s%s%s%s" % (M, Wt.shape[0], Nn, "+".join("%s%d" % ("dgG"[getattr(s, "mode", 0)] if hasattr(s, "mode") else "d", s.t.shape[1]) for s in srcs),
+    _lib.TIMED_TAG = "M=%d K=%d N=%d srcs=%s%s%s%s" % (M, Wt.shape[0], Nn, "+".join("%s%d" % ("dgG"[s.mode] if hasattr(s, "mode") else "p", getattr(s, "C", s.t.shape[1])) for s in srcs),
                                                       " gmax%d" % kw["group_max"] if kw.get("group_max", 1) > 1 else "", " gathered" if kw.get("gathered") else "",
-                                                      " T" if kw.get("transpose_out") else "")
+                                                      (" T" if kw.get("transpose_out") else "") + (" ->planes" if kw.get("planes_out") else ""))
     try:
         return _pg(srcs, Wt, M, Nn, **kw)
     finally:
