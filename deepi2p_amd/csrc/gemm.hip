@@ -1159,6 +1159,117 @@ __global__ __launch_bounds__(256, 2) void pointwise_gemm_x3p_kernel(const u32x4_
         for (int j = 0; j < 2; ++j) ep.store(m_blk + wm * 64 + i * 32 + 4 * half, n_blk + wn * 64 + j * 32 + l31, v[i][j]);
 }
 
+// The planes-source kernel with BOTH operands staged through LDS: a 256 x 128 tile, eight waves (4 x 2 of 64 x 64), one workgroup per
+// compute unit.  pointwise_gemm_x3p_kernel is bound by the vector-memory path (see its header: 144 KB per K-step and compute unit, the
+// weight fragments requested by both waves that share their rows); here a K-step moves the 256 rows' fragments ONCE (48 KB: four k-groups of
+// 12 contiguous KB, copied verbatim -- a fragment read is one ds_read_b128 at 48 bytes per lane, conflict-free) and the plane rows once per
+// 256 output rows instead of once per 128 (24 KB): 72 KB per K-step and compute unit for the same matrix work.  144 KB of LDS.
+// Same products in the same order per output element: bit-identical to the other two kernels.  Needs M % 256 == 0 on top of K % 32, N % 128.
+// Measured (profiles/r06_c30...c34): 5-8 % off the K loop (chain of the three kNN-fusion layers 323 -> 315 us), NOT the halving the byte count
+// suggests.  The same loop with its nine requests per wave as LDS-DMA (global_load_lds_dwordx4: no staging registers, no LDS stores), or with
+// those issued one by one between the product groups: the same time again.  Stamps in the loop: of ~8.3 k cycles per K-step and wave 1.5 k are
+// the wave's own matrix instructions; ~1.9 k go to ISSUING nine requests (the wave stalls at issue), 1.3 k waiting for them, 2.1 k at the barrier
+// for the slower waves.  Memory side: an L2 read takes 437 cycles on average (TCP_TCC_READ_REQ_LATENCY / REQ), the L1 is stalled on pending
+// requests 43 % of the time, the L2 channels are busy 82 %: each compute unit moves its 576 lines per K-step through a bounded number of
+// outstanding L1 misses.  What would change the regime is a tile with 2-4x the matrix work per staged byte (the 256 x 256 / one wave per SIMD
+// GEMM of cdna_hip_programming.md) -- not built: the three layers are 0.32 ms of a 5.8 ms step.
+constexpr int X3P8_A_EL = 4 * 256 * 3, X3P8_B_EL = 24 * 64, X3P8_BUF_EL = X3P8_A_EL + X3P8_B_EL;      // 16-byte elements per buffer (72 KB)
+constexpr int X3P8_LDS_BYTES = 2 * X3P8_BUF_EL * 16;
+
+template <bool PLANES>
+__global__ __launch_bounds__(512, 1) void pointwise_gemm_x3p8_kernel(const u32x4_t* __restrict__ P, const u32x4_t* __restrict__ Wp, float* __restrict__ Y,
+                                                                      int M, int K, int N, int Mp, EpiDev epi) {
+    extern __shared__ __attribute__((aligned(16))) u32x4_t lds8[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m_blk = blockIdx.y * 256, n_blk = blockIdx.x * X3_BN, b = blockIdx.z;
+    const int T = K / X3_BK;
+    const int kq = K >> 2, nh = N >> 1;                      // k-quads per plane; 16-byte elements per plane row
+    // plane rows: this thread moves k-quad `wave` of each of the three planes, columns 2 * lane, 2 * lane + 1
+    const u32x4_t* Pf = P + (long long)b * 3 * kq * nh + (long long)wave * nh + (n_blk >> 1) + lane;
+    // weight fragments: elements i * 512 + tid (i = 0..5) of the K-step's 4 x 768 (k-group, 256 rows x 3 planes)
+    const u32x4_t* Wf = Wp + (long long)m_blk * 3;
+    int aoff[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int e = i * 512 + tid, kg = e / 768;
+        aoff[i] = kg * Mp * 3 + (e - kg * 768);
+    }
+    u32x4_t sa[6], sb[3];
+    auto gload = [&](int t) {
+        const u32x4_t* wt = Wf + (long long)t * 4 * Mp * 3;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sa[i] = wt[aoff[i]];
+        const u32x4_t* pt = Pf + (long long)t * 8 * nh;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sb[i] = pt[(long long)i * kq * nh];
+    };
+    auto sstore = [&](int buf) {
+        u32x4_t* d = lds8 + buf * X3P8_BUF_EL;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i * 512 + tid] = sa[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) d[X3P8_A_EL + (i * 8 + wave) * 64 + lane] = sb[i];
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    auto substep = [&](int buf, int sub) __attribute__((always_inline)) {
+        const u32x4_t* d = lds8 + buf * X3P8_BUF_EL;
+        const u32x2_t* bq = reinterpret_cast<const u32x2_t*>(d + X3P8_A_EL);
+        u32x4_t af[2][3], bf[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) af[i][q] = d[((2 * sub + half) * 256 + wm * 64 + i * 32 + l31) * 3 + q];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int n = wn * 64 + j * 32 + l31;
+                const u32x2_t lo = bq[(q * 8 + (2 * sub + half) * 2) * X3_BN + n], hi = bq[(q * 8 + (2 * sub + half) * 2 + 1) * X3_BN + n];
+                bf[j][q] = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+            }
+        DI2P_MFMA_BEGIN();
+#define DI2P_X3_PROD(QA, QB)                                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                                      \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i][QA]), __builtin_bit_cast(bf16x8_t, bf[j][QB]), acc[i][j], 0, 0, 0);
+        DI2P_X3_PROD(2, 0) DI2P_X3_PROD(1, 1) DI2P_X3_PROD(0, 2)
+        DI2P_X3_PROD(1, 0) DI2P_X3_PROD(0, 1)
+        DI2P_X3_PROD(0, 0)
+#undef DI2P_X3_PROD
+        DI2P_MFMA_END();
+    };
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int t = 0; t + 1 < T; ++t) {
+        const int buf = t & 1;
+        gload(t + 1);
+        substep(buf, 0);
+        substep(buf, 1);
+        sstore(buf ^ 1);
+        __syncthreads();
+    }
+    substep((T - 1) & 1, 0);
+    substep((T - 1) & 1, 1);
+    EpiPointwiseT<-1, -1, PLANES> ep{epi, Y, b, M, N};
+    float v[2][2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            ep.template apply_pre<true>(m_blk + wm * 64 + i * 32 + 4 * half, min(n_blk + wn * 64 + j * 32 + l31, N - 1), acc[i][j], nullptr, v[i][j]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ep.store(m_blk + wm * 64 + i * 32 + 4 * half, n_blk + wn * 64 + j * 32 + l31, v[i][j]);
+}
+
 // Wt f32 [K][M] (k-major, what the fp32 kernels read) -> [Kp/8][Mp][3][8] bf16, zero filled outside K x M.  One thread per (k-group, m).
 __global__ __launch_bounds__(256) void bf16x3_pack_kernel(const float* __restrict__ Wt, unsigned short* __restrict__ Wp, int K, int M, int Kp, int Mp) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1385,8 +1496,15 @@ extern "C" int di2p_pointwise_gemm_x3p(const void* planes, const void* Wp, float
     EpiDev e;
     if (x3_epilogue(__func__, epi, Y, M, N, e)) return -1;
     const int Mp = di2p_cdiv(M, X3_BM) * X3_BM;
-    const dim3 grid(N / X3_BN, di2p_cdiv(M, X3_BM), B);
     const hipStream_t st = (hipStream_t)stream;
+    if (M % 256 == 0 && di2p_opt(DI2P_OPT_PW_X3_PLANES) != 2) {          // 256-row tiles, both operands through LDS (knob value 2: the 128-row kernel)
+        const dim3 grid(N / X3_BN, M / 256, B);
+        auto k = e.planes ? pointwise_gemm_x3p8_kernel<true> : pointwise_gemm_x3p8_kernel<false>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, X3P8_LDS_BYTES);
+        hipLaunchKernelGGL(k, grid, dim3(512), X3P8_LDS_BYTES, st, (const u32x4_t*)planes, (const u32x4_t*)Wp, Y, M, K, N, Mp, e);
+        DI2P_RETURN_LAUNCH();
+    }
+    const dim3 grid(N / X3_BN, di2p_cdiv(M, X3_BM), B);
     if (e.planes) hipLaunchKernelGGL(pointwise_gemm_x3p_kernel<true>, grid, dim3(256), 0, st, (const u32x4_t*)planes, (const u32x4_t*)Wp, Y, M, K, N, Mp, e);
     else hipLaunchKernelGGL(pointwise_gemm_x3p_kernel<false>, grid, dim3(256), 0, st, (const u32x4_t*)planes, (const u32x4_t*)Wp, Y, M, K, N, Mp, e);
     DI2P_RETURN_LAUNCH();

@@ -380,6 +380,16 @@ def test_bf16x3_split_planes_chain_is_bit_identical_to_fp32_handover(dev, B, N):
     yp = ops.pointwise_gemm([p2], W3, 256, N)
     yf = ops.pointwise_gemm([ops.Src(a2)], W3, 256, N, x3=True)
     assert torch.equal(yp, yf)
+    # the planes-source entry point has two kernels: 256-row tiles with both operands in LDS (M % 256 == 0: everything above) and 128-row
+    # tiles (any M % 4 == 0; knob pw_x3_planes = 2 forces it) -- the same bits from both
+    W4 = (torch.randn(512, 384, generator=g) / 512 ** 0.5).to(dev)
+    assert torch.equal(ops.pointwise_gemm([p2], W4, 384, N), ops.pointwise_gemm([ops.Src(a2)], W4, 384, N, x3=True))
+    _lib.set_option("pw_x3_planes", 2)
+    try:
+        q1, qm, q2, q3 = chain(True)
+        assert torch.equal(q1.t, p1.t) and torch.equal(qm, pm) and torch.equal(q2.t, p2.t) and torch.equal(q3, p3)
+    finally:
+        _lib.set_option("pw_x3_planes", 1)
 
 
 @pytest.mark.gpu
