@@ -384,6 +384,12 @@ def test_bf16x3_split_planes_chain_is_bit_identical_to_fp32_handover(dev, B, N):
     # tiles (any M % 4 == 0; knob pw_x3_planes = 2 forces it) -- the same bits from both
     W4 = (torch.randn(512, 384, generator=g) / 512 ** 0.5).to(dev)
     assert torch.equal(ops.pointwise_gemm([p2], W4, 384, N), ops.pointwise_gemm([ops.Src(a2)], W4, 384, N, x3=True))
+    # the general group-maximum path (not the 16-lane DPP one) and a per-frame bias row, planes out
+    bias = torch.randn(B, 256, generator=g).to(dev)
+    for grp in (8, 32):
+        fa, fm = ops.pointwise_gemm([ops.Src(x)], W1, 256, N, scale=s1, shift=h1, batch_bias=bias, group_max=grp, also_full=True, x3=True)
+        fp, pm2 = ops.pointwise_gemm([ops.Src(x)], W1, 256, N, scale=s1, shift=h1, batch_bias=bias, group_max=grp, also_full=True, x3=True, planes_out=True)
+        assert torch.equal(fp.float(), fa) and torch.equal(pm2, fm)
     _lib.set_option("pw_x3_planes", 2)
     try:
         q1, qm, q2, q3 = chain(True)
