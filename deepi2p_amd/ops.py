@@ -250,18 +250,23 @@ def bf16x3_pack(Wt):
     return Wp
 
 
+def _x3_auto(Wt, M, N):
+    """The automatic rule of _x3_operand: does the layer with weights Wt [K, M] on N columns per frame run on the bf16x3 kernel?"""
+    return (Wt.shape[0] >= X3_MIN_K and M % 128 == 0 and N % 4 == 0 and ((N + 127) // 128) * (M // 128) >= 8 and not Wt.requires_grad
+            and _lib.get_option("pw_x3") != 0)
+
+
 def _x3_operand(Wt, B, M, N, x3):
     """The packed operand if this layer runs on the bf16x3 kernel, else None.  x3: None = by shape and the library knob `pw_x3`; True / False force.
     Automatic rule: K >= 128, M % 128 == 0 and at least eight 128 x 128 workgroups PER FRAME -- a rule on the layer's shape only: a frame's
     result must not depend on the batch it is in (measured per layer of a 32-frame step,
     tools/call_times.py: 256x256x2048 135 -> 124 us, 512x256x2048 198 -> 139, 256x512x2048 211 -> 166, 1024x768x128 70 -> 55; the node-level
     layers with 128 workgroups or fewer are FASTER on the fp32 kernel's 64 x 64 tiles: 512x1024x128 48 vs 63 us, 128x512x128 19 vs 35)."""
-    K = Wt.shape[0]
     if x3 is None:
-        x3 = (K >= X3_MIN_K and M % 128 == 0 and N % 4 == 0 and ((N + 127) // 128) * (M // 128) >= 8 and not Wt.requires_grad
-              and _lib.get_option("pw_x3") != 0)
+        x3 = _x3_auto(Wt, M, N)
     if not x3:
         return None
+    K = Wt.shape[0]
     if M % 4 or N % 4 or not Wt.is_contiguous():
         raise RuntimeError("bf16x3 needs M % 4 == 0, N % 4 == 0 and a contiguous [K,M] weight")
     # an address is only an identity while the tensor that owns it is alive: the entry remembers (weakly) the base tensor it was made from --
@@ -292,13 +297,7 @@ def x3_planes_link(producer, consumer_Wt, B, N):
     M = Wt.shape[1]
     if _lib.get_option("pw_x3_planes") == 0 or consumer_Wt.shape[0] != M or not X3Planes.ok(M, N):
         return False
-
-    def auto(W):
-        Kc, Mc = W.shape
-        return (Kc >= X3_MIN_K and Mc % 128 == 0 and N % 4 == 0 and ((N + 127) // 128) * (Mc // 128) >= 8 and not W.requires_grad
-                and _lib.get_option("pw_x3") != 0 and W.is_contiguous())
-
-    return auto(Wt) and auto(consumer_Wt)
+    return all(_x3_auto(W, W.shape[1], N) and W.is_contiguous() for W in (Wt, consumer_Wt))
 
 
 def pointwise_gemm(srcs, Wt, M, N, scale=None, shift=None, batch_bias=None, relu=False, group_max=1, gathered=None,
@@ -312,7 +311,7 @@ def pointwise_gemm(srcs, Wt, M, N, scale=None, shift=None, batch_bias=None, relu
     `srcs=[planes]` (bit-identical to handing the fp32 output on; the split leaves the consumer's K loop)."""
     B = srcs[0].t.shape[0]
     K = Wt.shape[0]
-    from_planes = isinstance(srcs[0], X3Planes)
+    from_planes = any(isinstance(s, X3Planes) for s in srcs)
     if from_planes:
         if len(srcs) != 1 or srcs[0].C != K or srcs[0].N != N or srcs[0].t.device != Wt.device:
             raise RuntimeError("a split-planes source must be the only source, with K channels and N columns, on the weights' device")

@@ -414,6 +414,8 @@ def test_bf16x3_split_planes_argument_checks(dev):
     with pytest.raises(RuntimeError):                                # planes are the ONLY source, with matching K and N
         ops.pointwise_gemm([pl, ops.Src(x)], torch.randn(512, 256).to(dev), 256, 256)
     with pytest.raises(RuntimeError):
+        ops.pointwise_gemm([ops.Src(x), pl], torch.randn(512, 256).to(dev), 256, 256)
+    with pytest.raises(RuntimeError):
         ops.pointwise_gemm([pl], torch.randn(128, 256).to(dev), 256, 256)
     # the C entry points refuse what the host layer would never send
     e = _lib.EpilogueT()
