@@ -67,6 +67,9 @@ __device__ __forceinline__ void cx_split8(const float (&f)[8], u32x4_t& p1, u32x
     p3 = u32x4_t{cx_pack_hi(q[0], q[1]), cx_pack_hi(q[2], q[3]), cx_pack_hi(q[4], q[5]), cx_pack_hi(q[6], q[7])};
 }
 
+#ifndef DI2P_CX_CLK
+#define DI2P_CX_CLK 0
+#endif
 struct CxArgs {
     const float* x; const u32x4_t* Wp; const float* scale; const float* shift; const float* residual; float* y;
     const u32x4_t* Wp_ds; const float* scale_ds; const float* shift_ds; float* y_ds;      // fused 1x1 / stride-2 branch (DS instances)
@@ -85,6 +88,17 @@ struct CxArgs {
 // 0.75 ulp is a product of the same instruction): small products added to a large accumulator lose their low bits, with a bias.  Kept apart,
 // they meet an accumulator 2^-8 times smaller.  Measured against fp64 on the four stride-1 shapes: rms error 3.6e-7 -> 1.5e-7 (K = 576) ...
 // 9.1e-7 -> 3.6e-7 (K = 4608), below both fp32-MFMA kernels (4.2e-7 ... 6.3e-7); same speed.  Every shipped instance has it on.
+#if DI2P_CX_CLK
+// experiment: where a wave's lifetime goes (s_memtime stamps summed over all waves): [0] set-up + first patch + first weights up to the first
+// barrier, [1] the chunks' taps, [2] the chunks' closing barriers, [3] epilogue, [7] waves
+__device__ unsigned long long g_cx_clk[4096 * 4];          // one row per wave of the LAST launch (no atomics: they would be the epilogue)
+extern "C" int di2p_cx_clk(unsigned long long* out, int nwaves) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cx_clk), (size_t)nwaves * 32) == hipSuccess ? 0 : -1;
+}
+#define CX_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); clk_[k] += now_ - last_; last_ = now_; } while (0)
+#else
+#define CX_STAMP(k) do { } while (0)
+#endif
 template <int MF, int TM, int TN, int WM, int WN, int STRIDE, bool DS, bool DBUF, int ITEMS, int PWT, bool SA>
 __global__ __launch_bounds__(256, 1) void conv3x3_x3_kernel(const CxArgs a) {
     typedef Mma<MF> M;
@@ -94,6 +108,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3_kernel(const CxArgs a) {
     static_assert(!DS || STRIDE == 2, "the fused downsample branch belongs to the stride-2 layers");
     static_assert(!DBUF || ITEMS <= 6, "item k is fetched at tap k and written behind tap k + 3");
     static_assert(ITEMS <= 8, "one item per tap");
+#if DI2P_CX_CLK
+    unsigned long long clk_[4] = {0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+#endif
     const int PW = PWT ? PWT : a.PW, PWH = PWT ? (PWT + 1) / 2 : a.PWH;
     extern __shared__ __attribute__((aligned(16))) u32x4_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -273,12 +290,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3_kernel(const CxArgs a) {
             if (stores) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        CX_STAMP(1);
         if constexpr (STAGE && !DBUF) {
             __syncthreads();                  // every wave has read the patch of chunk c
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) stage_store(it, 0);
         }
         __syncthreads();
+        CX_STAMP(2);
     };
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) stage_load(it, 0);
@@ -287,6 +306,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3_kernel(const CxArgs a) {
     a_load(0, 0, 0);
     a_load(1, 1, 0);
     __syncthreads();
+    CX_STAMP(0);
     for (int c = 0; c + 1 < NC; ++c) chunk(c, std::true_type{});
     chunk(NC - 1, std::false_type{});
 
@@ -340,6 +360,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3_kernel(const CxArgs a) {
     if (a.residual) store(acc, a.scale, a.shift, a.residual, a.y, a.relu != 0, std::true_type{});
     else store(acc, a.scale, a.shift, a.residual, a.y, a.relu != 0, std::false_type{});
     if constexpr (DS) store(acc_ds, a.scale_ds, a.shift_ds, nullptr, a.y_ds, false, std::false_type{});
+#if DI2P_CX_CLK
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CX_STAMP(3);
+    if (lane == 0 && blockIdx.x * 4 + wave < 4096)
+        for (int k = 0; k < 4; ++k) g_cx_clk[(blockIdx.x * 4 + wave) * 4 + k] = clk_[k];
+#endif
 }
 
 struct CxCfg { int MF, TM, TN, WM, WN; };
