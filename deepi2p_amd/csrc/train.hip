@@ -344,6 +344,59 @@ __global__ __launch_bounds__(KmCfg::THREADS) void conv_dgrad_kernel(const float*
     mfma_gemm_block<KmCfg>(lds, la, lb, ep, K, blockIdx.y * KmCfg::BM, blockIdx.x * KmCfg::BN);
 }
 
+// Stride 2: an input pixel only meets the taps of ITS parity -- ky = (iy + pad) mod 2 + 2 ty, kx likewise: 1, 2, 2 or 4 of a 3 x 3 filter's nine,
+// one or none of a 1 x 1 filter's -- and the dense kernel above multiplies the other 3/4 (or more) of its K range by zeros it first computes with
+// divisions.  Here a workgroup owns ONE parity class (blockIdx.z = frame * 4 + class): its columns are that class's pixels, its K range the
+// class's taps in the dense kernel's order (co, ky, kx ascending), so every output sums the same non-zero products in the same order -- the
+// fp32 matrix instruction is an exact fma chain (tools/probe_mfma_rounding.hip) and a zero product changes nothing in one: bit-identical to
+// the dense kernel on finite operands (up to the sign of a zero), 1/4 of its matrix work.  A class without taps (1 x 1 / stride 2: three of
+// four) writes zeros.
+struct DgradS2 {
+    const float* Wg; const float* dy;
+    int Cin, KH, KW, pad, OH, OW, W;
+    int ky0, kx0, ny, nx, K;          // this class's taps and K = Cout * ny * nx
+    int Wc, ncol, a, b;               // the class's pixel grid: columns = (qy, qx), iy = 2 qy + a, ix = 2 qx + b
+    int iy, ix; bool valid;
+    __device__ __forceinline__ float load(int k, int m) const {            // A(k, m = ci)
+        if (k >= K || m >= Cin) return 0.0f;
+        const int nt = ny * nx, co = k / nt, t = k - co * nt, ty = t / nx, tx = t - ty * nx;
+        return Wg[(((long long)co * Cin + m) * KH + ky0 + 2 * ty) * KW + kx0 + 2 * tx];
+    }
+    __device__ __forceinline__ void column(int j) { valid = j < ncol; const int jc = valid ? j : 0, qy = jc / Wc; iy = 2 * qy + a; ix = 2 * (jc - qy * Wc) + b; }
+    __device__ __forceinline__ void begin_tile(int) {}
+    __device__ __forceinline__ float load(int k) const {                   // B(k, this thread's column)
+        if (!valid || k >= K) return 0.0f;
+        const int nt = ny * nx, co = k / nt, t = k - co * nt, ty = t / nx, tx = t - ty * nx;
+        const int oy = (iy + pad - ky0 - 2 * ty) >> 1, ox = (ix + pad - kx0 - 2 * tx) >> 1;      // exact: the tap has the pixel's parity
+        if (oy < 0 || ox < 0 || oy >= OH || ox >= OW) return 0.0f;
+        return dy[((long long)co * OH + oy) * OW + ox];
+    }
+};
+struct DgradS2Epi {
+    float* out; int M, HW, W, Wc, ncol, a, b;
+    __device__ __forceinline__ void tile(int mrow0, int n, const f32x16& acc) {
+        if (n >= ncol) return;
+        const int qy = n / Wc, pix = (2 * qy + a) * W + 2 * (n - qy * Wc) + b;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+            if (m < M) out[(long long)m * HW + pix] = acc[r];
+        }
+    }
+};
+__global__ __launch_bounds__(KmCfg::THREADS) void conv_dgrad_s2_kernel(const float* __restrict__ dy, const float* __restrict__ Wg, float* __restrict__ dx,
+                                                                       int Cin, int H, int W, int Cout, int KH, int KW, int pad, int OH, int OW) {
+    extern __shared__ float lds[];
+    const int bz = blockIdx.z >> 2, cls = blockIdx.z & 3, a = cls >> 1, b = cls & 1;
+    const int Hc = (H - a + 1) >> 1, Wc = (W - b + 1) >> 1, ncol = Hc * Wc;
+    if ((int)blockIdx.x * KmCfg::BN >= ncol) return;                        // (the grid is sized for the largest class)
+    const int ky0 = (a + pad) & 1, kx0 = (b + pad) & 1;
+    const int ny = ky0 < KH ? (KH - ky0 + 1) >> 1 : 0, nx = kx0 < KW ? (KW - kx0 + 1) >> 1 : 0;
+    DgradS2 l{Wg, dy + (long long)bz * Cout * OH * OW, Cin, KH, KW, pad, OH, OW, W, ky0, kx0, ny, nx > 0 ? nx : 1, Cout * ny * nx, Wc, ncol, a, b, 0, 0, false};
+    DgradS2Epi ep{dx + (long long)bz * Cin * H * W, Cin, H * W, W, Wc, ncol, a, b};
+    mfma_gemm_block<KmCfg>(lds, l, l, ep, l.K, blockIdx.y * KmCfg::BM, blockIdx.x * KmCfg::BN);
+}
+
 // =============================================================================================== per-channel reductions (BatchNorm, bias)
 // x[B][C][N]; grid (C, B * SN): block (c, s) reduces n in [chunk*per, ...) of row (b, c); fp64 partial pairs
 template <int MODE>   // 0: (sum x, sum x^2)   1: (sum g, sum g*xhat) with g = dy * [y > 0 if relu]
@@ -721,6 +774,12 @@ extern "C" int di2p_conv2d_dgrad(const float* dy, const float* Wgt, float* dx, i
     DI2P_CHECK_ARG(dy && Wgt && dx && B >= 1 && B <= 65535 && Cin >= 1 && Cout >= 1 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0, "bad args");
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     DI2P_CHECK_ARG(OH >= 1 && OW >= 1, "empty output");
+    if (stride == 2 && B <= 16383 && !di2p_opt(DI2P_OPT_CONV_DGRAD_DENSE)) {          // one parity class of input pixels per workgroup: 1/4 of the matrix work
+        const int ncol = ((H + 1) / 2) * ((W + 1) / 2);
+        hipLaunchKernelGGL(conv_dgrad_s2_kernel, dim3(di2p_cdiv(ncol, KmCfg::BN), di2p_cdiv(Cin, KmCfg::BM), B * 4), dim3(KmCfg::THREADS),
+                           KmCfg::LDS_FLOATS * sizeof(float), (hipStream_t)stream, dy, Wgt, dx, Cin, H, W, Cout, KH, KW, pad, OH, OW);
+        DI2P_RETURN_LAUNCH();
+    }
     hipLaunchKernelGGL(conv_dgrad_kernel, dim3(di2p_cdiv((long long)H * W, KmCfg::BN), di2p_cdiv(Cin, KmCfg::BM), B), dim3(KmCfg::THREADS),
                        KmCfg::LDS_FLOATS * sizeof(float), (hipStream_t)stream, dy, Wgt, dx, Cin, H, W, Cout, KH, KW, stride, pad, OH, OW);
     DI2P_RETURN_LAUNCH();

@@ -79,6 +79,32 @@ def test_conv2d_backward(B, Cin, H, W, Cout, k, s, p):
     _run_pair(lambda x, W: tn._Conv2d.apply(x, W, s, p), lambda x, W: F.conv2d(x, W, None, stride=s, padding=p), [x, Wt], tol=3e-5)
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,p", [(2, 64, 16, 32, 128, 3, 1), (2, 64, 16, 32, 128, 1, 0), (1, 256, 4, 8, 512, 3, 1), (2, 3, 32, 64, 64, 7, 3),
+                                               (3, 17, 9, 11, 5, 3, 1), (2, 8, 7, 5, 4, 1, 0), (1, 5, 6, 6, 3, 2, 0)])
+def test_conv2d_dgrad_stride2_parity_kernel_equals_dense_kernel(B, Cin, H, W, Cout, k, p):
+    """Round 6: for stride 2 the input gradient is computed per parity class of input pixels (only the taps that reach the class: 1/4 of the
+    dense kernel's matrix work, no divisibility tests).  Same non-zero products in the same order on an exact fma chain: the two kernels must
+    agree bit for bit (zeros compare equal whatever their sign); odd sizes, 1 x 1 (three classes without taps), 7 x 7 and an even filter."""
+    from deepi2p_amd import _lib
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(H * W + k)
+    OH, OW = (H + 2 * p - k) // 2 + 1, (W + 2 * p - k) // 2 + 1
+    dy = torch.randn(B, Cout, OH, OW, generator=g).to(dev)
+    Wt = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(dev)
+    out = []
+    for dense in (0, 1):
+        _lib.set_option("conv_dgrad_dense", dense)
+        try:
+            dx = torch.full((B, Cin, H, W), float("nan"), device=dev)
+            _lib.call("di2p_conv2d_dgrad", dy.data_ptr(), Wt.data_ptr(), dx.data_ptr(), B, Cin, H, W, Cout, k, k, 2, p, _lib.stream())
+            out.append(dx)
+        finally:
+            _lib.set_option("conv_dgrad_dense", 0)
+    assert torch.equal(out[0], out[1])
+    ref = torch.nn.grad.conv2d_input((B, Cin, H, W), Wt.double().cpu(), dy.double().cpu(), stride=2, padding=p)
+    assert float((out[0].double().cpu() - ref).abs().max()) <= 3e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_winograd_dgrad_filter_transform_equals_flip_transpose_transform():
     """Round 6: the transformed filter of a stride-1 3x3 layer's input gradient comes straight from the forward filter (one launch); it must be
     the SAME tensor, bit for bit, as flipping, transposing and copying the filter and then transforming it (what the step did before) -- also
