@@ -356,17 +356,24 @@ struct DgradS2 {
     int Cin, KH, KW, pad, OH, OW, W;
     int ky0, kx0, ny, nx, K;          // this class's taps and K = Cout * ny * nx
     int Wc, ncol, a, b;               // the class's pixel grid: columns = (qy, qx), iy = 2 qy + a, ix = 2 qx + b
+    int sh_t, sh_x;                   // log2(ny * nx), log2(nx) when both are powers of two (every class of a 3 x 3 or 1 x 1 filter), else -1
     int iy, ix; bool valid;
+    __device__ __forceinline__ void split(int k, int& co, int& ty, int& tx) const {
+        if (sh_t >= 0) { co = k >> sh_t; const int t = k & ((1 << sh_t) - 1); ty = t >> sh_x; tx = t & ((1 << sh_x) - 1); }
+        else { const int nt = ny * nx; co = k / nt; const int t = k - co * nt; ty = t / nx; tx = t - ty * nx; }
+    }
     __device__ __forceinline__ float load(int k, int m) const {            // A(k, m = ci)
         if (k >= K || m >= Cin) return 0.0f;
-        const int nt = ny * nx, co = k / nt, t = k - co * nt, ty = t / nx, tx = t - ty * nx;
+        int co, ty, tx;
+        split(k, co, ty, tx);
         return Wg[(((long long)co * Cin + m) * KH + ky0 + 2 * ty) * KW + kx0 + 2 * tx];
     }
     __device__ __forceinline__ void column(int j) { valid = j < ncol; const int jc = valid ? j : 0, qy = jc / Wc; iy = 2 * qy + a; ix = 2 * (jc - qy * Wc) + b; }
     __device__ __forceinline__ void begin_tile(int) {}
     __device__ __forceinline__ float load(int k) const {                   // B(k, this thread's column)
         if (!valid || k >= K) return 0.0f;
-        const int nt = ny * nx, co = k / nt, t = k - co * nt, ty = t / nx, tx = t - ty * nx;
+        int co, ty, tx;
+        split(k, co, ty, tx);
         const int oy = (iy + pad - ky0 - 2 * ty) >> 1, ox = (ix + pad - kx0 - 2 * tx) >> 1;      // exact: the tap has the pixel's parity
         if (oy < 0 || ox < 0 || oy >= OH || ox >= OW) return 0.0f;
         return dy[((long long)co * OH + oy) * OW + ox];
@@ -392,7 +399,10 @@ __global__ __launch_bounds__(KmCfg::THREADS) void conv_dgrad_s2_kernel(const flo
     if ((int)blockIdx.x * KmCfg::BN >= ncol) return;                        // (the grid is sized for the largest class)
     const int ky0 = (a + pad) & 1, kx0 = (b + pad) & 1;
     const int ny = ky0 < KH ? (KH - ky0 + 1) >> 1 : 0, nx = kx0 < KW ? (KW - kx0 + 1) >> 1 : 0;
-    DgradS2 l{Wg, dy + (long long)bz * Cout * OH * OW, Cin, KH, KW, pad, OH, OW, W, ky0, kx0, ny, nx > 0 ? nx : 1, Cout * ny * nx, Wc, ncol, a, b, 0, 0, false};
+    const int nx1 = nx > 0 ? nx : 1, nt = ny * nx1;
+    const bool pow2 = nt > 0 && (nt & (nt - 1)) == 0 && (nx1 & (nx1 - 1)) == 0;
+    DgradS2 l{Wg, dy + (long long)bz * Cout * OH * OW, Cin, KH, KW, pad, OH, OW, W, ky0, kx0, ny, nx1, Cout * ny * nx, Wc, ncol, a, b,
+              pow2 ? 31 - __builtin_clz(nt) : -1, pow2 ? 31 - __builtin_clz(nx1) : 0, 0, 0, false};
     DgradS2Epi ep{dx + (long long)bz * Cin * H * W, Cin, H * W, W, Wc, ncol, a, b};
     mfma_gemm_block<KmCfg>(lds, l, l, ep, l.K, blockIdx.y * KmCfg::BM, blockIdx.x * KmCfg::BN);
 }

@@ -9,7 +9,8 @@ for d in 0 1; do
   DI2P_CONV_DGRAD_DENSE=$d timeout 200 python bench.py --mode train --steps 6 --warmup 2 2>/dev/null | python -c "
 import json,sys
 l=json.loads(sys.stdin.readline()); c=l['calls_ms_per_step']
-print('dense $d: %.2f ms per step | conv2d_dgrad %.3f ms in %d calls' % (l['ms_per_step'], c['di2p_conv2d_dgrad']['ms'], c['di2p_conv2d_dgrad']['calls']))" >> $LOG
+d=c.get('di2p_conv2d_dgrad')
+print('dense $d: %.2f ms per step | conv2d_dgrad %s' % (l['ms_per_step'], ('%.3f ms in %d calls' % (d['ms'], d['calls'])) if d else 'below the ten largest calls (< %.2f ms)' % min(v['ms'] for v in c.values())))" >> $LOG
 done
 done
 cat $LOG
