@@ -86,6 +86,16 @@ def test_interpolate_gather_argmax_channelmax(dev):
     out = ops.interpolate(feats.to(dev), idx.to(dev), w.to(dev)).cpu()
     gath = torch.gather(feats.unsqueeze(3).expand(B, C, M, k), 2, idx.long().unsqueeze(1).expand(B, C, Nq, k))
     torch.testing.assert_close(out, (w.unsqueeze(1) * gath).sum(3), rtol=1e-5, atol=1e-6)
+    # many columns (training: 20480 points) run the kernel that keeps the 32-channel table slice in LDS: the same sums in the same order, i.e.
+    # the same bits as the gather-from-memory kernel on the same columns (which the first 1000 columns alone still select)
+    for kk, Nl in ((3, 2500), (1, 1024), (4, 1500)):
+        idx_l = torch.randint(0, M, (B, Nl, kk), generator=g, dtype=torch.int32)
+        w_l = torch.rand(B, Nl, kk, generator=g)
+        big = ops.interpolate(feats.to(dev), idx_l.to(dev), w_l.to(dev)).cpu()
+        small = ops.interpolate(feats.to(dev), idx_l[:, :1000].contiguous().to(dev), w_l[:, :1000].contiguous().to(dev)).cpu()
+        assert torch.equal(big[:, :, :1000], small)
+        g_l = torch.gather(feats.unsqueeze(3).expand(B, C, M, kk), 2, idx_l.long().unsqueeze(1).expand(B, C, Nl, kk))
+        torch.testing.assert_close(big, (w_l.unsqueeze(1) * g_l).sum(3), rtol=1e-5, atol=1e-6)
     db, q = torch.randn(B, 3, M, generator=g), torch.randn(B, 3, 50, generator=g)
     kn = torch.randint(0, M, (B, 50, 16), generator=g, dtype=torch.int32)
     gn = ops.gather_neighbors(db.to(dev), q.to(dev), kn.to(dev)).cpu().view(B, 3, 50, 16)
