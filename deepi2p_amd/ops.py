@@ -267,6 +267,12 @@ def _x3_operand(Wt, B, M, N, x3):
     if not x3:
         return None
     K = Wt.shape[0]
+    if x3 == "step":
+        # training: the operand is this step's transposed copy of a parameter -- split it on the stream, use it once, cache nothing (no
+        # host synchronisation: the split, the launch that reads it and the allocator's reuse of its memory are ordered by the stream)
+        if M % 4 or N % 4 or not Wt.is_contiguous():
+            raise RuntimeError("bf16x3 needs M % 4 == 0, N % 4 == 0 and a contiguous [K,M] weight")
+        return bf16x3_pack(Wt)
     if M % 4 or N % 4 or not Wt.is_contiguous():
         raise RuntimeError("bf16x3 needs M % 4 == 0, N % 4 == 0 and a contiguous [K,M] weight")
     # an address is only an identity while the tensor that owns it is alive: the entry remembers (weakly) the base tensor it was made from --
@@ -306,7 +312,8 @@ def pointwise_gemm(srcs, Wt, M, N, scale=None, shift=None, batch_bias=None, relu
     to two (table f32[B,nodes,M] node-major, idx i32[B,N,k], w f32[B,N,k]).  transpose_out: Y is f32[B,N,M].
     group_max > 1 returns the group maxima; with also_full=True it returns (full Y, maxima) from the same launch.
     x3: run the contraction on the bf16x3 kernel (exact three-way bf16 split of both operands, fp32 accumulation; None = for the GEMM-shaped
-    layers, K >= 128 and M % 128 == 0, unless the knob `pw_x3` is 0).
+    layers, K >= 128 and M % 128 == 0, unless the knob `pw_x3` is 0; "step" = yes, with the weights split for this call only -- the
+    training step, whose operand is a fresh transposed copy of a parameter every time).
     planes_out (bf16x3 layers only): the full-size output comes back as X3Planes -- already split for the bf16x3 layer that consumes it as
     `srcs=[planes]` (bit-identical to handing the fp32 output on; the split leaves the consumer's K loop)."""
     B = srcs[0].t.shape[0]

@@ -52,6 +52,14 @@ def _c(t):
 
 
 # ------------------------------------------------------------------------------------------------ contractions
+def _x3_step(K, M, N):
+    """Forward and input-gradient contractions of the big point layers on the bf16x3 kernel (exact three-way splits: as accurate as the
+    fp32-MFMA kernel, tests/test_gpu_contractions.py; the weights are split per call, ops.pointwise_gemm x3="step"): the layers with at
+    least 128 rows on both sides of the contraction and 2048 columns per frame -- the per-point head and the kNN-fusion layers, 2.2 of the
+    3.3 ms a step spends in di2p_pointwise_gemm.  Knob `pw_x3` = 0: fp32-MFMA kernels everywhere (rounds 3-5)."""
+    return "step" if (K >= 128 and M >= 128 and M % 4 == 0 and N % 4 == 0 and N >= 2048 and _lib.get_option("pw_x3") != 0) else False
+
+
 class _Linear(Function):
     """y[b,m,n] = sum_k W[m,k] x[b,k,n] + bias[m]; x f32[B,K,N]."""
 
@@ -61,7 +69,7 @@ class _Linear(Function):
         B, K, N = x.shape
         M = W.shape[0]
         W2 = W.reshape(M, K)
-        y = ops.pointwise_gemm([Src(x)], W2.t().contiguous(), M, N, shift=bias, x3=False)
+        y = ops.pointwise_gemm([Src(x)], W2.t().contiguous(), M, N, shift=bias, x3=_x3_step(K, M, N))
         ctx.save_for_backward(x, W2)
         ctx.has_bias = bias is not None
         ctx.wshape = W.shape
@@ -77,7 +85,7 @@ class _Linear(Function):
         lib = _lib.load()
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.pointwise_gemm([Src(dy)], _c(W2), K, N, x3=False)          # W[m][k] is the k-major operand of the reduction over m
+            dx = ops.pointwise_gemm([Src(dy)], _c(W2), K, N, x3=_x3_step(M, K, N))          # W[m][k] is the k-major operand of the reduction over m
         if ctx.needs_input_grad[1]:
             dW = ctx.sinks[0] if ctx.sinks[0] is not None else torch.empty((M, K), dtype=_f32, device=x.device)
             nb = lib.di2p_bmm_rc_workspace_bytes(B, M, K, N)
