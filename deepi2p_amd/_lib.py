@@ -58,6 +58,7 @@ _SIGS = {
                                ctypes.POINTER(EpilogueT), c_void_p],
     "di2p_pointwise_gemm_x3p": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(EpilogueT), c_void_p],
     "di2p_bf16x3_pack": [c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "di2p_bf16x3_pack_conv3x3": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "di2p_batch_gemv": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "di2p_batch_gemv2": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "di2p_attention_pool": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],

@@ -1271,7 +1271,12 @@ __global__ __launch_bounds__(512, 1) void pointwise_gemm_x3p8_kernel(const u32x4
 }
 
 // Wt f32 [K][M] (k-major, what the fp32 kernels read) -> [Kp/8][Mp][3][8] bf16, zero filled outside K x M.  One thread per (k-group, m).
-__global__ __launch_bounds__(256) void bf16x3_pack_kernel(const float* __restrict__ Wt, unsigned short* __restrict__ Wp, int K, int M, int Kp, int Mp) {
+// MODE 0: Wt is the [K][M] matrix itself.  MODE 1 / 2: Wt is a 3 x 3 filter bank W[Cout][Cin][3][3] and the matrix is its tap-major form for
+// di2p_conv3x3_x3 -- 1: the forward filter, row (tap, ci), column co (K = 9 Cin, M = Cout, ci_n = Cin); 2: the filter of the INPUT GRADIENT,
+// flipped and channel-transposed, row (tap, co), column ci (K = 9 Cout, M = Cin, ci_n = Cout): what the training step otherwise builds with a
+// flip, a transpose and two copies before every pack.
+template <int MODE>
+__global__ __launch_bounds__(256) void bf16x3_pack_kernel(const float* __restrict__ Wt, unsigned short* __restrict__ Wp, int K, int M, int Kp, int Mp, int ci_n) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long long)(Kp / 8) * Mp) return;
     const int kg = (int)(t / Mp), m = (int)(t - (long long)kg * Mp);
@@ -1280,7 +1285,14 @@ __global__ __launch_bounds__(256) void bf16x3_pack_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int k = kg * 8 + i;
-        const float a = (k < K && m < M) ? Wt[(long long)k * M + m] : 0.0f;
+        float a = 0.0f;
+        if (k < K && m < M) {
+            if (MODE == 0) a = Wt[(long long)k * M + m];
+            else {
+                const int tap = k / ci_n, c = k - tap * ci_n;
+                a = MODE == 1 ? Wt[((long long)m * ci_n + c) * 9 + tap] : Wt[((long long)c * M + m) * 9 + 8 - tap];
+            }
+        }
         const float a1 = x3_hi16(a), r1 = a - a1, a2 = x3_hi16(r1), r2 = r1 - a2;
         d[0 * ps + i] = (unsigned short)(__builtin_bit_cast(unsigned, a1) >> 16);
         d[1 * ps + i] = (unsigned short)(__builtin_bit_cast(unsigned, a2) >> 16);
@@ -1401,8 +1413,22 @@ extern "C" int di2p_bf16x3_pack(const float* Wt, int K, int M, void* Wp, void* s
     DI2P_CHECK_ARG(Wt && Wp && K >= 1 && M >= 1, "bad args");
     DI2P_CHECK_ARG(aligned16(Wp), "packed weights must be 16-byte aligned");
     const int Kp = di2p_cdiv(K, X3_BK) * X3_BK, Mp = di2p_cdiv(M, X3_BM) * X3_BM;
-    hipLaunchKernelGGL(bf16x3_pack_kernel, dim3(di2p_cdiv((long long)(Kp / 8) * Mp, 256)), dim3(256), 0, (hipStream_t)stream, Wt,
-                       (unsigned short*)Wp, K, M, Kp, Mp);
+    hipLaunchKernelGGL(bf16x3_pack_kernel<0>, dim3(di2p_cdiv((long long)(Kp / 8) * Mp, 256)), dim3(256), 0, (hipStream_t)stream, Wt,
+                       (unsigned short*)Wp, K, M, Kp, Mp, 0);
+    DI2P_RETURN_LAUNCH();
+}
+
+// di2p_bf16x3_pack of the tap-major matrix of a 3 x 3 filter bank W f32[Cout][Cin][3][3], straight from W: dgrad == 0 the forward filter
+// ([9 Cin, Cout]: Wp has di2p_bf16x3_packed_bytes(9 Cin, Cout) bytes), dgrad == 1 the filter of the input gradient ([9 Cout, Cin]: flipped
+// taps, channel roles swapped).  The same bytes as permuting / flipping W on the host side and calling di2p_bf16x3_pack.
+extern "C" int di2p_bf16x3_pack_conv3x3(const float* W, int Cout, int Cin, int dgrad, void* Wp, void* stream) {
+    DI2P_CHECK_ARG(W && Wp && Cout >= 1 && Cin >= 1 && aligned16(Wp), "bad args");
+    DI2P_CHECK_ARG((long long)Cout * Cin * 9 < (1ll << 31), "filter bank too large");
+    const int ci_n = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout, K = 9 * ci_n;
+    const int Kp = di2p_cdiv(K, X3_BK) * X3_BK, Mp = di2p_cdiv(M, X3_BM) * X3_BM;
+    const dim3 grid(di2p_cdiv((long long)(Kp / 8) * Mp, 256));
+    if (dgrad) hipLaunchKernelGGL(bf16x3_pack_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, W, (unsigned short*)Wp, K, M, Kp, Mp, ci_n);
+    else hipLaunchKernelGGL(bf16x3_pack_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, W, (unsigned short*)Wp, K, M, Kp, Mp, ci_n);
     DI2P_RETURN_LAUNCH();
 }
 

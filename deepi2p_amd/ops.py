@@ -250,6 +250,21 @@ def bf16x3_pack(Wt):
     return Wp
 
 
+def bf16x3_pack_conv3x3(W, dgrad=False):
+    """The split operand of conv3x3_x3 straight from a filter bank W f32[Cout,Cin,3,3] (contiguous): the forward filter, or (dgrad=True) the
+    filter whose convolution with dY is the layer's input gradient -- the same bytes as bf16x3_pack of the permuted (and flipped, transposed)
+    matrix, in one launch."""
+    require_cuda(W)
+    _chk(W, _f32, "bf16x3_pack_conv3x3 filter")
+    if W.dim() != 4 or W.shape[2:] != (3, 3) or not W.is_contiguous():
+        raise RuntimeError("bf16x3_pack_conv3x3 needs a contiguous f32[Cout,Cin,3,3]")
+    Cout, Cin = int(W.shape[0]), int(W.shape[1])
+    K, M = (9 * Cout, Cin) if dgrad else (9 * Cin, Cout)
+    Wp = torch.empty((_lib.load().di2p_bf16x3_packed_bytes(K, M),), dtype=torch.uint8, device=W.device)
+    call("di2p_bf16x3_pack_conv3x3", ptr(W), Cout, Cin, int(bool(dgrad)), ptr(Wp), stream())
+    return Wp
+
+
 def _x3_auto(Wt, M, N):
     """The automatic rule of _x3_operand: does the layer with weights Wt [K, M] on N columns per frame run on the bf16x3 kernel?"""
     return (Wt.shape[0] >= X3_MIN_K and M % 128 == 0 and N % 4 == 0 and ((N + 127) // 128) * (M // 128) >= 8 and not Wt.requires_grad

@@ -118,18 +118,43 @@ def _unit_affine(C, device):
     return _UNIT[key]
 
 
+def _use_conv_x3(xshape, Cout):
+    """Does the stride-1 3 x 3 layer x[B, Cin, H, W] -> Cout run on di2p_conv3x3_x3 in the training step?  From 16 frames on: every stage the knob
+    `conv_x3` names.  Below (the reference's training batch of 8): only the 256- and 512-channel stages -- the kernel's workgroup tiles are
+    sized for whole rounds of the chip at 32 frames; at 8 frames the Winograd kernel's smaller tiles win on the two large-image stages
+    (tools/bench_conv_x3.py, B=8: 30.8 / 38.7 us against 29.2 / 42.7) and lose on the small-image ones (48.2 / 73.2 against 29.2 / 46.0 us with
+    the smallest tile configuration, which _conv_forward then forces)."""
+    if not (_lib.get_option("conv_x3") & (1 << max(0, min(3, Cout.bit_length() - 7)))) or not ops.conv3x3_x3_supported(xshape, Cout, 1):
+        return False
+    return xshape[0] >= 16 or Cout >= 256
+
+
+def _conv3x3_x3(x, W, dgrad):
+    """The stride-1 3 x 3 layer with filter bank W[Cout, Cin, 3, 3] on di2p_conv3x3_x3 (exact three-way splits; the filters change every step: their
+    split is ONE small launch per call, straight from W): dgrad False: y = conv(x, W); True: the input gradient = conv(x = dY, W flipped and
+    channel-transposed) -- the filter the pack kernel builds itself."""
+    Cdst = W.shape[1] if dgrad else W.shape[0]
+    one, zero = _unit_affine(Cdst, x.device)
+    Wp = ops.bf16x3_pack_conv3x3(_c(W), dgrad=dgrad)
+    small = x.shape[0] < 16 and _lib.get_option("conv_x3_cfg") < 0
+    if small:        # few frames: the smallest tile configuration fills more of the chip (the library prices its choice for 32 frames)
+        _lib.set_option("conv_x3_cfg", 3)
+        if not ops.conv3x3_x3_supported(x.shape, Cdst, 1):        # ... where it runs the shape at all
+            _lib.set_option("conv_x3_cfg", -1)
+            small = False
+    try:
+        return ops.conv3x3_x3(x, Wp, Cdst, one, zero, 1, False)
+    finally:
+        if small:
+            _lib.set_option("conv_x3_cfg", -1)
+
+
 def _conv_forward(x, W, stride, pad):
     """conv2d through the inference engine with an identity epilogue; Cin % 16 == 0 takes its tap-major (16-byte staged) path."""
     Cout, Cin, KH, KW = W.shape
     one, zero = _unit_affine(Cout, x.device)
-    if ((KH, KW, stride, pad) == (3, 3, 1, 1) and Cin % 16 == 0 and x.shape[0] >= 16
-            and (_lib.get_option("conv_x3") & (1 << max(0, min(3, Cout.bit_length() - 7)))) and ops.conv3x3_x3_supported(x.shape, Cout, 1)):
-        # round 5: the direct convolution on the bf16 matrix instructions (exact three-way splits; the filters change every step: their
-        # split is one small launch per call, like the Winograd transform below) -- forward AND, through the flipped filter, the input gradient.
-        # From 16 frames on: its workgroup tiles are sized for whole rounds of the chip at 32 frames; at the reference's training batch of 8 they
-        # number 64-128 per launch and the Winograd kernel's smaller tiles win (measured: 18.3 against 17.8 ms per step)
-        Wt = W.permute(2, 3, 1, 0).reshape(-1, Cout).contiguous()
-        return ops.conv3x3_x3(x, ops.bf16x3_pack(Wt), Cout, one, zero, 1, False)
+    if (KH, KW, stride, pad) == (3, 3, 1, 1) and Cin % 16 == 0 and _use_conv_x3(x.shape, Cout):
+        return _conv3x3_x3(x, W, False)
     if (KH, KW, stride, pad) == (3, 3, 1, 1) and Cin % 16 == 0 and Cout % 32 == 0 and x.shape[3] % 2 == 0 and x.shape[3] >= 4:
         # the fused Winograd kernel (the filters change every step: their transform is one small launch per call)
         return ops.conv3x3_winograd(x, ops.winograd_weights(W), one, zero, False)
@@ -164,11 +189,12 @@ class _Conv2d(Function):
                 # the forward engine does it (the strided layers go through the generic gather-form kernel)
                 one, zero = _unit_affine(Cin, dy.device)
                 if ((KH, pad) == (3, 1) and Cout % 16 == 0 and Cin % 32 == 0 and dy.shape[3] % 2 == 0 and dy.shape[3] >= 4
-                        and not (dy.shape[0] >= 16 and (_lib.get_option("conv_x3") & (1 << max(0, min(3, Cin.bit_length() - 7))))
-                                 and ops.conv3x3_x3_supported(dy.shape, Cin, 1))):
+                        and not _use_conv_x3(dy.shape, Cin)):
                     # round 6: the Winograd kernel with the gradient filter transformed straight from W (one launch instead of flip + transpose +
                     # copy + transform); the same U, the same kernel, the same bits as the path below
                     dx = ops.conv3x3_winograd(dy, ops.winograd_weights_dgrad(W), one, zero, False)
+                elif (KH, pad) == (3, 1) and Cout % 16 == 0 and _use_conv_x3(dy.shape, Cin):
+                    dx = _conv3x3_x3(dy, W, True)
                 else:
                     dx = _conv_forward(dy, W.flip(2, 3).transpose(0, 1), 1, pad)
             else:

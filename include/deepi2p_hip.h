@@ -147,6 +147,10 @@ int di2p_pointwise_gemm(const di2p_src_t* srcs_host, int n_src, const float* Wt,
  * Same sources, epilogues and output layouts as di2p_pointwise_gemm; needs M % 4 == 0 and N % 4 == 0. */
 long long di2p_bf16x3_packed_bytes(int K, int M);
 int di2p_bf16x3_pack(const float* Wt, int K, int M, void* Wp, void* stream);
+/* (ABI 6, training) the split tap-major matrix of a 3x3 filter bank W f32[Cout][Cin][3][3] for di2p_conv3x3_x3, straight from W:
+ * dgrad == 0: of the forward filter ([9 Cin, Cout]); dgrad == 1: of the filter that computes the layer's INPUT gradient as a convolution of
+ * dY ([9 Cout, Cin]: taps flipped, channel roles swapped; models/resnet.py:56-72 under autograd).  Same bytes as di2p_bf16x3_pack of that matrix. */
+int di2p_bf16x3_pack_conv3x3(const float* W, int Cout, int Cin, int dgrad, void* Wp, void* stream);
 int di2p_pointwise_gemm_x3(const di2p_src_t* srcs_host, int n_src, const void* Wp, float* Y,
                            int B, int M, int K, int N, const di2p_epilogue_t* epi_host, void* stream);
 /* A chain of such layers (GeneralKNNFusionModule's layers_before.1 -> layers_after.0 -> layers_after.1, models/layers_pc.py:779-818) hands

@@ -118,6 +118,20 @@ def test_winograd_dgrad_filter_transform_equals_flip_transpose_transform():
         assert a.shape == b.shape == (16, Cout, Cin) and torch.equal(a, b)
 
 
+def test_bf16x3_pack_conv3x3_equals_host_side_permutation():
+    """Round 6: the split operand of di2p_conv3x3_x3 straight from a filter bank, for the forward filter and for the input-gradient filter
+    (flipped taps, channel roles swapped): the same bytes as permuting / flipping on the host side and packing the tap-major matrix."""
+    from deepi2p_amd import ops
+    dev = torch.device("cuda", 0)
+    for Cout, Cin in ((256, 256), (512, 256), (48, 80)):
+        W = torch.randn(Cout, Cin, 3, 3, generator=torch.Generator().manual_seed(Cout + Cin)).to(dev)
+        assert torch.equal(ops.bf16x3_pack_conv3x3(W), ops.bf16x3_pack(W.permute(2, 3, 1, 0).reshape(-1, Cout).contiguous()))
+        Wg = W.flip(2, 3).transpose(0, 1)                    # [Cin, Cout, 3, 3]: the filter of the input gradient
+        assert torch.equal(ops.bf16x3_pack_conv3x3(W, dgrad=True), ops.bf16x3_pack(Wg.permute(2, 3, 1, 0).reshape(-1, Cin).contiguous()))
+    with pytest.raises(RuntimeError):
+        ops.bf16x3_pack_conv3x3(torch.randn(8, 8, 5, 5).to(dev))
+
+
 def test_maxpool_avgpool_backward():
     from deepi2p_amd import train_net as tn
     g = torch.Generator().manual_seed(3)
