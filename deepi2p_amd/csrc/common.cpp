@@ -40,6 +40,7 @@ const OptDef kOpts[DI2P_OPT_COUNT] = {
     {"head_x3", "DI2P_HEAD_X3", 1},                 {"head_x3_tab", "DI2P_HEAD_X3_TAB", 1},
     {"stem_x3", "DI2P_STEM_X3", 1},                 {"bn_unfused", "DI2P_BN_UNFUSED", 0},
     {"pw_x3_planes", "DI2P_PW_X3_PLANES", 1},        {"conv_dgrad_dense", "DI2P_CONV_DGRAD_DENSE", 0},
+    {"rc_tile64", "DI2P_RC_TILE64", 0},
 };
 long long g_opt[DI2P_OPT_COUNT];
 std::once_flag g_opt_once;

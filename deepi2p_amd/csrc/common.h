@@ -69,6 +69,7 @@ enum Di2pOption {
     DI2P_OPT_BN_UNFUSED,            // 1: train-mode BatchNorm finalizes its statistics in a launch of its own (rounds 2-5; default: inside the elementwise pass, same results)
     DI2P_OPT_PW_X3_PLANES,          // 1 (default): consecutive bf16x3 pointwise layers hand their activations on as split bf16 planes (di2p_epilogue_t.planes_out -> di2p_pointwise_gemm_x3p) instead of fp32 (bit-identical; read by networks.py); 2: the same, and di2p_pointwise_gemm_x3p always runs its 128-row kernel (default: 256-row tiles with both operands in LDS when M % 256 == 0)
     DI2P_OPT_CONV_DGRAD_DENSE,      // 1: di2p_conv2d_dgrad runs its dense kernel for stride 2 too (default: one parity class of input pixels per workgroup, 1/4 of the matrix work; same results)
+    DI2P_OPT_RC_TILE64,             // 1: the reduction GEMMs of the training step (weight gradients) always run 64 x 64 tiles (default: 128 x 128 for strided operand pairs with at least 128 rows and columns)
     DI2P_OPT_COUNT
 };
 long long di2p_opt(int id);

@@ -209,6 +209,109 @@ __global__ __launch_bounds__(256) void rc_gemm_kernel(LA la, LB lb, int R, int r
     rc_gemm_tile<AV, BV>(lds, la, lb, r_begin, r_end, blockIdx.y * RC_BM, blockIdx.x * RC_BM, partial + (long long)blockIdx.z * rows * cols, rows, cols);
 }
 
+// 128 x 128 tiles (a wave: 64 x 64 = 2 x 2 matrix tiles) for the plainly strided operand pair with 16-byte rows -- the weight gradients of the
+// big point layers.  Those launches are bound by operand traffic (every 64 x 64 tile re-reads its 64 + 64 rows over the whole reduction range:
+// dW of the per-point head's first layer, 256 x 736 over 8 x 20480 columns, moved 4 GB for 62 Gflop: 0.86 ms); a 128 x 128 tile reads half of
+// that per output element.  Same reduction order per output element for the same chunks.
+constexpr int RC2_BM = 128, RC2_LD = 129;
+constexpr int RC2_LDS_FLOATS = 2 * 2 * RC_BK * RC2_LD;
+struct RcStageVec4 {
+    f32x4 v[4];
+    const float* ptr[4];
+    bool okp[4];
+    int r4, row0;
+    template <class L>
+    __device__ __forceinline__ void init(int tid, L& l, int blk) {
+        r4 = tid & 7; row0 = tid >> 3;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int i = blk + row0 + 32 * p;
+            okp[p] = i < l.n;
+            ptr[p] = l.p + (long long)min(i, l.n - 1) * l.ld + r4 * 4;
+        }
+    }
+    __device__ __forceinline__ void load(int r0, int r_end) {
+        const bool ok = r0 + r4 * 4 < r_end;
+        const int rc = ok ? r0 : r_end - 32;           // (a clamped, still in-range 16-byte read; zeroed below)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(ptr[p] + (rc < 0 ? 0 : rc));
+            v[p] = (ok && okp[p]) ? t : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    }
+    __device__ __forceinline__ void store(float* S) const {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) S[(r4 * 4 + i) * RC2_LD + row0 + 32 * p] = v[p][i];
+    }
+};
+__global__ __launch_bounds__(256) void rc_gemm128_kernel(RcStrided la, RcStrided lb, int R, int rch, int chunks, float* __restrict__ partial, int rows, int cols) {
+    extern __shared__ float lds[];
+    const int z = blockIdx.z / chunks, ch = blockIdx.z % chunks;
+    la.batch(z); lb.batch(z);
+    const int r_begin = ch * rch, r_end = min(R, r_begin + rch);
+    float* out = partial + (long long)blockIdx.z * rows * cols;
+    const int row_blk = blockIdx.y * RC2_BM, col_blk = blockIdx.x * RC2_BM;
+    float* As = lds;                          // [2][BK][LD]
+    float* Bs = lds + 2 * RC_BK * RC2_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
+    RcStageVec4 sa, sb;
+    sa.init(tid, la, row_blk);
+    sb.init(tid, lb, col_blk);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int T = (r_end - r_begin + RC_BK - 1) / RC_BK;
+    if (T > 0) {
+        sa.load(r_begin, r_end); sb.load(r_begin, r_end);
+        sa.store(As); sb.store(Bs);
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < T) { sa.load(r_begin + (t + 1) * RC_BK, r_end); sb.load(r_begin + (t + 1) * RC_BK, r_end); }
+        const float* Ab = As + buf * RC_BK * RC2_LD + wm * 64 + l31;
+        const float* Bb = Bs + buf * RC_BK * RC2_LD + wn * 64 + l31;
+#pragma unroll
+        for (int k0 = 0; k0 < RC_BK; k0 += 8) {          // four k-pairs at a time: 16 operand registers
+            float a[4][2], b[4][2];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[kk][i] = Ab[(k0 + 2 * kk + half) * RC2_LD + i * 32];
+                    b[kk][i] = Bb[(k0 + 2 * kk + half) * RC2_LD + i * 32];
+                }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < T) { sa.store(As + (buf ^ 1) * RC_BK * RC2_LD); sb.store(Bs + (buf ^ 1) * RC_BK * RC2_LD); }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = col_blk + wn * 64 + j * 32 + l31;
+            if (col >= cols) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_blk + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < rows) out[(long long)row * cols + col] = acc[i][j][r];
+            }
+        }
+}
+
 // out[g][e] = alpha * sum_{p < per_group} partial[g * per_group + p][e], in a fixed order
 __global__ __launch_bounds__(256) void rc_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int per_group, long long elems,
                                                         long long total, float alpha) {
@@ -232,10 +335,12 @@ __global__ __launch_bounds__(256) void rc_reduce_kernel(const float* __restrict_
 }
 
 struct RcPlan { int rch, chunks; long long bytes; };
-RcPlan rc_plan(int Z, int rows, int cols, int R) {
+// the big strided pairs take 128 x 128 tiles (rc_gemm128_kernel)
+inline bool rc_big(int rows, int cols) { return rows >= 128 && cols >= 128 && !di2p_opt(DI2P_OPT_RC_TILE64); }
+RcPlan rc_plan(int Z, int rows, int cols, int R, int bm = RC_BM) {
     RcPlan pl;
     // enough workgroups to fill the chip, chunks of at least 256 reduction steps
-    const long long tiles = (long long)di2p_cdiv(rows, RC_BM) * di2p_cdiv(cols, RC_BM) * Z;
+    const long long tiles = (long long)di2p_cdiv(rows, bm) * di2p_cdiv(cols, bm) * Z;
     int chunks = (int)((1024 + tiles - 1) / tiles);
     const int max_chunks = R / 256 > 1 ? R / 256 : 1;
     if (chunks > max_chunks) chunks = max_chunks;
@@ -253,13 +358,18 @@ inline bool rc_vec_ok(const float* base, long long ld, long long batch_stride, i
 template <class LA, class LB>
 int rc_launch(const char* who, LA la, LB lb, int Z, int rows, int cols, int R, float alpha, bool reduce_z, float* out, void* ws, long long ws_bytes,
               hipStream_t st, bool a_vec = false, bool b_vec = false) {
-    const RcPlan pl = rc_plan(Z, rows, cols, R);
+    bool big = false;
+    if constexpr (std::is_same<LA, RcStrided>::value && std::is_same<LB, RcStrided>::value) big = a_vec && b_vec && rc_big(rows, cols);
+    const RcPlan pl = rc_plan(Z, rows, cols, R, big ? RC2_BM : RC_BM);
     if (!ws || ws_bytes < pl.bytes) { di2p_set_error("%s: workspace too small (%lld bytes needed)", who, pl.bytes); return -1; }
     if ((long long)Z * pl.chunks > 65535) { di2p_set_error("%s: too many reduction chunks", who); return -1; }
-    const dim3 grid(di2p_cdiv(cols, RC_BM), di2p_cdiv(rows, RC_BM), Z * pl.chunks);
+    const dim3 grid(di2p_cdiv(cols, big ? RC2_BM : RC_BM), di2p_cdiv(rows, big ? RC2_BM : RC_BM), Z * pl.chunks);
     const size_t lds = RC_LDS_FLOATS * sizeof(float);
     if constexpr (std::is_same<LA, RcStrided>::value && std::is_same<LB, RcStrided>::value) {
-        if (a_vec && b_vec) hipLaunchKernelGGL((rc_gemm_kernel<true, true, LA, LB>), grid, dim3(256), lds, st, la, lb, R, pl.rch, pl.chunks, (float*)ws, rows, cols);
+        if (big) {
+            (void)hipFuncSetAttribute((const void*)rc_gemm128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RC2_LDS_FLOATS * sizeof(float)));
+            hipLaunchKernelGGL(rc_gemm128_kernel, grid, dim3(256), RC2_LDS_FLOATS * sizeof(float), st, la, lb, R, pl.rch, pl.chunks, (float*)ws, rows, cols);
+        } else if (a_vec && b_vec) hipLaunchKernelGGL((rc_gemm_kernel<true, true, LA, LB>), grid, dim3(256), lds, st, la, lb, R, pl.rch, pl.chunks, (float*)ws, rows, cols);
         else hipLaunchKernelGGL((rc_gemm_kernel<false, false, LA, LB>), grid, dim3(256), lds, st, la, lb, R, pl.rch, pl.chunks, (float*)ws, rows, cols);
     } else if constexpr (std::is_same<LA, RcStrided>::value) {
         if (a_vec) hipLaunchKernelGGL((rc_gemm_kernel<true, false, LA, LB>), grid, dim3(256), lds, st, la, lb, R, pl.rch, pl.chunks, (float*)ws, rows, cols);
@@ -734,7 +844,8 @@ extern "C" int di2p_channel_sum(const float* x, float* out, int B, int C, int N,
 
 extern "C" long long di2p_bmm_rc_workspace_bytes(int Z, int rows, int cols, int R) {
     if (Z < 1 || rows < 1 || cols < 1 || R < 1) return 0;
-    return rc_plan(Z, rows, cols, R).bytes;
+    const long long b64 = rc_plan(Z, rows, cols, R).bytes, b128 = rc_plan(Z, rows, cols, R, RC2_BM).bytes;      // (whichever kernel the call takes)
+    return b64 > b128 ? b64 : b128;
 }
 
 extern "C" int di2p_bmm_rc(const float* A, long long lda, long long a_batch_stride, const float* Bm, long long ldb, long long b_batch_stride, float* out,

@@ -35,7 +35,8 @@ def _run_pair(fn_dev, fn_ref, tensors, tol=2e-5, grads=None):
         _close(d.grad, r.grad, tol, "gradient of input %d" % i)
 
 
-@pytest.mark.parametrize("B,K,M,N", [(2, 7, 32, 1024), (3, 96, 128, 515), (1, 736, 256, 2048), (2, 128, 2, 640), (2, 67, 256, 128 * 16)])
+@pytest.mark.parametrize("B,K,M,N", [(2, 7, 32, 1024), (3, 96, 128, 515), (1, 736, 256, 2048), (2, 128, 2, 640), (2, 67, 256, 128 * 16),
+                                     (2, 200, 384, 2048), (3, 132, 130, 4100)])      # (the last two: 128 x 128 weight-gradient tiles with ragged edges)
 def test_linear_backward(B, K, M, N):
     from deepi2p_amd import train_net as tn
     g = torch.Generator().manual_seed(B * 1000 + K)
