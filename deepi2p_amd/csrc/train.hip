@@ -724,6 +724,56 @@ __global__ __launch_bounds__(256) void maxpool_backward_kernel(const float* __re
     dx[i] = g;
 }
 
+// The same gradient with the windows' arg-maxima computed ONCE: a workgroup owns MPB_R output rows of one plane -- it stages the 2 R + 3 input
+// rows their windows and their neighbours' touch in LDS, finds the first maximum of the (R + 1) x OW windows that reach its 2 R input rows
+// (nine LDS reads each instead of 36 memory reads per input pixel), and every input pixel then adds the gradients of the <= 4 windows it won,
+// in the same (oy, ox) order: the same bits.
+constexpr int MPB_R = 4;
+__global__ __launch_bounds__(256) void maxpool_backward_lds_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int H, int W,
+                                                                   int OH, int OW) {
+    extern __shared__ float mp_lds[];
+    float* xs = mp_lds;                                   // [2 R + 3][W]: input rows 2 oy0 - 1 ..
+    int* arg = reinterpret_cast<int*>(mp_lds + (2 * MPB_R + 3) * W);     // [R + 1][OW]: linear index (iy * W + ix) of the window's first maximum
+    const int oy0 = blockIdx.x * MPB_R;
+    const long long plane = blockIdx.y;
+    const float* xp = x + plane * H * W;
+    const float* dyp = dy + plane * OH * OW;
+    const int y_lo = 2 * oy0 - 1;
+    for (int i = threadIdx.x; i < (2 * MPB_R + 3) * W; i += 256) {
+        const int r = i / W, yy = y_lo + r;
+        xs[i] = (yy >= 0 && yy < H) ? xp[yy * W + (i - r * W)] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (MPB_R + 1) * OW; i += 256) {
+        const int wr = i / OW, oy = oy0 + wr, ox = i - wr * OW;
+        float best = 0.0f;
+        int a = -1;
+        if (oy < OH) {
+            for (int ky = 0; ky < 3; ++ky) {
+                const int yy = oy * 2 - 1 + ky;
+                if (yy < 0 || yy >= H) continue;
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int xx = ox * 2 - 1 + kx;
+                    if (xx < 0 || xx >= W) continue;
+                    const float v = xs[(yy - y_lo) * W + xx];
+                    if (a < 0 || v > best) { best = v; a = yy * W + xx; }
+                }
+            }
+        }
+        arg[i] = a;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * MPB_R * W; i += 256) {
+        const int r = i / W, iy = 2 * oy0 + r, ix = i - r * W;
+        if (iy >= H) break;
+        float g = 0.0f;
+        for (int oy = max(iy / 2, 0); oy <= min((iy + 1) / 2, OH - 1); ++oy)
+            for (int ox = max(ix / 2, 0); ox <= min((ix + 1) / 2, OW - 1); ++ox)
+                if (arg[(oy - oy0) * OW + ox] == iy * W + ix) g += dyp[oy * OW + ox];
+        dx[plane * H * W + iy * W + ix] = g;
+    }
+}
+
 // dX[b][c][max_idx[b][c][m]] += dV[b][c][m] * mask[b][m]   (index_max + gather + mask of networks_pc.py:88-93,101-104)
 __global__ __launch_bounds__(256) void segment_max_backward_kernel(const float* __restrict__ dv, const int* __restrict__ max_idx, const float* __restrict__ mask,
                                                                    float* __restrict__ dx, int C, int N, int M, long long total) {
@@ -922,6 +972,11 @@ extern "C" int di2p_maxpool3x3s2_backward(const float* x, const float* dy, float
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
     hipStream_t st = (hipStream_t)stream;
     const long long total = (long long)B * C * H * W;
+    const size_t lds = ((size_t)(2 * MPB_R + 3) * W + (size_t)(MPB_R + 1) * OW) * 4;
+    if (lds <= 64 * 1024 && (long long)B * C <= 65535) {
+        hipLaunchKernelGGL(maxpool_backward_lds_kernel, dim3(di2p_cdiv(OH, MPB_R), B * C), dim3(256), lds, st, x, dy, dx, H, W, OH, OW);
+        DI2P_RETURN_LAUNCH();
+    }
     hipLaunchKernelGGL(maxpool_backward_kernel, dim3(di2p_cdiv(total, 256)), dim3(256), 0, st, x, dy, dx, H, W, OH, OW, total);
     DI2P_RETURN_LAUNCH();
 }

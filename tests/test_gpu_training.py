@@ -138,6 +138,9 @@ def test_maxpool_avgpool_backward():
     g = torch.Generator().manual_seed(3)
     x = torch.relu(torch.randn(2, 16, 32, 64, generator=g))          # exact zeros: ties inside the windows
     _run_pair(lambda x: tn._MaxPool.apply(x), lambda x: F.max_pool2d(x, 3, 2, 1), [x])
+    for shape in ((1, 3, 5, 7), (2, 4, 9, 256), (1, 2, 80, 256), (1, 1, 1, 1), (1, 2, 6, 2)):       # odd sizes, several row bands, degenerate planes
+        x = torch.relu(torch.randn(*shape, generator=g))
+        _run_pair(lambda x: tn._MaxPool.apply(x), lambda x: F.max_pool2d(x, 3, 2, 1), [x])
     x = torch.randn(2, 16, 5, 7, generator=g)
     _run_pair(lambda x: tn._AvgPool.apply(x), lambda x: F.adaptive_avg_pool2d(x, (1, 1)), [x])
 
