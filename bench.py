@@ -634,8 +634,9 @@ def main_train(args):
     # Algorithmic work = what autograd of the reference's graph does: forward + dgrad + wgrad = 3 x the forward multiply-accumulates of
     # SURVEY.md 8(d) (coarse + fine model: 13.284 GMAC per frame at 20480 points / 160x512), minus the input gradient of the stem (the
     # image needs none).  Time = HIP events around every contraction call of one serial step.
-    mfma_calls = ("di2p_pointwise_gemm", "di2p_point_head", "di2p_point_chain", "di2p_conv3x3_winograd", "di2p_conv2d", "di2p_conv2d_ws", "di2p_conv7x7s2_stem",
-                  "di2p_conv2d_wgrad", "di2p_conv2d_dgrad", "di2p_bmm_rc", "di2p_bmm_km", "di2p_gather_backward", "di2p_winograd_weight_transform")
+    mfma_calls = ("di2p_pointwise_gemm", "di2p_pointwise_gemm_x3", "di2p_point_head", "di2p_point_chain", "di2p_conv3x3_winograd", "di2p_conv3x3_x3", "di2p_conv2d",
+                  "di2p_conv2d_ws", "di2p_conv7x7s2_stem", "di2p_conv2d_wgrad", "di2p_conv2d_dgrad", "di2p_bmm_rc", "di2p_bmm_km", "di2p_gather_backward",
+                  "di2p_winograd_weight_transform", "di2p_winograd_weight_transform_dgrad", "di2p_bf16x3_pack", "di2p_bf16x3_pack_conv3x3")
     mfma_ms = sum(fam[k][0] for k in mfma_calls if k in fam)
     roofline = None
     if (N, H, W) == (20480, 160, 512) and mfma_ms > 0:
@@ -648,7 +649,8 @@ def main_train(args):
                     "algorithmic_per_launch": algo / max(sum(fam[k][1] for k in mfma_calls if k in fam), 1),
                     "step_fraction": mfma_ms / (1e3 * dt / args.steps),
                     "note": "achieved = reference-algorithmic flops (3 x forward 2*MAC of SURVEY 8d, coarse+fine, minus the stem's input gradient) / "
-                            "summed event time of the contraction calls of one serial step; fp32-input MFMA peak; the rest of the step is "
+                            "summed event time of the contraction calls of one serial step (fp32- and bf16x3-MFMA launches and their filter transforms / "
+                            "splits alike); priced against the fp32-input MFMA peak; the rest of the step is "
                             "BatchNorm statistics / normalisation passes (HBM-bound), routers and the optimiser"}
     if rank == 0:
         top = sorted(fam.items(), key=lambda kv: -kv[1][0])[:10]
@@ -656,7 +658,8 @@ def main_train(args):
                 "value": B * world * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": 1e3 * dt / args.steps, "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32 (fp32-input MFMA contractions, fp64 BatchNorm/bias reductions)", "data": "synthetic frames, seeded He-normal initial weights",
+                "dtype": "f32 (fp32-input MFMA contractions; the big point layers and the 256- / 512-channel 3x3 layers, forward and input gradient: bf16 MFMA on exact "
+                         "three-way fp32 splits, fp32 accumulation; fp64 BatchNorm/bias reductions)", "data": "synthetic frames, seeded He-normal initial weights",
                 "config": {"workload": "reference training configuration kitti/options.py:20-60 (batch 8, 20480 pts, 160x512, coarse+fine, Adam 1e-3)",
                            "mode": "train", "frames_per_gpu_per_step": B, "points": N, "image": [H, W], "parallelism": "dp%d" % world,
                            "weights_broadcast_bytes": bcast_bytes},
