@@ -96,6 +96,7 @@ def parse_args(argv=None):
     ap.add_argument("--points", type=int, default=None)
     ap.add_argument("--restarts", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-graph", action="store_true", help="--mode train, one GPU: forward + losses + backward of a step replayed from one hipGraph (ClassifierTrainer.optimize_graphed)")
     ap.add_argument("--streams", type=int, default=None,
                     help="HIP streams = batches in flight (1 = fully serial); default 8 for the frames mode (with GPU_MAX_HW_QUEUES=16, "
                          "set below unless the environment already has it), 3 otherwise")
@@ -599,12 +600,13 @@ def main_train(args):
         torch.cuda.synchronize()
 
     losses = []
+    step_fn = tr.optimize_graphed if (getattr(args, "train_graph", False) and world == 1) else tr.optimize
     for _ in range(args.warmup):
-        losses.append(tr.optimize(*t, K, Pgt)["loss"])
+        losses.append(step_fn(*t, K, Pgt)["loss"].clone())
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses.append(tr.optimize(*t, K, Pgt)["loss"])
+        losses.append(step_fn(*t, K, Pgt)["loss"].clone())
     t_enqueue = time.perf_counter() - t0          # host time to enqueue the steps (close to dt: the step is launch-bound)
     sync_all()
     dt = time.perf_counter() - t0
@@ -662,6 +664,7 @@ def main_train(args):
                          "three-way fp32 splits, fp32 accumulation; fp64 BatchNorm/bias reductions)", "data": "synthetic frames, seeded He-normal initial weights",
                 "config": {"workload": "reference training configuration kitti/options.py:20-60 (batch 8, 20480 pts, 160x512, coarse+fine, Adam 1e-3)",
                            "mode": "train", "frames_per_gpu_per_step": B, "points": N, "image": [H, W], "parallelism": "dp%d" % world,
+                           "step": "optimize_graphed (forward + losses + backward replayed from one hipGraph)" if step_fn is not tr.optimize else "optimize (eager launches)",
                            "weights_broadcast_bytes": bcast_bytes},
                 "gradient_allreduce": {"bytes": int(tr.flat_grad.numel() * 4), "ms": ar_ms, "launches_per_step": 1},
                 "roofline": roofline,

@@ -167,6 +167,78 @@ class ClassifierTrainer:
         self.detector._invalidate()          # the packed inference operands (folded BN, transposed weights) are stale now
         return L
 
+    # ------------------------------------------------------------------ the same step, forward + losses + backward replayed from ONE hipGraph
+    def _capture(self, inputs):
+        """Static copies of the step's inputs and dropout masks, two eager passes on a side stream (first-use allocations and library
+        set-up happen outside the capture; the BatchNorm buffers they touch are put back), then the capture of zero-gradients + forward +
+        losses + backward."""
+        dev = inputs[0].device
+        self._g_in = [x.clone() for x in inputs]
+        P = self.tensors()
+        c0, c1 = train_net.head_widths(P)
+        B, N = inputs[0].shape[0], inputs[0].shape[2]
+        self._g_masks = [torch.empty((B, c, N), dtype=torch.uint8, device=dev) for c in (c0, c1)]
+        for i, m in enumerate(self._g_masks):
+            m.copy_(train_net.dropout_mask(tuple(m.shape), 0.5, self.seed, 2 * self.steps + i, dev))
+        buffers = [(b, b.clone()) for _, b in self.detector.named_buffers()]
+        # one stream inside the capture: with the eager step's branch streams captured as parallel branches the replay measured 22.9 ms per step
+        # (8 ms of it host time inside the graph launch) against 14.8 ms without them (eager: 13.9 with, 15.0 without; profiles/r06_c42_train_graph.txt)
+        had, old = hasattr(self.opt, "branch_streams"), getattr(self.opt, "branch_streams", None)
+        self.opt.branch_streams = False
+
+        def fwd_bwd():
+            self.flat_grad.zero_()
+            scores, L = self.forward_pass(*self._g_in, True, self._g_masks)
+            d = L["d_coarse"] if L["d_fine"] is None else torch.cat((L["d_coarse"], L["d_fine"]), dim=1)
+            scores.backward(d)
+            return L
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                fwd_bwd()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        with torch.no_grad():
+            for b, saved in buffers:
+                b.copy_(saved)
+        self._g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(self._g):
+                self._g_L = fwd_bwd()
+        finally:
+            if had:
+                self.opt.branch_streams = old
+            else:
+                del self.opt.branch_streams
+        self._g_key = tuple(tuple(x.shape) for x in inputs)
+
+    def optimize_graphed(self, pc, intensity, sn, node_a, node_b, img, K, P_gt):
+        """optimize() with zero-gradients + forward + losses + backward replayed from one captured hipGraph (the ~1000 launches of a step become
+        one); inputs are copied into the capture's static buffers, the dropout masks are drawn into them with the step's seeds, the
+        gradient exchange and Adam run eagerly behind the replay.  Same kernels on the same values as optimize(): the same parameters after
+        every step (tests/test_gpu_training.py).  NOT the default and not faster: the step is bound by its kernels, not by their launches
+        (measured at batch 8: 14.8 ms against 13.9 ms for the eager step, which overlaps the image and point branches on two streams;
+        0.3 ms of host time per step instead of 11-13 -- the reason to use it is a busy host).  Single process only (the multi-process fine-loss rescale needs a collective inside the
+        step); the capture is redone when an input shape changes.  The returned dict's tensors are the capture's: read them before the
+        next call."""
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            return self.optimize(pc, intensity, sn, node_a, node_b, img, K, P_gt)
+        inputs = (pc, intensity, sn, node_a, node_b, img, K, P_gt)
+        if getattr(self, "_g", None) is None or self._g_key != tuple(tuple(x.shape) for x in inputs):
+            self._capture(inputs)
+        for dst, src in zip(self._g_in, inputs):
+            dst.copy_(src)
+        for i, m in enumerate(self._g_masks):
+            m.copy_(train_net.dropout_mask(tuple(m.shape), 0.5, self.seed, 2 * self.steps + i, m.device))
+        self._g.replay()
+        self.adam.step(self.flat_grad)
+        self.steps += 1
+        self.detector._invalidate()
+        return self._g_L
+
     def test_model(self, pc, intensity, sn, node_a, node_b, img, K, P_gt):
         self.detector.eval()
         return self.forward_pass(pc, intensity, sn, node_a, node_b, img, K, P_gt, train=False, want_grads=False)[1]

@@ -287,6 +287,34 @@ def test_trainer_optimises_and_eval_path_follows():
     print("losses", ["%.3f" % v for v in losses], "eval loss %.3f coarse acc %.3f" % (float(ev["loss"]), float(ev["coarse_accuracy"])))
 
 
+def test_graphed_step_equals_eager_step():
+    """ClassifierTrainer.optimize_graphed replays zero-gradients + forward + losses + backward from one captured hipGraph: the same kernels on the
+    same values -- two trainers from the same weights, one eager and one graphed, hold the same parameters, BatchNorm buffers and losses after
+    every step (the capture's warm-up passes must leave no trace in the BatchNorm statistics)."""
+    from deepi2p_amd import networks, synthetic
+    from deepi2p_amd.training import ClassifierTrainer
+    B, N, H, W = 2, 2048, 64, 128
+    opt = synthetic.OptLike(N, H, W, True)
+    opt.lr, opt.coarse_loss_alpha = 1e-3, 50.0
+    sd = synthetic.random_state_dict(opt, 11)
+    trs = []
+    for _ in range(2):
+        det = networks.KeypointDetector(opt)
+        det.load_state_dict(sd)
+        trs.append(ClassifierTrainer(det.to(DEV), opt, seed=3))
+    for step in range(4):
+        b = synthetic.make_batch(40 + step, B, N=N, H=H, W=W)
+        t = [torch.from_numpy(np.ascontiguousarray(b[k])).to(DEV) for k in ("pc", "intensity", "sn", "node_a", "node_b", "img")]
+        K = torch.from_numpy(b["K"]).float().to(DEV)
+        Pgt = torch.from_numpy(np.ascontiguousarray(b["P_gt"][:, :3, :])).float().to(DEV)
+        Le = trs[0].optimize(*t, K, Pgt)
+        Lg = trs[1].optimize_graphed(*t, K, Pgt)
+        assert float(Le["loss"]) == float(Lg["loss"]), (step, float(Le["loss"]), float(Lg["loss"]))
+        assert torch.equal(trs[0].flat, trs[1].flat), step
+    for (ka, va), (kb, vb) in zip(trs[0].detector.state_dict().items(), trs[1].detector.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka
+
+
 def test_gradient_sinks_equal_autograd_accumulation():
     """ClassifierTrainer makes the backward kernels write each parameter's gradient straight into its slice of the flat buffer;
     the result must equal what autograd hands back for the same kernels (tolerance 1e-5, kept from when the max-pool backward added
