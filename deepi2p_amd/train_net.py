@@ -137,6 +137,8 @@ def _conv3x3_x3(x, W, dgrad):
     one, zero = _unit_affine(Cdst, x.device)
     Wp = ops.bf16x3_pack_conv3x3(_c(W), dgrad=dgrad)
     small = x.shape[0] < 16 and _lib.get_option("conv_x3_cfg") < 0
+    # (the knob is process-wide and set for the duration of ONE launch call: a training step and an inference executor must not run on two
+    #  threads of one process at the same time -- the reference trains and evaluates in turn, kitti/train_classifier.py:54-154)
     if small:        # few frames: the smallest tile configuration fills more of the chip (the library prices its choice for 32 frames)
         _lib.set_option("conv_x3_cfg", 3)
         if not ops.conv3x3_x3_supported(x.shape, Cdst, 1):        # ... where it runs the shape at all
